@@ -1,0 +1,203 @@
+/*
+ * musev_hip.h -- C ABI of libmusev_hip.so, the MI355X (gfx950) kernel library behind
+ * musev_amd.models.UNet3DConditionModel and musev_amd.pipelines (the MuseV parallel-denoise hot path).
+ *
+ * The reference (TMElyralab/MuseV) is 100 % Python and has no FFI boundary of its own: every entry point
+ * below replaces a *torch / xformers / diffusers call site* on the hot path, cited per function as
+ * "replaces: <reference file:line>".  Conventions:
+ *   - extern "C", plain device pointers + explicit sizes/strides; no torch types, no ownership transfer,
+ *     no hidden allocation (scratch is passed in by the caller), no global mutable state except the
+ *     thread-local last-error string.
+ *   - every launch goes to the hipStream_t passed as `stream` (void* so that C callers need no HIP headers).
+ *   - return value: 0 = ok, negative = MV_ERR_*; mv_last_error() returns a human-readable message.
+ *   - storage dtype: IEEE fp16 ("half") for activations and packed weights, fp32 accumulation and
+ *     statistics.  Activation layout is channels-last: [B, T, H, W, C] (== rows x C matrices).
+ */
+#ifndef MUSEV_HIP_H
+#define MUSEV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_OK 0
+#define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define MV_ERR_LAUNCH (-2)    /* HIP launch error */
+
+#define MV_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int mv_abi_version(void);
+const char* mv_last_error(void);
+
+/* ---- implicit GEMM family (K2 conv3x3, K3 linear / 1x1 conv, K4 temporal conv) --------------------
+ * out[m, n] = act( alpha * ( sum_k A(m, k) * W[n, k] + bias[n] + rowbias[m / rows_per_group, n] ) )
+ *             + residual[m, n]
+ * replaces: torch.nn.Linear / Conv2d(1x1) / Conv2d(3x3) / Conv3d((3,1,1)) calls inside
+ *   diffusers ResnetBlock2D / Downsample2D / Upsample2D (constructed at musev/models/unet_3d_blocks.py:272-345,486-571),
+ *   musev/models/resnet.py:57-82 (TemporalConvLayer conv1..4), musev/models/transformer_2d.py:257-271,365-389
+ *   (proj_in / proj_out), diffusers Attention.to_q/to_k/to_v/to_out (musev/models/attention_processor.py:501-533),
+ *   FeedForward (musev/models/attention.py:398-429), musev/models/temporal_transformer.py:243-251,276.
+ */
+#define MV_GEMM_LINEAR 0   /* A(m,k) = a[m*lda + k]  (k < c1) or a2[m*lda2 + k - c1]                   */
+#define MV_GEMM_CONV3X3 1  /* A gathers a 3x3 neighbourhood of an NHWC image, zero padding 1           */
+#define MV_GEMM_TCONV3 2   /* A gathers frames t-1, t, t+1 of a [B,T,HW,C] tensor, zero padding in t   */
+
+#define MV_ACT_NONE 0
+#define MV_ACT_SILU 1
+
+typedef struct mv_gemm_desc {
+    const void* a;         /* fp16 source 1                                                            */
+    const void* a2;        /* fp16 source 2 (channel-concatenated after source 1) or NULL              */
+    const void* w;         /* fp16 packed weight [N][K], K = taps * (c1 + c2), tap-major, channel-minor */
+    void* c;               /* fp16 output [M][ldc]                                                     */
+    const void* bias;      /* fp16 [N] or NULL                                                         */
+    const void* rowbias;   /* fp16 [M / rows_per_group][ldrb] or NULL (time / frame embedding add)     */
+    const void* residual;  /* fp16 [M][ldr] or NULL                                                    */
+    const float* alpha;    /* device scalar; |*alpha| is used (temporal_weight); NULL -> 1.0           */
+    int64_t M;
+    int32_t N, K;
+    int32_t lda, lda2, ldc, ldr, ldrb;  /* leading dimensions in elements                              */
+    int32_t c1, c2;        /* channels of source 1 / 2 (c2 = 0 when a2 == NULL)                        */
+    int32_t mode;          /* MV_GEMM_*                                                                */
+    int32_t stride;        /* conv3x3: 1 or 2                                                          */
+    int32_t upsample;      /* conv3x3: 1 = input is nearest-upsampled x2 on the fly                    */
+    int32_t hin, win;      /* conv3x3: source image size (before upsample)                             */
+    int32_t hout, wout;    /* conv3x3: output image size                                               */
+    int32_t t, hw;         /* tconv3: frames per batch item, pixels per frame                          */
+    int32_t rows_per_group;/* rowbias row = m / rows_per_group                                         */
+    int32_t act;           /* MV_ACT_*                                                                 */
+    int32_t geglu;         /* 1: w rows are [value | gate] interleaved per 16; out[m, n] for n < N/2 = */
+                           /*    value * gelu(gate) (N is the full 2x width, ldc counts N/2 columns)   */
+} mv_gemm_desc;
+
+int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
+
+/* ---- GroupNorm (K1) --------------------------------------------------------------------------------
+ * replaces: torch.nn.GroupNorm(32, C)(+SiLU) in ResnetBlock2D.norm1/norm2, Transformer2DModel.norm
+ *   (musev/models/transformer_2d.py:260), TransformerTemporalModel.norm (temporal_transformer.py:117,239),
+ *   TemporalConvLayer conv*[0] (resnet.py:57-75; statistics span T*H*W: pass rows = T*H*W, groups_n = B),
+ *   conv_norm_out (unet_3d_condition.py:562-568).
+ * x: [n_items][rows][c1] (+ optional second source [n_items][rows][c2], channel-concatenated),
+ * y: [n_items][rows][c1+c2].  partial: fp32 scratch [n_items][nsplit][2][c1+c2];
+ * scale_shift: fp32 scratch [n_items][2][c1+c2].
+ */
+int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
+                     int64_t n_items, int64_t rows, int32_t num_groups, float eps,
+                     const void* gamma, const void* beta, int32_t silu,
+                     void* y, int32_t ldy, float* partial, int32_t nsplit, float* scale_shift,
+                     void* stream);
+/* scratch sizes (in floats) for the call above */
+int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t c, int32_t nsplit);
+int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c);
+
+/* ---- LayerNorm over the channel dim (K5) -------------------------------------------------------------
+ * replaces: nn.LayerNorm norm1/norm2/norm3 of BasicTransformerBlock (musev/models/attention.py:186,345,399). */
+int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t c,
+                     const void* gamma, const void* beta, float eps, void* stream);
+
+/* ---- fused softmax attention (K6a/b/d) ---------------------------------------------------------------
+ * out[n, q, h*d:(h+1)*d] (=, or += out_scale *)  softmax_j( scale * <Q[n,q,h], K_seg[.., j, h]> ) V_seg[.., j, h]
+ * over the concatenation of up to MV_ATTN_MAX_SEG key/value segments (no concat copy is made).
+ * Segment s serves query batch n from key/value batch  kvb = (n / div) * mul + add.
+ * replaces: xformers.ops.memory_efficient_attention at musev/models/attention_processor.py:258 (text
+ *   cross-attn), :292 (IP-Adapter second attention -> accumulate=1,out_scale=ip_adapter_scale), :519
+ *   (reference-only self-attn: segments = [self frame, vision-condition frame(s), (referencenet tokens)]),
+ *   :724 (ReferEmbFuseAttention: segments = [referencenet tokens, self frame]).
+ */
+#define MV_ATTN_MAX_SEG 4
+typedef struct mv_attn_seg {
+    const void* k;     /* fp16, row (kvb * len + j) at k + row*ldk, head h at column h*d                */
+    const void* v;
+    int32_t ldk, ldv;
+    int32_t len;       /* keys per batch item                                                          */
+    int32_t div, mul, add;
+} mv_attn_seg;
+
+typedef struct mv_attn_desc {
+    const void* q;     /* fp16 [nb][lq][ldq]                                                           */
+    void* out;         /* fp16 [nb][lq][ldo]                                                           */
+    int32_t ldq, ldo;
+    int32_t nb, lq, heads, d;
+    float scale;
+    int32_t nseg;
+    mv_attn_seg seg[MV_ATTN_MAX_SEG];
+    int32_t accumulate; /* 0: out = attn ; 1: out += out_scale * attn                                   */
+    float out_scale;
+} mv_attn_desc;
+
+int mv_attention_f16(const mv_attn_desc* d, void* stream);
+
+/* ---- temporal self-attention over T <= 32 frames per pixel (K6c) -------------------------------------
+ * rows are ordered (b, t, p): sequence of pixel (b, p) = rows (b*T + t)*HW + p, t = 0..T-1.
+ * replaces: F.scaled_dot_product_attention through diffusers AttnProcessor2_0 in the temporal
+ *   BasicTransformerBlock (attn1 and attn2, double_self_attention) musev/models/temporal_transformer.py:157-177,
+ *   musev/models/attention.py:293-308,354-366 -- without the (b t) c h w <-> (b h w) t c permute copies
+ *   of temporal_transformer.py:234-241,277-279. */
+int mv_temporal_attention_f16(const void* q, const void* k, const void* v, int32_t ldq, int32_t ldk, int32_t ldv,
+                              void* out, int32_t ldo, int32_t b, int32_t t, int32_t hw, int32_t heads,
+                              int32_t d, float scale, void* stream);
+
+/* ---- GEGLU gate (K7): y[m, j] = x[m, j] * gelu(x[m, half + j]) -----------------------------------------
+ * replaces: diffusers GEGLU inside FeedForward (musev/models/attention.py:398-429). */
+int mv_geglu_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t half_cols, void* stream);
+
+/* ---- small-channel 3x3 convolutions (conv_in: Cin = 4, conv_out: Cout = 4) ----------------------------
+ * replaces: self.conv_in / self.conv_out (musev/models/unet_3d_condition.py:334-339,570-575,1009,1262). */
+int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
+                             const void* add /* optional [rows][cout] (pose_guider_emb) */, void* y,
+                             int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
+int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
+                              void* y, int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
+
+/* ---- elementwise helpers -------------------------------------------------------------------------------*/
+/* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift=0): out[i, :] = [cos(t_i f), sin(t_i f)]           */
+/* replaces: diffusers Timesteps in self.time_proj / self.frame_proj (unet_3d_condition.py:343,354,888,918) */
+int mv_timestep_embedding_f16(const float* t, int32_t n, int32_t dim, void* out, void* stream);
+int mv_silu_f16(const void* x, void* y, int64_t n, void* stream);
+/* y = a + b (fp16), used for ControlNet residual adds (unet_3d_condition.py:1146-1156,1195)               */
+int mv_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* rows of x selected by zeroing: y[g, :] = 0 for group rows flagged in mask (temb zeroing of the          */
+/* vision-condition frames, unet_3d_condition.py:898-906)                                                   */
+int mv_zero_rows_f16(void* x, int32_t ld, const int32_t* row_idx, int32_t n_idx, int32_t cols, void* stream);
+/* layout: [B, C, T, H, W] (fp16 or fp32) -> channels-last fp16 [B, T, H, W, C] and back                    */
+/* replaces: rearrange(sample, "b c t h w -> (b t) c h w") and its inverse (unet_3d_condition.py:1008,1263) */
+int mv_bcthw_to_bthwc_f16(const void* x, int32_t x_is_f32, void* y, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);
+int mv_bthwc_to_bcthw_f16(const void* x, void* y, int32_t y_is_f32, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);
+
+/* ---- sliding-window denoise loop glue (K12) -----------------------------------------------------------
+ * mv_window_gather: builds the UNet input of one window, channels-last fp16 [2?][n_cond + win][HW][C]:
+ *   cond frames first (from cond_latents), then latents[:, :, idx[k]] (both CFG halves get the same data).
+ * replaces: musev/pipelines/pipeline_controlnet.py:1902-1946 (gather, CFG repeat, scale_model_input (identity
+ *   for DDIM), batch_concat_two_tensor_with_index).
+ * latents: fp32 [C][T_total][HW] (batch 1), cond: fp32 [C][n_cond][HW].
+ */
+int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
+                     int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, void* out, void* stream);
+/* mv_window_scatter_add: eps_acc[half][C][T_total][HW] += eps_win (channels-last fp16 [halves][n_cond+win][HW][C],
+ *   cond frames dropped); counter[T_total] += 1.
+ * replaces: pipeline_controlnet.py:2068-2078. */
+int mv_window_scatter_add(const void* eps_win, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
+                          int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset,
+                          float* eps_acc, float* counter, int32_t add_counter, void* stream);
+/* mv_cfg_ddim_step: eps = acc / counter; eps = eps_u + g (eps_t - eps_u); DDIM (eta = 0, epsilon prediction):
+ *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps   (in place on latents)
+ * replaces: pipeline_controlnet.py:2079,2101-2117 + musev/schedulers/scheduling_ddim.py:198-264. */
+int mv_cfg_ddim_step(float* latents, const float* eps_acc, const float* counter, int32_t c, int32_t t_total,
+                     int32_t hw, int32_t halves, float guidance, float alpha_t, float alpha_prev, void* stream);
+
+/* ---- weight packing -------------------------------------------------------------------------------------
+ * conv weight [O][I][kh][kw] (torch layout, fp16 or fp32) -> [O][kh][kw][I] fp16;  Conv3d [O][I][3][1][1] -> [O][3][I]
+ * replaces: nothing in the reference (torch consumes its native layout); lets real checkpoints (state_dict keys
+ * of SURVEY.md 8b) feed the kernels above. */
+int mv_pack_conv_weight_f16(const void* w, int32_t w_is_f32, void* out, int32_t o, int32_t i, int32_t taps, void* stream);
+
+/* ---- instrumentation: hardware layout probes used by tests (not on the product path) ------------------ */
+int mv_probe_tr16(const void* lds_image /* 1024 x int16 */, void* out /* 64 x 4 x int16 */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSEV_HIP_H */

@@ -1,0 +1,443 @@
+// attention.hip -- fused softmax attention for gfx950 (MFMA 16x16x32 f16, fp32 online softmax).
+//
+// mv_attention_f16: flash-style forward over up to 4 key/value SEGMENTS that share one softmax.  The
+// reference concatenates [self tokens | vision-condition-frame tokens | referencenet tokens] into one K/V
+// source before to_k/to_v (attention_processor.py:431-493); because to_k/to_v are row-wise linear, the
+// projections of the shared tokens are identical for every frame, so here K/V are projected ONCE per source
+// tensor and each query frame walks the segments in place (no concat copy, no repeated projection).
+//
+// Work decomposition: grid = (q tiles of 128, heads, frames); block = 4 waves; each wave owns 32 query rows
+// (two 16-row MFMA tiles) and the block streams 64-row K/V tiles through LDS (register-prefetched).
+//   S^T = K Q^T  (operands swapped so a lane holds ONE query column and 16 key scores -> the row max / row sum
+//                 are in-lane plus two xor-shuffles over the 4 lane groups; no LDS round trip for P)
+//   O^T = V^T P^T with the MFMA k-index permuted as kv = 32c + 16*(j/4) + 4g + (j%4): the exp'd scores feed the
+//                 second MFMA straight from the accumulator registers, and V^T fragments come from the row-major
+//                 V tile through ds_read_b64_tr_b16 (hardware 4x16 transpose read).
+// Head dims 40 / 80 / 160 (SD-1.5: C/8): the QK^T contraction is zero-padded to 64 / 96 / 160, O^T uses 3 / 5 / 10
+// d-tiles of 16.
+//
+// mv_temporal_attention_f16: the temporal transformer's sequences are 13 tokens long (12 frames + 1 condition
+// frame), one sequence per pixel and head -- far too small for MFMA tiles.  One 16/32-lane group per (pixel, head),
+// lane = query frame, fp32 VALU dot products; rows stay in (b, t, p) order so no permute copy is needed.
+#include "common.h"
+
+namespace {
+
+struct SegArgs {
+    const half_t* k;
+    const half_t* v;
+    int ldk, ldv, len, div, mul, add;
+};
+
+struct AttnArgs {
+    const half_t* q;
+    half_t* out;
+    int ldq, ldo, nb, lq, heads;
+    float scale_log2e;
+    int nseg;
+    SegArgs seg[MV_ATTN_MAX_SEG];
+    int accumulate;
+    float out_scale;
+};
+
+template <int D>
+struct AttnCfg {
+    static constexpr int DP = ((D + 31) / 32) * 32;  // padded QK^T contraction length
+    static constexpr int NC = DP / 32;               // 32-wide k chunks
+    static constexpr int NDT = (D + 15) / 16;        // O^T d-tiles
+    static constexpr int DCH = D / 8;                // 16-byte chunks per row of real data
+    static constexpr int KRS = DP + 8;               // K tile row stride (halfs): odd number of 16-byte slots
+    static constexpr int VRS = NDT * 16 + 8;         // V tile row stride (halfs): odd number of 16-byte slots
+    static constexpr int KV = 64;                    // keys per tile
+    static constexpr int QT = (D > 80) ? 1 : 2;      // 16-row query tiles per wave (register budget at d = 160)
+    static constexpr int QB = 64 * QT;               // query rows per block
+    static constexpr int CHUNKS = KV * DCH;          // 16-byte chunks per K (or V) tile
+    static constexpr int PF = (2 * CHUNKS + 255) / 256;  // prefetch registers (uint4) per thread for K+V
+    static constexpr int LDS_HALFS = KV * KRS + KV * VRS;
+};
+
+
+__device__ __attribute__((aligned(16))) uint4 g_attn_zero[4];
+
+// uniform per-field selects instead of p.seg[s]: a dynamic index into the by-value kernel argument (or a struct
+// copy of it) would be materialised in scratch memory
+#define ATTN_SEG_FIELD(p, s, f) ((s) == 0 ? (p).seg[0].f : (s) == 1 ? (p).seg[1].f : (s) == 2 ? (p).seg[2].f : (p).seg[3].f)
+
+// Per-thread description of the 16-byte chunks this thread stages for every K/V tile of the current segment.
+template <int D>
+struct AttnStage {
+    long goff[AttnCfg<D>::PF];  // element offset of the chunk inside a tile (row * ld + ch * 8), per-segment
+    int row[AttnCfg<D>::PF];    // tile row of the chunk (for the tail predicate); >= KV marks "no chunk"
+    int loff[AttnCfg<D>::PF];   // LDS offset in halfs (K region first, V region after)
+    bool isv[AttnCfg<D>::PF];
+};
+
+// Issue the global loads of the K/V tile starting at key `b0` into registers (no wait).  Rows past the segment
+// end read the zero page, so masked keys carry finite (zero) K and V rows.
+template <int D>
+__device__ __forceinline__ void attn_prefetch(u32x4 (&pf)[AttnCfg<D>::PF], const AttnStage<D>& st, const half_t* kb,
+                                              const half_t* vb, long ldk, long ldv, int b0, int len,
+                                              const half_t* zero) {
+    using C = AttnCfg<D>;
+    const half_t* kt = kb + (long)b0 * ldk;  // uniform tile bases
+    const half_t* vt = vb + (long)b0 * ldv;
+#pragma unroll
+    for (int i = 0; i < C::PF; ++i) {
+        const bool ok = (b0 + st.row[i]) < len;
+        const half_t* ptr = (st.isv[i] ? vt : kt) + st.goff[i];
+        ptr = ok ? ptr : zero;
+        pf[i] = *reinterpret_cast<const u32x4*>(ptr);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void attn_commit(const u32x4 (&pf)[AttnCfg<D>::PF], const AttnStage<D>& st, half_t* lds) {
+    using C = AttnCfg<D>;
+#pragma unroll
+    for (int i = 0; i < C::PF; ++i) {
+        if (st.row[i] < C::KV) *reinterpret_cast<u32x4*>(lds + st.loff[i]) = pf[i];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) half_t lds[C::LDS_HALFS];
+    half_t* sK = lds;
+    half_t* sV = lds + C::KV * C::KRS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const int n = blockIdx.z;
+    const int q0 = blockIdx.x * C::QB + wave * (16 * C::QT);
+
+    // zero the K tile once: the padded contraction columns [D, DP) must read as 0 forever
+    for (int i = tid; i < C::KV * C::KRS / 8; i += 256) reinterpret_cast<uint4*>(sK)[i] = uint4{0, 0, 0, 0};
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l15][d = 32c + 8g .. +8] ----
+    half8v qf[C::QT][C::NC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int qr = q0 + 16 * qt + l15;
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+            const int dcol = 32 * c + 8 * g;
+            half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qr < p.lq && dcol < D)
+                v = *reinterpret_cast<const half8v*>(p.q + ((long)n * p.lq + qr) * p.ldq + h * D + dcol);
+            qf[qt][c] = v;
+        }
+    }
+
+    float4v acc_o[C::QT][C::NDT];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
+    float m_run[C::QT], l_run[C::QT];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+    }
+
+    // ---- walk the key/value segments; inside a segment the next tile is prefetched under the MFMAs ----
+    const half_t* zero = reinterpret_cast<const half_t*>(g_attn_zero);
+    u32x4 pf[C::PF];
+    AttnStage<D> stg;
+#pragma unroll
+    for (int i = 0; i < C::PF; ++i) {
+        const int idx = tid + 256 * i;  // [0, 2*CHUNKS): first the K chunks, then the V chunks
+        const bool isv = idx >= C::CHUNKS;
+        const int cidx = isv ? idx - C::CHUNKS : idx;
+        const int row = cidx / C::DCH, ch = cidx - row * C::DCH;
+        stg.isv[i] = isv;
+        stg.row[i] = (idx < 2 * C::CHUNKS) ? row : (1 << 20);
+        stg.loff[i] = isv ? C::KV * C::KRS + row * C::VRS + ch * 8 : row * C::KRS + ch * 8;
+        stg.goff[i] = ch * 8;  // + row * ld, filled per segment
+    }
+
+#pragma unroll 1
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        const int len = ATTN_SEG_FIELD(p, seg, len);
+        const long ldk = ATTN_SEG_FIELD(p, seg, ldk), ldv = ATTN_SEG_FIELD(p, seg, ldv);
+        const int sdiv = ATTN_SEG_FIELD(p, seg, div), smul = ATTN_SEG_FIELD(p, seg, mul), sadd = ATTN_SEG_FIELD(p, seg, add);
+        const long kvb = (long)(n / sdiv) * smul + sadd;
+        const half_t* kb = ATTN_SEG_FIELD(p, seg, k) + kvb * len * ldk + h * D;
+        const half_t* vb = ATTN_SEG_FIELD(p, seg, v) + kvb * len * ldv + h * D;
+        AttnStage<D> st = stg;
+#pragma unroll
+        for (int i = 0; i < C::PF; ++i) {
+            const int r = st.row[i] < C::KV ? st.row[i] : 0;
+            st.goff[i] += (long)r * (st.isv[i] ? ldv : ldk);
+        }
+        attn_prefetch<D>(pf, st, kb, vb, ldk, ldv, 0, len, zero);
+      for (int cur_base = 0; cur_base < len; cur_base += C::KV) {
+        __syncthreads();  // previous tile fully consumed (also orders the initial zero fill)
+        attn_commit<D>(pf, st, lds);
+        __syncthreads();
+        // prefetch the next tile of this segment while this one is computed (past the end: zero page)
+        attn_prefetch<D>(pf, st, kb, vb, ldk, ldv, cur_base + C::KV, len, zero);
+
+        // ---- S^T = K Q^T : acc_s[qt][st][r] = S[q = l15][kv = 16 st + 4 g + r] ----
+        float4v acc_s[C::QT][4];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc_s[qt][st] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                half8v kf = *reinterpret_cast<const half8v*>(sK + (16 * st + l15) * C::KRS + 32 * c + 8 * g);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_s[qt][st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][c], acc_s[qt][st], 0, 0, 0);
+            }
+        }
+        // ---- mask the tail of the segment ----
+        if (cur_base + C::KV > len) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (cur_base + 16 * st + 4 * g + r >= len) {
+#pragma unroll
+                        for (int qt = 0; qt < C::QT; ++qt) acc_s[qt][st][r] = -INFINITY;
+                    }
+                }
+        }
+        // ---- online softmax (per lane: one query column, 16 scores; lane groups g hold the other 48) ----
+        half8v pfrag[C::QT][2];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[qt][st][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx * p.scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = __builtin_amdgcn_exp2f(fmaf(acc_s[qt][st][r], p.scale_log2e, -m_new));
+                    acc_s[qt][st][r] = e;
+                    ps += e;
+                }
+            l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                half8v f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (half_t)acc_s[qt][2 * cc][r];
+                    f[4 + r] = (half_t)acc_s[qt][2 * cc + 1][r];
+                }
+                pfrag[qt][cc] = f;
+            }
+        }
+        // ---- O^T += V^T P^T : A = V^T fragment via transpose read, B = P fragment ----
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt) {
+                // 16-lane group g reads the [4 kv][16 d] blocks at kv = 32cc + 4g (+16), d = 16 dt
+                const half_t* b0 = sV + (32 * cc + 4 * g + (l15 >> 2)) * C::VRS + 16 * dt + (l15 & 3) * 4;
+                short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(b0));
+                short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(b0 + 16 * C::VRS));
+                typedef short short8v __attribute__((ext_vector_type(8)));
+                short8v tv = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                half8v vf = __builtin_bit_cast(half8v, tv);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfrag[qt][cc], acc_o[qt][dt], 0, 0, 0);
+            }
+        }
+      }
+    }
+
+    // ---- epilogue: O^T[d = 16 dt + 4 g + r][q = l15] / l ----
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qr = q0 + 16 * qt + l15;
+        if (qr >= p.lq) continue;
+        half_t* orow = p.out + ((long)n * p.lq + qr) * p.ldo + h * D;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+            const int dcol = 16 * dt + 4 * g;
+            if (dcol >= D) continue;
+            float4v o = acc_o[qt][dt] * inv;
+            if (p.accumulate) {
+                half4v prev = *reinterpret_cast<const half4v*>(orow + dcol);
+                o = float4v{(float)prev[0], (float)prev[1], (float)prev[2], (float)prev[3]} + o * p.out_scale;
+            }
+            half4v w = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *reinterpret_cast<half4v*>(orow + dcol) = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+struct TAttnArgs {
+    const half_t* q;
+    const half_t* k;
+    const half_t* v;
+    half_t* out;
+    int ldq, ldk, ldv, ldo;
+    int b, t, hw, heads, d;
+    float scale;
+    long items;  // b * hw * heads
+};
+
+template <int GL>  // lanes per (pixel, head) item: 16 or 32 (>= T)
+__global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs a) {
+    const int tid = threadIdx.x;
+    const int gl = tid % GL;  // query frame of this lane
+    const long item = (long)blockIdx.x * (256 / GL) + tid / GL;
+    if (item >= a.items) return;
+    const int h = (int)(item % a.heads);
+    const long bp = item / a.heads;
+    const int pix = (int)(bp % a.hw);
+    const int b = (int)(bp / a.hw);
+    const bool active = gl < a.t;
+    const int tq = active ? gl : 0;
+    const long qrow = ((long)b * a.t + tq) * a.hw + pix;
+    const int dch = a.d >> 3;
+
+    float s[GL];
+#pragma unroll
+    for (int j = 0; j < GL; ++j) s[j] = 0.f;
+    // key/value rows of frame j (clamped so every load is unconditional; j >= T is masked in the softmax)
+    const long row0 = (long)b * a.t * a.hw + pix;
+    for (int ch = 0; ch < dch; ++ch) {
+        half8v qv = *reinterpret_cast<const half8v*>(a.q + qrow * a.ldq + h * a.d + ch * 8);
+        float qf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e];
+#pragma unroll
+        for (int jb = 0; jb < GL; jb += 16) {
+            half8v kv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int jj = (jb + j) < a.t ? (jb + j) : a.t - 1;
+                kv[j] = *reinterpret_cast<const half8v*>(a.k + (row0 + (long)jj * a.hw) * a.ldk + h * a.d + ch * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(qf[e], (float)kv[j][e], acc);
+                s[jb + j] += acc;
+            }
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < GL; ++j)
+        if (j < a.t) mx = fmaxf(mx, s[j] * a.scale);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < GL; ++j) {
+        float e = (j < a.t) ? __expf(s[j] * a.scale - mx) : 0.f;
+        s[j] = e;
+        l += e;
+    }
+    const float inv = 1.0f / l;
+    for (int ch = 0; ch < dch; ++ch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < GL; jb += 16) {
+            half8v vv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int jj = (jb + j) < a.t ? (jb + j) : a.t - 1;
+                vv[j] = *reinterpret_cast<const half8v*>(a.v + (row0 + (long)jj * a.hw) * a.ldv + h * a.d + ch * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf(s[jb + j], (float)vv[j][e], o[e]);
+            }
+        }
+        if (active) {
+            half8v w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (half_t)(o[e] * inv);
+            *reinterpret_cast<half8v*>(a.out + qrow * a.ldo + h * a.d + ch * 8) = w;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
+    MV_REQUIRE(d && d->q && d->out, "mv_attention_f16: null pointer");
+    MV_REQUIRE(d->nseg >= 1 && d->nseg <= MV_ATTN_MAX_SEG, "mv_attention_f16: nseg=%d out of range", d->nseg);
+    MV_REQUIRE(d->d == 40 || d->d == 80 || d->d == 160, "mv_attention_f16: head dim %d not in {40,80,160}", d->d);
+    MV_REQUIRE(d->nb > 0 && d->lq > 0 && d->heads > 0, "mv_attention_f16: empty problem");
+    MV_REQUIRE(d->ldq % 8 == 0 && d->ldo % 4 == 0, "mv_attention_f16: ldq %% 8 / ldo %% 4");
+    MV_REQUIRE(d->nb <= 65535 && d->heads <= 65535, "mv_attention_f16: grid too large");
+    AttnArgs a;
+    a.q = (const half_t*)d->q; a.out = (half_t*)d->out; a.ldq = d->ldq; a.ldo = d->ldo;
+    a.nb = d->nb; a.lq = d->lq; a.heads = d->heads;
+    a.scale_log2e = d->scale * 1.4426950408889634f;
+    a.nseg = d->nseg; a.accumulate = d->accumulate; a.out_scale = d->out_scale;
+    for (int s = 0; s < MV_ATTN_MAX_SEG; ++s) {
+        if (s < d->nseg) {
+            const mv_attn_seg& g = d->seg[s];
+            MV_REQUIRE(g.k && g.v && g.len > 0 && g.div > 0, "mv_attention_f16: bad segment %d", s);
+            MV_REQUIRE(g.ldk % 8 == 0 && g.ldv % 8 == 0, "mv_attention_f16: segment %d ldk/ldv %% 8", s);
+            a.seg[s] = SegArgs{(const half_t*)g.k, (const half_t*)g.v, g.ldk, g.ldv, g.len, g.div, g.mul, g.add};
+        } else {
+            a.seg[s] = SegArgs{nullptr, nullptr, 0, 0, 0, 1, 0, 0};
+        }
+    }
+    const int qb = d->d > 80 ? 64 : 128;  // AttnCfg<D>::QB
+    dim3 grid((unsigned)((d->lq + qb - 1) / qb), (unsigned)d->heads, (unsigned)d->nb);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->d == 40) hipLaunchKernelGGL(attn_kernel<40>, grid, dim3(256), 0, s, a);
+    else if (d->d == 80) hipLaunchKernelGGL(attn_kernel<80>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn_kernel<160>, grid, dim3(256), 0, s, a);
+    MV_CHECK_LAUNCH("mv_attention_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_temporal_attention_f16(const void* q, const void* k, const void* v, int32_t ldq, int32_t ldk,
+                                         int32_t ldv, void* out, int32_t ldo, int32_t b, int32_t t, int32_t hw,
+                                         int32_t heads, int32_t d, float scale, void* stream) {
+    MV_REQUIRE(q && k && v && out, "mv_temporal_attention_f16: null pointer");
+    MV_REQUIRE(t >= 1 && t <= 32, "mv_temporal_attention_f16: T=%d not in [1,32]", t);
+    MV_REQUIRE(d % 8 == 0 && d > 0, "mv_temporal_attention_f16: head dim %% 8");
+    MV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "mv_temporal_attention_f16: ld %% 8");
+    TAttnArgs a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.out = (half_t*)out;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.b = b; a.t = t; a.hw = hw; a.heads = heads; a.d = d;
+    a.scale = scale; a.items = (long)b * hw * heads;
+    hipStream_t s = (hipStream_t)stream;
+    if (t <= 16) {
+        const unsigned grid = (unsigned)((a.items + 15) / 16);
+        hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, a);
+    } else {
+        const unsigned grid = (unsigned)((a.items + 7) / 8);
+        hipLaunchKernelGGL(tattn_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+    }
+    MV_CHECK_LAUNCH("mv_temporal_attention_f16");
+    return MV_OK;
+}

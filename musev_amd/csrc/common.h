@@ -1,0 +1,64 @@
+// common.h -- shared device/host helpers for libmusev_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/musev_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define MV_WAVE 64
+
+// host-side error plumbing ---------------------------------------------------------------------------
+void mv_set_error(const char* fmt, ...);
+
+#define MV_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            mv_set_error(__VA_ARGS__);   \
+            return MV_ERR_INVALID;       \
+        }                                \
+    } while (0)
+
+#define MV_CHECK_LAUNCH(name)                                                       \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            mv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+            return MV_ERR_LAUNCH;                                                   \
+        }                                                                           \
+    } while (0)
+
+// device helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ float mv_silu(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) gelu, matching torch.nn.functional.gelu default used by diffusers GEGLU
+__device__ __forceinline__ float mv_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: blocks that the dispatcher places on the same XCD
+// (observed: id % 8) get a contiguous range of logical ids, so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int mv_xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, k = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

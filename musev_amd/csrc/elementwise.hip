@@ -1,0 +1,405 @@
+// elementwise.hip -- HBM-bound helpers of the UNet3D step and the sliding-window denoise loop (gfx950).
+// All kernels use 8/16-byte vector accesses on the channels-last layout and grid-stride loops.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(long work_items) {
+    long g = (work_items + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;  // grid-stride beyond ~32 blocks per CU
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---- GEGLU: y[m, j] = x[m, j] * gelu(x[m, half + j]) ----
+__global__ void geglu_kernel(const half_t* x, int ldx, half_t* y, int ldy, long rows, int half_cols) {
+    const int oc = half_cols >> 3;
+    const long total = rows * oc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / oc;
+        const int o = (int)(i - r * oc);
+        half8v a = *reinterpret_cast<const half8v*>(x + r * ldx + o * 8);
+        half8v g = *reinterpret_cast<const half8v*>(x + r * ldx + half_cols + o * 8);
+        half8v w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (half_t)((float)a[j] * mv_gelu((float)g[j]));
+        *reinterpret_cast<half8v*>(y + r * ldy + o * 8) = w;
+    }
+}
+
+__global__ void silu_kernel(const half_t* x, half_t* y, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        half8v a = reinterpret_cast<const half8v*>(x)[i];
+        half8v w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (half_t)mv_silu((float)a[j]);
+        reinterpret_cast<half8v*>(y)[i] = w;
+    }
+}
+
+__global__ void add_kernel(const half_t* a, const half_t* b, half_t* y, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        half8v u = reinterpret_cast<const half8v*>(a)[i];
+        half8v v = reinterpret_cast<const half8v*>(b)[i];
+        half8v w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (half_t)((float)u[j] + (float)v[j]);
+        reinterpret_cast<half8v*>(y)[i] = w;
+    }
+}
+
+__global__ void zero_rows_kernel(half_t* x, int ld, const int* row_idx, int n_idx, int cols) {
+    const long total = (long)n_idx * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        x[(long)row_idx[r] * ld + c] = (half_t)0.f;
+    }
+}
+
+// sinusoidal embedding, flip_sin_to_cos=True, downscale_freq_shift=0: out = [cos(t f_k), sin(t f_k)], f_k = 10000^(-k/half)
+__global__ void timestep_embedding_kernel(const float* t, int n, int dim, half_t* out) {
+    const int half_dim = dim / 2;
+    const int total = n * half_dim;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / half_dim, k = i - r * half_dim;
+        const float freq = expf(-logf(10000.0f) * (float)k / (float)half_dim);
+        const float arg = t[r] * freq;
+        out[(long)r * dim + k] = (half_t)cosf(arg);
+        out[(long)r * dim + half_dim + k] = (half_t)sinf(arg);
+    }
+}
+
+// ---- layout: [B, C, T, HW] <-> [B, T, HW, C] (C small: latent channels) ----
+template <typename SrcT>
+__global__ void bcthw_to_bthwc_kernel(const SrcT* x, half_t* y, int b, int c, int t, int hw) {
+    const long total = (long)b * t * hw * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % c);
+        long r = i / c;
+        const int p = (int)(r % hw);
+        r /= hw;
+        const int ti = (int)(r % t);
+        const int bi = (int)(r / t);
+        y[i] = (half_t)(float)x[(((long)bi * c + ci) * t + ti) * hw + p];
+    }
+}
+template <typename DstT>
+__global__ void bthwc_to_bcthw_kernel(const half_t* x, DstT* y, int b, int c, int t, int hw) {
+    const long total = (long)b * t * hw * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the destination [b][c][t][hw] so that stores are coalesced
+        const int p = (int)(i % hw);
+        long r = i / hw;
+        const int ti = (int)(r % t);
+        r /= t;
+        const int ci = (int)(r % c);
+        const int bi = (int)(r / c);
+        y[i] = (DstT)(float)x[(((long)bi * t + ti) * hw + p) * c + ci];
+    }
+}
+
+// ---- conv3x3 with tiny Cin (conv_in: 4 -> 320): one thread per (pixel, 8 output channels) ----
+// weights [cout][3][3][cin] are staged in LDS as fp32 [tap*cin][cout] so lanes read consecutive channels.
+__global__ void conv3x3_cin_small_kernel(const half_t* x, int cin, const half_t* w, const half_t* bias, const half_t* add,
+                                         half_t* y, int cout, long n_img, int h, int wd) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [9*cin][cout]
+    const int kk = 9 * cin;
+    for (int i = threadIdx.x; i < kk * cout; i += blockDim.x) {
+        const int o = i / kk, k = i - o * kk;
+        sw[k * cout + o] = (float)w[i];
+    }
+    __syncthreads();
+    const int oc8 = cout >> 3;
+    const long total = n_img * h * wd * oc8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o8 = (int)(i % oc8);
+        const long pix = i / oc8;
+        const int px = (int)(pix % wd);
+        const long r = pix / wd;
+        const int py = (int)(r % h);
+        const long img = r / h;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bias ? (float)bias[o8 * 8 + j] : 0.f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+            if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
+            const half_t* src = x + ((img * h + iy) * wd + ix) * cin;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float xv = (float)src[ci];
+                const float* wp = sw + (tap * cin + ci) * cout + o8 * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
+            }
+        }
+        half8v o;
+        if (add) {
+            half8v a = *reinterpret_cast<const half8v*>(add + pix * cout + o8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+        *reinterpret_cast<half8v*>(y + pix * cout + o8 * 8) = o;
+    }
+}
+
+// ---- conv3x3 with tiny Cout (conv_out: 320 -> 4): one wave per output pixel, lanes split the 9*Cin reduction ----
+__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x, int cin, const half_t* w,
+                                                                 const half_t* bias, half_t* y, int cout, long n_img,
+                                                                 int h, int wd) {
+    extern __shared__ __attribute__((aligned(16))) half_t swh[];  // [cout][9*cin]
+    const int kk = 9 * cin;
+    for (int i = threadIdx.x; i < cout * kk / 8; i += blockDim.x)
+        reinterpret_cast<uint4*>(swh)[i] = reinterpret_cast<const uint4*>(w)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int oc = cin >> 3;  // octets per tap
+    const long npix = n_img * h * wd;
+    for (long pix = (long)blockIdx.x * 4 + wave; pix < npix; pix += (long)gridDim.x * 4) {
+        const int px = (int)(pix % wd);
+        const long r = pix / wd;
+        const int py = (int)(r % h);
+        const long img = r / h;
+        float acc[8];  // cout <= 8
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int e = lane; e < 9 * oc; e += 64) {
+            const int tap = e / oc, o = e - tap * oc;
+            const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+            if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
+            half8v xv = *reinterpret_cast<const half8v*>(x + ((img * h + iy) * wd + ix) * cin + o * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cout) {
+                    half8v wv = *reinterpret_cast<const half8v*>(swh + j * kk + tap * cin + o * 8);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[j] = fmaf((float)xv[q], (float)wv[q], acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = wave_sum(acc[j]);
+        if (lane < cout) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (lane == j) v = acc[j];
+            if (bias) v += (float)bias[lane];
+            y[pix * cout + lane] = (half_t)v;
+        }
+    }
+}
+
+// ---- sliding-window loop glue ----
+// out: channels-last fp16 [copies][n_cond + win][hw][c]; frame f < n_cond from cond[c][n_cond][hw], else latents[:, idx[f-n_cond]]
+__global__ void window_gather_kernel(const float* latents, const float* cond, const int* idx, int win, int n_cond, int c,
+                                     int t_total, int hw, int copies, half_t* out) {
+    const int tw = n_cond + win;
+    const long per = (long)tw * hw * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % c);
+        long r = i / c;
+        const int p = (int)(r % hw);
+        const int f = (int)(r / hw);
+        float v;
+        if (f < n_cond) v = cond[((long)ci * n_cond + f) * hw + p];
+        else v = latents[((long)ci * t_total + idx[f - n_cond]) * hw + p];
+        const half_t hv = (half_t)v;
+        for (int k = 0; k < copies; ++k) out[k * per + i] = hv;
+    }
+}
+
+// eps_acc[half_offset + k][c][t_total][hw] += eps_win[k][n_cond + j][hw][c]  for window frame j -> idx[j]
+__global__ void window_scatter_add_kernel(const half_t* eps_win, const int* idx, int win, int n_cond, int c, int t_total,
+                                          int hw, int halves, int half_offset, float* eps_acc, float* counter,
+                                          int add_counter) {
+    const long total = (long)halves * c * win * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % hw);
+        long r = i / hw;
+        const int j = (int)(r % win);
+        r /= win;
+        const int ci = (int)(r % c);
+        const int k = (int)(r / c);
+        const float v = (float)eps_win[(((long)k * (n_cond + win) + n_cond + j) * hw + p) * c + ci];
+        eps_acc[(((long)(half_offset + k) * c + ci) * t_total + idx[j]) * hw + p] += v;
+    }
+    if (add_counter && blockIdx.x == 0 && threadIdx.x < win) counter[idx[threadIdx.x]] += 1.0f;
+}
+
+__global__ void cfg_ddim_step_kernel(float* latents, const float* eps_acc, const float* counter, int c, int t_total, int hw,
+                                     int halves, float guidance, float sqrt_at, float sqrt_1mat, float sqrt_ap,
+                                     float sqrt_1map) {
+    const long n = (long)c * t_total * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tf = (int)((i / hw) % t_total);
+        const float inv = 1.0f / counter[tf];
+        float eps = eps_acc[i] * inv;
+        if (halves == 2) {
+            const float et = eps_acc[n + i] * inv;
+            eps = eps + guidance * (et - eps);
+        }
+        const float x = latents[i];
+        const float x0 = (x - sqrt_1mat * eps) / sqrt_at;
+        latents[i] = sqrt_ap * x0 + sqrt_1map * eps;
+    }
+}
+
+// conv weight repack: [O][I][taps] -> [O][taps][I] fp16
+template <typename SrcT>
+__global__ void pack_conv_weight_kernel(const SrcT* w, half_t* out, int o, int ic, int taps) {
+    const long total = (long)o * ic * taps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % ic);
+        long r = i / ic;
+        const int tp = (int)(r % taps);
+        const long oo = r / taps;
+        out[i] = (half_t)(float)w[(oo * ic + ci) * taps + tp];
+    }
+}
+
+// ds_read_b64_tr_b16 semantics probe: lane l reads through the transpose path at byte offset addr[l]
+__global__ void probe_tr16_kernel(const short* image, short* out) {
+    __shared__ __attribute__((aligned(16))) short lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = image[i];
+    __syncthreads();
+    const int l = threadIdx.x;
+    // same addressing the attention kernel uses with row stride 64 shorts: 16-lane group g, lane i -> row 4g + i/4, col (i%4)*4
+    const int l15 = l & 15, g = l >> 4;
+    const short* p = lds + (4 * g + (l15 >> 2)) * 64 + (l15 & 3) * 4;
+    short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+    out[l * 4 + 0] = v[0];
+    out[l * 4 + 1] = v[1];
+    out[l * 4 + 2] = v[2];
+    out[l * 4 + 3] = v[3];
+}
+
+}  // namespace
+
+extern "C" int mv_geglu_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t half_cols, void* stream) {
+    MV_REQUIRE(x && y && rows > 0 && half_cols > 0 && half_cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "mv_geglu_f16: bad args");
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid_for(rows * (half_cols / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const half_t*)x, ldx, (half_t*)y, ldy, (long)rows, half_cols);
+    MV_CHECK_LAUNCH("mv_geglu_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_silu_f16(const void* x, void* y, int64_t n, void* stream) {
+    MV_REQUIRE(x && y && n > 0 && n % 8 == 0, "mv_silu_f16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (long)(n / 8));
+    MV_CHECK_LAUNCH("mv_silu_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+    MV_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "mv_add_f16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, (half_t*)y, (long)(n / 8));
+    MV_CHECK_LAUNCH("mv_add_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_zero_rows_f16(void* x, int32_t ld, const int32_t* row_idx, int32_t n_idx, int32_t cols, void* stream) {
+    MV_REQUIRE(x && row_idx && n_idx > 0 && cols > 0, "mv_zero_rows_f16: bad args");
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long)n_idx * cols)), dim3(kBlock), 0, (hipStream_t)stream, (half_t*)x, ld, row_idx, n_idx, cols);
+    MV_CHECK_LAUNCH("mv_zero_rows_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_timestep_embedding_f16(const float* t, int32_t n, int32_t dim, void* out, void* stream) {
+    MV_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0, "mv_timestep_embedding_f16: bad args");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((long)n * dim / 2)), dim3(kBlock), 0, (hipStream_t)stream, t, n, dim, (half_t*)out);
+    MV_CHECK_LAUNCH("mv_timestep_embedding_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_bcthw_to_bthwc_f16(const void* x, int32_t x_is_f32, void* y, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream) {
+    MV_REQUIRE(x && y && b > 0 && c > 0 && t > 0 && hw > 0, "mv_bcthw_to_bthwc_f16: bad args");
+    const long n = (long)b * c * t * hw;
+    if (x_is_f32) hipLaunchKernelGGL(bcthw_to_bthwc_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const float*)x, (half_t*)y, b, c, t, hw);
+    else hipLaunchKernelGGL(bcthw_to_bthwc_kernel<half_t>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, b, c, t, hw);
+    MV_CHECK_LAUNCH("mv_bcthw_to_bthwc_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_bthwc_to_bcthw_f16(const void* x, void* y, int32_t y_is_f32, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream) {
+    MV_REQUIRE(x && y && b > 0 && c > 0 && t > 0 && hw > 0, "mv_bthwc_to_bcthw_f16: bad args");
+    const long n = (long)b * c * t * hw;
+    if (y_is_f32) hipLaunchKernelGGL(bthwc_to_bcthw_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, (float*)y, b, c, t, hw);
+    else hipLaunchKernelGGL(bthwc_to_bcthw_kernel<half_t>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, b, c, t, hw);
+    MV_CHECK_LAUNCH("mv_bthwc_to_bcthw_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* w, const void* bias, const void* add, void* y,
+                                        int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream) {
+    MV_REQUIRE(x && w && y && cin > 0 && cin <= 16 && cout % 8 == 0 && n_img > 0 && h > 0 && w_ > 0, "mv_conv3x3_cin_small_f16: bad args (cin=%d cout=%d)", cin, cout);
+    const size_t smem = (size_t)9 * cin * cout * sizeof(float);
+    MV_REQUIRE(smem <= 64 * 1024, "mv_conv3x3_cin_small_f16: weights do not fit LDS");
+    hipLaunchKernelGGL(conv3x3_cin_small_kernel, dim3(grid_for(n_img * h * w_ * (cout / 8))), dim3(kBlock), smem, (hipStream_t)stream,
+                       (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (const half_t*)add, (half_t*)y, cout, (long)n_img, h, w_);
+    MV_CHECK_LAUNCH("mv_conv3x3_cin_small_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w, const void* bias, void* y, int32_t cout,
+                                         int64_t n_img, int32_t h, int32_t w_, void* stream) {
+    MV_REQUIRE(x && w && y && cin % 8 == 0 && cout > 0 && cout <= 8 && n_img > 0 && h > 0 && w_ > 0, "mv_conv3x3_cout_small_f16: bad args (cin=%d cout=%d)", cin, cout);
+    const size_t smem = (size_t)9 * cin * cout * sizeof(half_t);
+    MV_REQUIRE(smem <= 64 * 1024, "mv_conv3x3_cout_small_f16: weights do not fit LDS");
+    long g = (n_img * h * w_ + 3) / 4;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv3x3_cout_small_kernel, dim3((unsigned)g), dim3(kBlock), smem, (hipStream_t)stream,
+                       (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_);
+    MV_CHECK_LAUNCH("mv_conv3x3_cout_small_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
+                                int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, void* out, void* stream) {
+    MV_REQUIRE(latents && idx && out && win > 0 && n_cond >= 0 && (n_cond == 0 || cond) && c > 0 && t_total > 0 && hw > 0 && cfg_copies > 0,
+               "mv_window_gather: bad args");
+    hipLaunchKernelGGL(window_gather_kernel, dim3(grid_for((long)(n_cond + win) * hw * c)), dim3(kBlock), 0, (hipStream_t)stream,
+                       latents, cond, idx, win, n_cond, c, t_total, hw, cfg_copies, (half_t*)out);
+    MV_CHECK_LAUNCH("mv_window_gather");
+    return MV_OK;
+}
+
+extern "C" int mv_window_scatter_add(const void* eps_win, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
+                                     int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset, float* eps_acc,
+                                     float* counter, int32_t add_counter, void* stream) {
+    MV_REQUIRE(eps_win && idx && eps_acc && counter && win > 0 && win <= kBlock && halves > 0, "mv_window_scatter_add: bad args");
+    hipLaunchKernelGGL(window_scatter_add_kernel, dim3(grid_for((long)halves * c * win * hw)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const half_t*)eps_win, idx, win, n_cond, c, t_total, hw, halves, half_offset, eps_acc, counter, add_counter);
+    MV_CHECK_LAUNCH("mv_window_scatter_add");
+    return MV_OK;
+}
+
+extern "C" int mv_cfg_ddim_step(float* latents, const float* eps_acc, const float* counter, int32_t c, int32_t t_total,
+                                int32_t hw, int32_t halves, float guidance, float alpha_t, float alpha_prev, void* stream) {
+    MV_REQUIRE(latents && eps_acc && counter && (halves == 1 || halves == 2) && alpha_t > 0.f && alpha_t <= 1.f && alpha_prev > 0.f && alpha_prev <= 1.f,
+               "mv_cfg_ddim_step: bad args");
+    hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3(grid_for((long)c * t_total * hw)), dim3(kBlock), 0, (hipStream_t)stream, latents,
+                       eps_acc, counter, c, t_total, hw, halves, guidance, sqrtf(alpha_t), sqrtf(1.f - alpha_t), sqrtf(alpha_prev),
+                       sqrtf(1.f - alpha_prev));
+    MV_CHECK_LAUNCH("mv_cfg_ddim_step");
+    return MV_OK;
+}
+
+extern "C" int mv_pack_conv_weight_f16(const void* w, int32_t w_is_f32, void* out, int32_t o, int32_t i, int32_t taps, void* stream) {
+    MV_REQUIRE(w && out && o > 0 && i > 0 && taps > 0, "mv_pack_conv_weight_f16: bad args");
+    const long n = (long)o * i * taps;
+    if (w_is_f32) hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const float*)w, (half_t*)out, o, i, taps);
+    else hipLaunchKernelGGL(pack_conv_weight_kernel<half_t>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)w, (half_t*)out, o, i, taps);
+    MV_CHECK_LAUNCH("mv_pack_conv_weight_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_probe_tr16(const void* lds_image, void* out, void* stream) {
+    MV_REQUIRE(lds_image && out, "mv_probe_tr16: null pointer");
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const short*)lds_image, (short*)out);
+    MV_CHECK_LAUNCH("mv_probe_tr16");
+    return MV_OK;
+}

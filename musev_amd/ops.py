@@ -1,0 +1,406 @@
+"""Tensor-level wrappers over the C ABI (libmusev_hip.so).
+
+PyTorch is used here only as plumbing: device memory (caching allocator), the current HIP stream and dtype
+bookkeeping.  Every function launches hand-written gfx950 kernels on ``torch.cuda.current_stream()``; there is no
+eager/CPU fallback -- a missing library or a non-CUDA tensor raises.
+
+Activations are "rows x channels" fp16 matrices in channels-last order ([B, T, H, W, C] flattened to [B*T*H*W, C]);
+2-D views with a unit inner stride and an arbitrary row stride are accepted everywhere (column slices of a fused
+QKV projection are passed without copies).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3, MV_GEMM_LINEAR, MV_GEMM_TCONV3,
+                   check)
+
+__all__ = [
+    "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
+    "conv3x3_cin_small", "conv3x3_cout_small", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
+    "window_gather", "window_scatter_add", "cfg_ddim_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
+]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    if t.dtype != torch.float16 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA fp16 tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+def _vec(t: Optional[torch.Tensor], name: str, n: Optional[int] = None) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float16 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous CUDA fp16 tensor")
+    if n is not None and t.numel() != n:
+        raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+    return t
+
+
+def _fill_epilogue(d: GemmDesc, N: int, M: int, bias, rowbias, rows_per_group, residual, alpha, act, out_cols):
+    d.bias = _p(_vec(bias, "bias", N))
+    if rowbias is not None:
+        rb = _mat(rowbias, "rowbias")
+        d.rowbias, d.ldrb, d.rows_per_group = rb.data_ptr(), rb.stride(0), int(rows_per_group)
+        if rows_per_group <= 0 or rb.shape[0] * rows_per_group < M or rb.shape[1] != N:
+            raise ValueError("rowbias: shape / rows_per_group do not cover the output")
+    if residual is not None:
+        r = _mat(residual, "residual")
+        if r.shape[0] != M or r.shape[1] != out_cols:
+            raise ValueError("residual: shape mismatch")
+        d.residual, d.ldr = r.data_ptr(), r.stride(0)
+    if alpha is not None:
+        if alpha.dtype != torch.float32 or alpha.numel() != 1 or not alpha.is_cuda:
+            raise ValueError("alpha: expected a CUDA fp32 scalar tensor")
+        d.alpha = alpha.data_ptr()
+    d.act = int(act)
+
+
+def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+    if out is None:
+        return torch.empty((M, cols), dtype=torch.float16, device=like.device)
+    o = _mat(out, "out")
+    if o.shape[0] != M or o.shape[1] != cols:
+        raise ValueError(f"out: expected {(M, cols)}, got {tuple(o.shape)}")
+    return o
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
+         rows_per_group: int = 0, residual=None, alpha=None, act: int = MV_ACT_NONE, geglu: bool = False,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(|alpha| * ([a | a2] @ w.T + bias + rowbias[row // rows_per_group])) + residual   (fp16, fp32 accumulate).
+
+    ``w`` is [N, K] (torch Linear layout).  With ``geglu`` the rows of ``w`` / ``bias`` must be packed by
+    :func:`pack_geglu` and the result has N/2 columns: value * gelu(gate).
+    """
+    a = _mat(a, "a")
+    w = _mat(w, "w")
+    if not w.is_contiguous():
+        raise ValueError("w must be contiguous [N, K]")
+    M, c1 = a.shape
+    N, K = w.shape
+    d = GemmDesc()
+    d.a, d.lda, d.c1 = a.data_ptr(), a.stride(0), c1
+    if a2 is not None:
+        a2 = _mat(a2, "a2")
+        if a2.shape[0] != M:
+            raise ValueError("a2: row count mismatch")
+        d.a2, d.lda2, d.c2 = a2.data_ptr(), a2.stride(0), a2.shape[1]
+    if c1 + (a2.shape[1] if a2 is not None else 0) != K:
+        raise ValueError(f"gemm: K mismatch: inputs give {c1 + (a2.shape[1] if a2 is not None else 0)}, weight has {K}")
+    cols = N // 2 if geglu else N
+    o = _out(out, M, cols, a)
+    d.w, d.c, d.ldc = w.data_ptr(), o.data_ptr(), o.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.mode, d.geglu = MV_GEMM_LINEAR, int(geglu)
+    _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, alpha, act, cols)
+    check(_lib.load().mv_gemm_f16(C.byref(d), _stream()), "mv_gemm_f16")
+    return o
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2: Optional[torch.Tensor] = None,
+            stride: int = 1, upsample: bool = False, bias=None, rowbias=None, rows_per_group: int = 0, residual=None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 convolution, padding 1, over channels-last images x = [n_img*h*w_, C1] (+ optional concatenated x2).
+
+    ``w`` is the packed weight [Cout, 9*(C1+C2)] (tap-major, see :func:`pack_conv_weight`).  ``upsample`` applies a
+    nearest x2 upsample to the input on the fly (Upsample2D); ``stride=2`` is Downsample2D.
+    """
+    x = _mat(x, "x")
+    w = _mat(w, "w")
+    c1 = x.shape[1]
+    c2 = 0
+    if x.shape[0] != n_img * h * w_:
+        raise ValueError("conv3x3: x rows != n_img*h*w")
+    d = GemmDesc()
+    d.a, d.lda, d.c1 = x.data_ptr(), x.stride(0), c1
+    if x2 is not None:
+        x2 = _mat(x2, "x2")
+        c2 = x2.shape[1]
+        d.a2, d.lda2, d.c2 = x2.data_ptr(), x2.stride(0), c2
+    N, K = w.shape
+    if K != 9 * (c1 + c2):
+        raise ValueError(f"conv3x3: weight K={K} != 9*({c1}+{c2})")
+    if upsample:
+        ho, wo = 2 * h, 2 * w_
+    else:
+        ho, wo = (h + 2 - 3) // stride + 1, (w_ + 2 - 3) // stride + 1
+    M = n_img * ho * wo
+    o = _out(out, M, N, x)
+    d.w, d.c, d.ldc = w.data_ptr(), o.data_ptr(), o.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.mode, d.stride, d.upsample = MV_GEMM_CONV3X3, stride, int(upsample)
+    d.hin, d.win, d.hout, d.wout = h, w_, ho, wo
+    _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, None, MV_ACT_NONE, N)
+    check(_lib.load().mv_gemm_f16(C.byref(d), _stream()), "mv_gemm_f16(conv3x3)")
+    return o
+
+
+def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=None, residual=None, alpha=None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv3d (3,1,1), padding (1,0,0), over x = [b*t*hw, C] in (b, t, p) row order; w packed [Cout, 3*C]."""
+    x = _mat(x, "x")
+    w = _mat(w, "w")
+    M, c1 = x.shape
+    if M != b * t * hw:
+        raise ValueError("tconv3: x rows != b*t*hw")
+    N, K = w.shape
+    if K != 3 * c1:
+        raise ValueError("tconv3: weight K != 3*C")
+    o = _out(out, M, N, x)
+    d = GemmDesc()
+    d.a, d.lda, d.c1 = x.data_ptr(), x.stride(0), c1
+    d.w, d.c, d.ldc = w.data_ptr(), o.data_ptr(), o.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.mode, d.t, d.hw = MV_GEMM_TCONV3, t, hw
+    _fill_epilogue(d, N, M, bias, None, 0, residual, alpha, MV_ACT_NONE, N)
+    check(_lib.load().mv_gemm_f16(C.byref(d), _stream()), "mv_gemm_f16(tconv3)")
+    return o
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items: int, rows: int, *, eps: float,
+              silu: bool, x2: Optional[torch.Tensor] = None, groups: int = 32,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm(groups) (+SiLU) with statistics over (rows, C/groups) per item; x = [n_items*rows, C1] (+ x2)."""
+    x = _mat(x, "x")
+    c1 = x.shape[1]
+    c2 = 0
+    if x.shape[0] != n_items * rows:
+        raise ValueError("groupnorm: x rows != n_items*rows")
+    if x2 is not None:
+        x2 = _mat(x2, "x2")
+        c2 = x2.shape[1]
+    c = c1 + c2
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    lib = _lib.load()
+    nsplit = lib.mv_groupnorm_default_nsplit(n_items, rows, c)
+    scratch = torch.empty(n_items * nsplit * 2 * c + n_items * 2 * c, dtype=torch.float32, device=x.device)
+    partial_ptr = scratch.data_ptr()
+    ss_ptr = partial_ptr + 4 * n_items * nsplit * 2 * c
+    o = _out(out, n_items * rows, c, x)
+    check(lib.mv_groupnorm_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
+                               n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
+                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, ss_ptr, _stream()), "mv_groupnorm_f16")
+    return o
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _mat(x, "x")
+    M, c = x.shape
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    o = _out(out, M, c, x)
+    check(_lib.load().mv_layernorm_f16(x.data_ptr(), x.stride(0), o.data_ptr(), o.stride(0), M, c, gamma.data_ptr(),
+                                       beta.data_ptr(), float(eps), _stream()), "mv_layernorm_f16")
+    return o
+
+
+Seg = Tuple[torch.Tensor, torch.Tensor, int, int, int, int]  # (k, v, len, div, mul, add)
+
+
+def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int, d: int, scale: float, *,
+              out: Optional[torch.Tensor] = None, accumulate: bool = False, out_scale: float = 1.0) -> torch.Tensor:
+    """Multi-segment softmax attention.  q = [nb*lq, heads*d]; each segment (k, v, len, div, mul, add) holds 2-D
+    key/value matrices whose row (kvb*len + j) is key j of key batch kvb = (n // div) * mul + add for query batch n."""
+    q = _mat(q, "q")
+    if q.shape[0] != nb * lq or q.shape[1] != heads * d:
+        raise ValueError("attention: q shape mismatch")
+    o = _out(out, nb * lq, heads * d, q)
+    ds = AttnDesc()
+    ds.q, ds.out, ds.ldq, ds.ldo = q.data_ptr(), o.data_ptr(), q.stride(0), o.stride(0)
+    ds.nb, ds.lq, ds.heads, ds.d = nb, lq, heads, d
+    ds.scale, ds.nseg = float(scale), len(segs)
+    ds.accumulate, ds.out_scale = int(accumulate), float(out_scale)
+    if not 1 <= len(segs) <= _lib.MV_ATTN_MAX_SEG:
+        raise ValueError("attention: need 1..4 segments")
+    for i, (k, v, ln, div, mul, add_) in enumerate(segs):
+        k = _mat(k, "k")
+        v = _mat(v, "v")
+        max_kvb = ((nb - 1) // div) * mul + add_
+        if k.shape[0] < (max_kvb + 1) * ln or v.shape[0] < (max_kvb + 1) * ln:
+            raise ValueError(f"attention: segment {i} does not cover key batch {max_kvb}")
+        s = ds.seg[i]
+        s.k, s.v, s.ldk, s.ldv, s.len, s.div, s.mul, s.add = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), ln, div, mul, add_
+    check(_lib.load().mv_attention_f16(C.byref(ds), _stream()), "mv_attention_f16")
+    return o
+
+
+def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, b: int, t: int, hw: int, heads: int, d: int,
+                       scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    q, k, v = _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
+    M = b * t * hw
+    if q.shape[0] != M or k.shape[0] != M or v.shape[0] != M:
+        raise ValueError("temporal_attention: rows != b*t*hw")
+    o = _out(out, M, heads * d, q)
+    check(_lib.load().mv_temporal_attention_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+                                                v.stride(0), o.data_ptr(), o.stride(0), b, t, hw, heads, d,
+                                                float(scale), _stream()), "mv_temporal_attention_f16")
+    return o
+
+
+def geglu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _mat(x, "x")
+    M, two = x.shape
+    half = two // 2
+    o = _out(out, M, half, x)
+    check(_lib.load().mv_geglu_f16(x.data_ptr(), x.stride(0), o.data_ptr(), o.stride(0), M, half, _stream()), "mv_geglu_f16")
+    return o
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    if not x.is_contiguous() or x.dtype != torch.float16:
+        raise ValueError("silu: contiguous fp16 expected")
+    y = torch.empty_like(x)
+    check(_lib.load().mv_silu_f16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mv_silu_f16")
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous() or a.dtype != torch.float16 or b.dtype != torch.float16:
+        raise ValueError("add: contiguous fp16 tensors of equal shape expected")
+    y = torch.empty_like(a)
+    check(_lib.load().mv_add_f16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mv_add_f16")
+    return y
+
+
+def conv3x3_cin_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int,
+                      add_: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _mat(x, "x")
+    w = _mat(w, "w")
+    cin, cout = x.shape[1], w.shape[0]
+    if not x.is_contiguous() or w.shape[1] != 9 * cin:
+        raise ValueError("conv3x3_cin_small: bad shapes")
+    y = torch.empty((n_img * h * w_, cout), dtype=torch.float16, device=x.device)
+    check(_lib.load().mv_conv3x3_cin_small_f16(x.data_ptr(), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
+                                               _p(add_), y.data_ptr(), cout, n_img, h, w_, _stream()),
+          "mv_conv3x3_cin_small_f16")
+    return y
+
+
+def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int) -> torch.Tensor:
+    x = _mat(x, "x")
+    w = _mat(w, "w")
+    cin, cout = x.shape[1], w.shape[0]
+    if not x.is_contiguous() or w.shape[1] != 9 * cin:
+        raise ValueError("conv3x3_cout_small: bad shapes")
+    y = torch.empty((n_img * h * w_, cout), dtype=torch.float16, device=x.device)
+    check(_lib.load().mv_conv3x3_cout_small_f16(x.data_ptr(), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
+                                                y.data_ptr(), cout, n_img, h, w_, _stream()), "mv_conv3x3_cout_small_f16")
+    return y
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    t = t.to(dtype=torch.float32).contiguous()
+    out = torch.empty((t.numel(), dim), dtype=torch.float16, device=t.device)
+    check(_lib.load().mv_timestep_embedding_f16(t.data_ptr(), t.numel(), dim, out.data_ptr(), _stream()),
+          "mv_timestep_embedding_f16")
+    return out
+
+
+def zero_rows(x: torch.Tensor, row_idx: torch.Tensor) -> None:
+    x = _mat(x, "x")
+    idx = row_idx.to(dtype=torch.int32).contiguous()
+    check(_lib.load().mv_zero_rows_f16(x.data_ptr(), x.stride(0), idx.data_ptr(), idx.numel(), x.shape[1], _stream()),
+          "mv_zero_rows_f16")
+
+
+def bcthw_to_bthwc(x: torch.Tensor) -> torch.Tensor:
+    """[B, C, T, H, W] (fp16|fp32) -> fp16 [B*T*H*W, C] channels-last rows."""
+    b, c, t, h, w = x.shape
+    x = x.contiguous()
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    y = torch.empty((b * t * h * w, c), dtype=torch.float16, device=x.device)
+    check(_lib.load().mv_bcthw_to_bthwc_f16(x.data_ptr(), int(x.dtype == torch.float32), y.data_ptr(), b, c, t, h * w,
+                                            _stream()), "mv_bcthw_to_bthwc_f16")
+    return y
+
+
+def bthwc_to_bcthw(x: torch.Tensor, b: int, t: int, h: int, w: int, dtype=torch.float16) -> torch.Tensor:
+    x = _mat(x, "x")
+    c = x.shape[1]
+    if not x.is_contiguous():
+        raise ValueError("bthwc_to_bcthw: contiguous input expected")
+    y = torch.empty((b, c, t, h, w), dtype=dtype, device=x.device)
+    check(_lib.load().mv_bthwc_to_bcthw_f16(x.data_ptr(), y.data_ptr(), int(dtype == torch.float32), b, c, t, h * w,
+                                            _stream()), "mv_bthwc_to_bcthw_f16")
+    return y
+
+
+def window_gather(latents: torch.Tensor, cond: Optional[torch.Tensor], idx: torch.Tensor, n_cond: int, copies: int) -> torch.Tensor:
+    """latents fp32 [C, T_total, HW]; cond fp32 [C, n_cond, HW]; idx int32 [win] -> fp16 [copies*(n_cond+win)*HW, C]."""
+    c, t_total, hw = latents.shape
+    win = idx.numel()
+    out = torch.empty((copies * (n_cond + win) * hw, c), dtype=torch.float16, device=latents.device)
+    check(_lib.load().mv_window_gather(latents.data_ptr(), _p(cond), idx.data_ptr(), win, n_cond, c, t_total, hw, copies,
+                                       out.data_ptr(), _stream()), "mv_window_gather")
+    return out
+
+
+def window_scatter_add(eps_win: torch.Tensor, idx: torch.Tensor, n_cond: int, halves: int, half_offset: int,
+                       eps_acc: torch.Tensor, counter: torch.Tensor, add_counter: bool) -> None:
+    """eps_win fp16 [halves*(n_cond+win)*HW, C]; eps_acc fp32 [H, C, T_total, HW]; counter fp32 [T_total]."""
+    _, c, t_total, hw = eps_acc.shape
+    win = idx.numel()
+    check(_lib.load().mv_window_scatter_add(eps_win.data_ptr(), idx.data_ptr(), win, n_cond, c, t_total, hw, halves,
+                                            half_offset, eps_acc.data_ptr(), counter.data_ptr(), int(add_counter),
+                                            _stream()), "mv_window_scatter_add")
+
+
+def cfg_ddim_step(latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.Tensor, guidance: float, alpha_t: float,
+                  alpha_prev: float) -> None:
+    halves, c, t_total, hw = eps_acc.shape
+    check(_lib.load().mv_cfg_ddim_step(latents.data_ptr(), eps_acc.data_ptr(), counter.data_ptr(), c, t_total, hw, halves,
+                                       float(guidance), float(alpha_t), float(alpha_prev), _stream()), "mv_cfg_ddim_step")
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """torch conv weight [O, I, *k] (k = 3x3, 3x1x1 or 1x1) -> packed fp16 [O, taps*I] (tap-major, channel-minor)."""
+    o, i = w.shape[0], w.shape[1]
+    taps = 1
+    for s in w.shape[2:]:
+        taps *= s
+    w = w.contiguous()
+    if w.dtype not in (torch.float16, torch.float32):
+        w = w.float()
+    out = torch.empty((o, taps * i), dtype=torch.float16, device=w.device)
+    check(_lib.load().mv_pack_conv_weight_f16(w.data_ptr(), int(w.dtype == torch.float32), out.data_ptr(), o, i, taps,
+                                              _stream()), "mv_pack_conv_weight_f16")
+    return out
+
+
+def pack_geglu(w: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Reorder a GEGLU projection (rows [value(4C) | gate(4C)]) into blocks of [16 value | 16 gate] rows so the
+    gate can be applied in the GEMM epilogue (pure index shuffle; done once at weight-pack time)."""
+    n2 = w.shape[0]
+    half = n2 // 2
+    if half % 16 != 0:
+        raise ValueError("pack_geglu: 4C must be a multiple of 16")
+    idx = torch.arange(half, device=w.device).view(-1, 16)
+    perm = torch.cat([idx, idx + half], dim=1).reshape(-1)
+    wp = w.index_select(0, perm).contiguous()
+    bp = bias.index_select(0, perm).contiguous() if bias is not None else None
+    return wp, bp
+
+
+def probe_tr16(image: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((64, 4), dtype=torch.int16, device=image.device)
+    check(_lib.load().mv_probe_tr16(image.data_ptr(), out.data_ptr(), _stream()), "mv_probe_tr16")
+    return out

@@ -1,0 +1,400 @@
+"""Per-kernel parity cases: each HIP entry point (through the C ABI) against a plain PyTorch fp32 reference of the
+same op on the same seeded inputs.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and by tools/gpu_report.py
+(one-shot report that does not stop at the first failure).
+
+Tolerances: inputs/outputs are fp16, accumulation fp32 -> |err| <= atol + rtol*|ref| with rtol = 2^-9 (two fp16
+roundings) and an atol scaled to the magnitude of the contraction (stated per case).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+DEV = "cuda"
+
+
+def _rand(shape, seed, scale=1.0, dtype=torch.float16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(dtype).to(DEV)
+
+
+def _cmp(name, got, ref, atol, rtol=2e-3):
+    got = got.float()
+    ref = ref.float()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    worst = (err - bound).max().item()
+    return {
+        "name": name,
+        "max_abs_err": err.max().item(),
+        "ref_absmax": ref.abs().max().item(),
+        "atol": atol,
+        "rtol": rtol,
+        "ok": bool(worst <= 0.0) and bool(torch.isfinite(got).all()),
+    }
+
+
+# ---------------------------------------------------------------------------------------------------
+def case_tr16_probe():
+    """ds_read_b64_tr_b16 must return, to lane i of a 16-lane group, column i of the 4x16 block whose rows are
+    addressed by lanes (4r .. 4r+3)."""
+    from musev_amd import ops
+    img = torch.arange(1024, dtype=torch.int16, device=DEV)
+    out = ops.probe_tr16(img).cpu()
+    exp = torch.empty((64, 4), dtype=torch.int16)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for j in range(4):
+            exp[l, j] = (4 * g + j) * 64 + i  # image[row 4g + j][col i] with row stride 64
+    ok = bool((out == exp).all())
+    return {"name": "tr16_probe", "ok": ok, "max_abs_err": float((out.int() - exp.int()).abs().max()),
+            "got_lane0": out[0].tolist(), "got_lane1": out[1].tolist(), "got_lane17": out[17].tolist(),
+            "exp_lane17": exp[17].tolist()}
+
+
+def case_gemm(M=1000, N=320, K=640, seed=0, two_src=False, epilogue=True):
+    from musev_amd import ops
+    a = _rand((M, K), seed)
+    w = _rand((N, K), seed + 1, 1.0 / math.sqrt(K))
+    bias = _rand((N,), seed + 2) if epilogue else None
+    groups = 7
+    rpg = (M + groups - 1) // groups
+    rowbias = _rand((groups, N), seed + 3) if epilogue else None
+    res = _rand((M, N), seed + 4) if epilogue else None
+    alpha = torch.tensor([-0.37], dtype=torch.float32, device=DEV) if epilogue else None
+    if two_src:
+        c1 = 384 if K > 384 else K // 2
+        got = ops.gemm(a[:, :c1], w, a2=a[:, c1:], bias=bias, rowbias=rowbias, rows_per_group=rpg, residual=res, alpha=alpha)
+    else:
+        got = ops.gemm(a, w, bias=bias, rowbias=rowbias, rows_per_group=rpg, residual=res, alpha=alpha)
+    ref = a.float() @ w.float().t()
+    if epilogue:
+        ref = ref + bias.float()
+        ref = ref + rowbias.float()[torch.arange(M, device=DEV) // rpg]
+        ref = ref * 0.37 + res.float()
+    return _cmp(f"gemm M{M} N{N} K{K} two_src={two_src} epi={epilogue}", got, ref, atol=4e-3)
+
+
+def case_gemm_silu():
+    from musev_amd import ops
+    a = _rand((26, 320), 5)
+    w = _rand((1280, 320), 6, 1.0 / math.sqrt(320))
+    b = _rand((1280,), 7)
+    got = ops.gemm(a, w, bias=b, act=ops.MV_ACT_SILU)
+    ref = F.silu(a.float() @ w.float().t() + b.float())
+    return _cmp("gemm silu (time-embedding MLP shape)", got, ref, atol=3e-3)
+
+
+def case_gemm_geglu(M=777, C=320):
+    from musev_amd import ops
+    a = _rand((M, C), 8)
+    w = _rand((8 * C, C), 9, 1.0 / math.sqrt(C))
+    b = _rand((8 * C,), 10, 0.1)
+    wp, bp = ops.pack_geglu(w, b)
+    got = ops.gemm(a, wp, bias=bp, geglu=True)
+    h = a.float() @ w.float().t() + b.float()
+    ref = h[:, : 4 * C] * F.gelu(h[:, 4 * C:])
+    return _cmp(f"gemm geglu M{M} C{C}", got, ref, atol=4e-3)
+
+
+def case_conv3x3(n=3, h=16, w=24, c1=64, c2=0, cout=320, stride=1, upsample=False, seed=20):
+    from musev_amd import ops
+    cin = c1 + c2
+    x = _rand((n, cin, h, w), seed)
+    wt = _rand((cout, cin, 3, 3), seed + 1, 1.0 / math.sqrt(9 * cin))
+    bias = _rand((cout,), seed + 2)
+    xr = x.float()
+    if upsample:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xr, wt.float(), bias.float(), stride=stride, padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    temb = _rand((n, cout), seed + 3)
+    res = _rand((n * ho * wo, cout), seed + 4)
+    ref = ref + temb.float()[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(n * ho * wo, cout) + res.float()
+    xl = x.permute(0, 2, 3, 1).reshape(n * h * w, cin).contiguous()
+    wp = ops.pack_conv_weight(wt)
+    if c2:
+        got = ops.conv3x3(xl[:, :c1].contiguous(), wp, n, h, w, x2=xl[:, c1:].contiguous(), stride=stride, upsample=upsample,
+                          bias=bias, rowbias=temb, rows_per_group=ho * wo, residual=res)
+    else:
+        got = ops.conv3x3(xl, wp, n, h, w, stride=stride, upsample=upsample, bias=bias, rowbias=temb,
+                          rows_per_group=ho * wo, residual=res)
+    return _cmp(f"conv3x3 n{n} {h}x{w} c{c1}+{c2}->{cout} s{stride} up{int(upsample)}", got, ref, atol=5e-3)
+
+
+def case_tconv3(b=2, t=5, hw=48, c=128, seed=30):
+    from musev_amd import ops
+    x = _rand((b, c, t, hw, 1), seed)
+    wt = _rand((c, c, 3, 1, 1), seed + 1, 1.0 / math.sqrt(3 * c))
+    bias = _rand((c,), seed + 2)
+    ref = F.conv3d(x.float(), wt.float(), bias.float(), padding=(1, 0, 0))
+    alpha = torch.tensor([0.6], dtype=torch.float32, device=DEV)
+    ref = x.float() + 0.6 * ref
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(b * t * hw, c)
+    xl = x.permute(0, 2, 3, 4, 1).reshape(b * t * hw, c).contiguous()
+    got = ops.tconv3(xl, ops.pack_conv_weight(wt), b, t, hw, bias=bias, residual=xl, alpha=alpha)
+    return _cmp(f"tconv3 b{b} t{t} hw{hw} c{c}", got, ref, atol=4e-3)
+
+
+def case_groupnorm(n=3, rows=200, c1=320, c2=0, silu=True, eps=1e-5, seed=40):
+    from musev_amd import ops
+    c = c1 + c2
+    x = _rand((n, rows, c), seed) * 1.5 + 0.3
+    gamma = _rand((c,), seed + 1) * 0.2 + 1.0
+    beta = _rand((c,), seed + 2, 0.2)
+    xr = x.float().permute(0, 2, 1)  # [n, c, rows]
+    ref = F.group_norm(xr, 32, gamma.float(), beta.float(), eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(n * rows, c)
+    xl = x.reshape(n * rows, c)
+    if c2:
+        got = ops.groupnorm(xl[:, :c1].contiguous(), gamma, beta, n, rows, eps=eps, silu=silu, x2=xl[:, c1:].contiguous())
+    else:
+        got = ops.groupnorm(xl, gamma, beta, n, rows, eps=eps, silu=silu)
+    return _cmp(f"groupnorm n{n} rows{rows} c{c1}+{c2} silu{int(silu)}", got, ref, atol=4e-3)
+
+
+def case_layernorm(rows=999, c=640, seed=50):
+    from musev_amd import ops
+    x = _rand((rows, c), seed) * 2.0 + 0.5
+    gamma = _rand((c,), seed + 1) * 0.2 + 1.0
+    beta = _rand((c,), seed + 2, 0.2)
+    got = ops.layernorm(x, gamma, beta, 1e-5)
+    ref = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    return _cmp(f"layernorm rows{rows} c{c}", got, ref, atol=4e-3)
+
+
+def _attn_ref(q, ks, vs, heads, d, scale):
+    # q [nb, lq, C]; ks/vs [nb, lk, C] already gathered per query batch
+    nb, lq, c = q.shape
+    qh = q.float().view(nb, lq, heads, d).transpose(1, 2)
+    kh = ks.float().view(nb, -1, heads, d).transpose(1, 2)
+    vh = vs.float().view(nb, -1, heads, d).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    o = torch.softmax(s, dim=-1) @ vh
+    return o.transpose(1, 2).reshape(nb * lq, c)
+
+
+def case_attention_self(d=40, b=2, t=3, lq=200, cond_idx=0, seed=60, qscale=1.0):
+    """reference-only self attention: segments = [own frame, vision-condition frame of the same batch item]."""
+    from musev_amd import ops
+    heads = 8
+    c = heads * d
+    nb = b * t
+    qkv = _rand((nb * lq, 3 * c), seed, qscale)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    scale = d ** -0.5
+    got = ops.attention(q, [(k, v, lq, 1, 1, 0), (k, v, lq, t, t, cond_idx)], nb, lq, heads, d, scale)
+    k3, v3 = k.reshape(nb, lq, c), v.reshape(nb, lq, c)
+    cond = [(n // t) * t + cond_idx for n in range(nb)]
+    ks = torch.cat([k3, k3[cond]], dim=1)
+    vs = torch.cat([v3, v3[cond]], dim=1)
+    ref = _attn_ref(q.reshape(nb, lq, c), ks, vs, heads, d, scale)
+    return _cmp(f"attention self+cond d{d} nb{nb} lq{lq} qscale{qscale}", got, ref, atol=3e-3)
+
+
+def case_attention_cross(d=80, nb=6, t=3, lq=130, lk=77, seed=70, with_ip=True):
+    """text cross attention (keys per batch item, shared by its t frames) + IP-Adapter second attention."""
+    from musev_amd import ops
+    heads = 8
+    c = heads * d
+    b = nb // t
+    q = _rand((nb * lq, c), seed)
+    kv = _rand((b * lk, 2 * c), seed + 1)
+    k, v = kv[:, :c], kv[:, c:]
+    scale = d ** -0.5
+    got = ops.attention(q, [(k, v, lk, t, 1, 0)], nb, lq, heads, d, scale)
+    bidx = [n // t for n in range(nb)]
+    ref = _attn_ref(q.reshape(nb, lq, c), k.reshape(b, lk, c)[bidx], v.reshape(b, lk, c)[bidx], heads, d, scale)
+    if with_ip:
+        kvi = _rand((b * 4, 2 * c), seed + 2)
+        ki, vi = kvi[:, :c], kvi[:, c:]
+        got = ops.attention(q, [(ki, vi, 4, t, 1, 0)], nb, lq, heads, d, scale, out=got, accumulate=True, out_scale=0.7)
+        ref_ip = _attn_ref(q.reshape(nb, lq, c), ki.reshape(b, 4, c)[bidx], vi.reshape(b, 4, c)[bidx], heads, d, scale)
+        ref = ref.half().float() + 0.7 * ref_ip
+    return _cmp(f"attention cross d{d} nb{nb} lq{lq} lk{lk} ip{int(with_ip)}", got, ref, atol=3e-3)
+
+
+def case_attention_spike(d=40):
+    """forces online-softmax rescales: one key per 64-key tile has a much larger score than everything before it."""
+    from musev_amd import ops
+    heads, lq, lk, nb = 8, 64, 320, 1
+    c = heads * d
+    q = _rand((nb * lq, c), 80)
+    k = _rand((nb * lk, c), 81)
+    v = _rand((nb * lk, c), 82)
+    for tile in range(5):
+        k[tile * 64 + 7 * tile + 3] *= (2.0 + 1.5 * tile)  # growing spikes -> the running max jumps in every tile
+    scale = d ** -0.5
+    got = ops.attention(q, [(k, v, lk, 1, 1, 0)], nb, lq, heads, d, scale)
+    ref = _attn_ref(q.reshape(nb, lq, c), k.reshape(nb, lk, c), v.reshape(nb, lk, c), heads, d, scale)
+    return _cmp(f"attention spike d{d}", got, ref, atol=3e-3)
+
+
+def case_temporal_attention(b=2, t=13, hw=70, d=40, seed=90):
+    from musev_amd import ops
+    heads = 8
+    c = heads * d
+    qkv = _rand((b * t * hw, 3 * c), seed)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    scale = d ** -0.5
+    got = ops.temporal_attention(q, k, v, b, t, hw, heads, d, scale)
+
+    def seq(x):  # [(b t hw), c] -> [(b hw), t, c]
+        return x.reshape(b, t, hw, c).permute(0, 2, 1, 3).reshape(b * hw, t, c)
+    ref = _attn_ref(seq(q), seq(k), seq(v), heads, d, scale)  # [(b hw t), c]
+    ref = ref.reshape(b, hw, t, c).permute(0, 2, 1, 3).reshape(b * t * hw, c)
+    return _cmp(f"temporal_attention b{b} t{t} hw{hw} d{d}", got, ref, atol=3e-3)
+
+
+def case_geglu():
+    from musev_amd import ops
+    x = _rand((333, 2560), 100)
+    got = ops.geglu(x)
+    ref = x.float()[:, :1280] * F.gelu(x.float()[:, 1280:])
+    return _cmp("geglu", got, ref, atol=2e-3)
+
+
+def case_conv_in_out():
+    from musev_amd import ops
+    n, h, w = 3, 16, 24
+    x = _rand((n, 4, h, w), 110)
+    wt = _rand((320, 4, 3, 3), 111, 1.0 / 6.0)
+    b = _rand((320,), 112)
+    ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(n * h * w, 320)
+    xl = x.permute(0, 2, 3, 1).reshape(n * h * w, 4).contiguous()
+    got = ops.conv3x3_cin_small(xl, ops.pack_conv_weight(wt), b, n, h, w)
+    r1 = _cmp("conv_in 4->320", got, ref, atol=3e-3)
+    y = _rand((n, 320, h, w), 113)
+    wo = _rand((4, 320, 3, 3), 114, 1.0 / math.sqrt(2880))
+    bo = _rand((4,), 115)
+    ref2 = F.conv2d(y.float(), wo.float(), bo.float(), padding=1).permute(0, 2, 3, 1).reshape(n * h * w, 4)
+    yl = y.permute(0, 2, 3, 1).reshape(n * h * w, 320).contiguous()
+    got2 = ops.conv3x3_cout_small(yl, ops.pack_conv_weight(wo), bo, n, h, w)
+    r2 = _cmp("conv_out 320->4", got2, ref2, atol=3e-3)
+    r1["ok"] = r1["ok"] and r2["ok"]
+    r1["name"] = "conv_in/conv_out"
+    r1["max_abs_err"] = max(r1["max_abs_err"], r2["max_abs_err"])
+    return r1
+
+
+def case_timestep_embedding():
+    from musev_amd import ops
+    t = torch.tensor([951.0, 1.0, 0.0, 8.0, 96.0], device=DEV)
+    got = ops.timestep_embedding(t, 320)
+    half = 160
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, device=DEV, dtype=torch.float32) / half)
+    arg = t[:, None] * freq[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+    return _cmp("timestep_embedding", got, ref, atol=2e-3)
+
+
+def case_layout_and_misc():
+    from musev_amd import ops
+    x = _rand((2, 4, 5, 6, 7), 120, dtype=torch.float32)
+    y = ops.bcthw_to_bthwc(x)
+    ref = x.permute(0, 2, 3, 4, 1).reshape(-1, 4)
+    r = _cmp("bcthw_to_bthwc", y, ref, atol=1e-3)
+    back = ops.bthwc_to_bcthw(y, 2, 5, 6, 7, dtype=torch.float32)
+    r2 = _cmp("bthwc_to_bcthw", back, x.half().float(), atol=1e-6)
+    a = _rand((64, 40), 121)
+    s = ops.silu(a)
+    r3 = _cmp("silu", s, F.silu(a.float()), atol=1e-3)
+    z = a.clone()
+    ops.zero_rows(z, torch.tensor([3, 17], device=DEV))
+    refz = a.clone()
+    refz[[3, 17]] = 0
+    r4 = _cmp("zero_rows", z, refz, atol=0.0, rtol=0.0)
+    r5 = _cmp("add", ops.add(a, s), a.float() + s.float(), atol=1e-3)
+    ok = all(t["ok"] for t in (r, r2, r3, r4, r5))
+    return {"name": "layout+misc", "ok": ok, "max_abs_err": max(t["max_abs_err"] for t in (r, r2, r3, r4, r5)),
+            "parts": {t["name"]: t["ok"] for t in (r, r2, r3, r4, r5)}}
+
+
+def case_window_loop():
+    """gather / scatter-add / CFG + DDIM step against the torch expressions of pipeline_controlnet.py:1902-2117."""
+    from musev_amd import ops
+    c, t_total, hw, n_cond = 4, 20, 48, 1
+    g = torch.Generator().manual_seed(130)
+    lat = torch.randn((c, t_total, hw), generator=g).to(DEV)
+    cond = torch.randn((c, n_cond, hw), generator=g).to(DEV)
+    idx = torch.tensor([16, 17, 18, 19, 0, 1], dtype=torch.int32, device=DEV)
+    win = idx.numel()
+    inp = ops.window_gather(lat, cond, idx, n_cond, 2)
+    frames = torch.cat([cond, lat[:, idx.long()]], dim=1)  # [c, n_cond+win, hw]
+    ref_in = frames.permute(1, 2, 0).reshape(-1, c)
+    ref_in = torch.cat([ref_in, ref_in], dim=0)
+    r1 = _cmp("window_gather", inp, ref_in.half().float(), atol=1e-6)
+    eps_win = _rand((2 * (n_cond + win) * hw, c), 131)
+    acc = torch.zeros((2, c, t_total, hw), device=DEV)
+    cnt = torch.zeros((t_total,), device=DEV)
+    ops.window_scatter_add(eps_win, idx, n_cond, 2, 0, acc, cnt, True)
+    ops.window_scatter_add(eps_win, idx, n_cond, 2, 0, acc, cnt, True)
+    e = eps_win.float().reshape(2, n_cond + win, hw, c)[:, n_cond:].permute(0, 3, 1, 2)  # [2, c, win, hw]
+    ref_acc = torch.zeros_like(acc)
+    ref_acc[:, :, idx.long()] += 2 * e
+    ref_cnt = torch.zeros_like(cnt)
+    ref_cnt[idx.long()] += 2
+    r2 = _cmp("window_scatter_add", acc, ref_acc, atol=1e-6)
+    r3 = _cmp("counter", cnt, ref_cnt, atol=0.0)
+    # step on the covered frames only (others have counter 0): fill counter to avoid 0-division in the check
+    cnt2 = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
+    lat2 = lat.clone()
+    a_t, a_p, gs = 0.3, 0.45, 3.5
+    ops.cfg_ddim_step(lat2, acc, cnt2, gs, a_t, a_p)
+    eps = acc / cnt2[None, None, :, None]
+    eps = eps[0] + gs * (eps[1] - eps[0])
+    x0 = (lat - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
+    ref_lat = math.sqrt(a_p) * x0 + math.sqrt(1 - a_p) * eps
+    r4 = _cmp("cfg_ddim_step", lat2, ref_lat, atol=1e-5, rtol=1e-5)
+    parts = (r1, r2, r3, r4)
+    return {"name": "window loop glue", "ok": all(p["ok"] for p in parts), "max_abs_err": max(p["max_abs_err"] for p in parts),
+            "parts": {p["name"]: p["ok"] for p in parts}}
+
+
+ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
+    ("tr16_probe", case_tr16_probe),
+    ("gemm_plain", lambda: case_gemm(M=1000, N=320, K=640, epilogue=False)),
+    ("gemm_epilogue", lambda: case_gemm(M=1000, N=320, K=640)),
+    ("gemm_ragged", lambda: case_gemm(M=333, N=196, K=200, seed=3)),
+    ("gemm_two_src", lambda: case_gemm(M=517, N=640, K=960, two_src=True, seed=4)),
+    ("gemm_big", lambda: case_gemm(M=4096, N=1280, K=1280, seed=5)),
+    ("gemm_text_kv", lambda: case_gemm(M=154, N=640, K=768, epilogue=False, seed=6)),
+    ("gemm_silu", case_gemm_silu),
+    ("gemm_geglu", case_gemm_geglu),
+    ("conv3x3", case_conv3x3),
+    ("conv3x3_two_src", lambda: case_conv3x3(c1=128, c2=64, cout=160, seed=21)),
+    ("conv3x3_stride2", lambda: case_conv3x3(stride=2, seed=22)),
+    ("conv3x3_upsample", lambda: case_conv3x3(h=8, w=12, upsample=True, seed=23)),
+    ("conv3x3_wide", lambda: case_conv3x3(n=2, h=8, w=8, c1=1280, c2=1280, cout=1280, seed=24)),
+    ("tconv3", case_tconv3),
+    ("tconv3_t13", lambda: case_tconv3(b=2, t=13, hw=64, c=320, seed=31)),
+    ("groupnorm", case_groupnorm),
+    ("groupnorm_concat", lambda: case_groupnorm(n=2, rows=130, c1=640, c2=320, seed=41)),
+    ("groupnorm_nosilu_eps6", lambda: case_groupnorm(n=2, rows=4096, c1=320, silu=False, eps=1e-6, seed=42)),
+    ("groupnorm_c2560", lambda: case_groupnorm(n=2, rows=64, c1=1280, c2=1280, seed=43)),
+    ("layernorm_320", lambda: case_layernorm(c=320)),
+    ("layernorm_640", case_layernorm),
+    ("layernorm_1280", lambda: case_layernorm(c=1280, seed=51)),
+    ("attention_self_d40", case_attention_self),
+    ("attention_self_d80", lambda: case_attention_self(d=80, lq=100, seed=61)),
+    ("attention_self_d160", lambda: case_attention_self(d=160, lq=64, seed=62)),
+    ("attention_self_d40_big", lambda: case_attention_self(d=40, b=1, t=2, lq=1024, cond_idx=1, seed=63, qscale=2.0)),
+    ("attention_cross_d80", case_attention_cross),
+    ("attention_cross_d40", lambda: case_attention_cross(d=40, seed=71)),
+    ("attention_cross_d160", lambda: case_attention_cross(d=160, lq=64, seed=72)),
+    ("attention_spike", case_attention_spike),
+    ("temporal_attention", case_temporal_attention),
+    ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),
+    ("temporal_attention_t20", lambda: case_temporal_attention(b=1, t=20, hw=16, d=80, seed=92)),
+    ("geglu", case_geglu),
+    ("conv_in_out", case_conv_in_out),
+    ("timestep_embedding", case_timestep_embedding),
+    ("layout_misc", case_layout_and_misc),
+    ("window_loop", case_window_loop),
+]
