@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""bench.py -- MuseV parallel-denoise hot path on MI355X: denoised frames/sec @512x512, 12-frame window, 20 DDIM steps.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one denoise step of the hot path: for every window owned by this rank, window gather -> UNet3D forward
+(HIP kernels) -> prediction exchange (RCCL all-gather, N > 1 only) -> scatter-add / average / CFG / DDIM update.
+The metric is quoted for a 20-step denoise, so  value = generated_frames / (20 * seconds_per_step), aggregated over
+all ranks (the time is the MAX over ranks of K timed steps bracketed by barrier + device synchronize).
+
+Workloads (BASELINE.json configs; synthetic N(0,1) latents / prompt embeddings, seeded random fp16 weights of the
+real SD-1.5 MuseV architecture, 1.42 B parameters -- no checkpoints or datasets exist in this environment):
+  N = 1  : config 2 -- text2video `musev`, 512x512 (latent 64x64), 12 frames + 1 vision-condition frame, CFG batch 2.
+  N > 1  : the same per-GPU work (one 12-frame window x 2 CFG halves per rank): 8*N frames, window 12, overlap 4,
+           `uniform` closed-loop schedule => exactly N windows ("scaling": "weak").  Overlapping windows recompute 4
+           of every 12 frames, so the unique-frame rate of a perfectly parallel run is 8N/12 of N x the 1-GPU rate.
+  --workload config4 : 96 frames = 12 windows = 24 units, strong scaling over the ranks (north-star config 4).
+  --workload config3 : `musev_referencenet` + IP-Adapter (+13 ReferEmbFuse attentions), single window.
+
+Extra JSON objects (tier contract):
+  roofline      the dominant kernel (the implicit-GEMM family, MFMA-bound): algorithmic FLOPs per launch / launch
+                duration, measured live with HIP events on the launch stream in an instrumented repeat of the timed
+                steps; plus the whole-step figure (SURVEY.md 8d analytic FLOPs / step time).
+  cpu_baseline  the oracle (plain torch fp32) timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X (MI355X_MICROARCH.md)
+DENOISE_STEPS = 20
+
+
+def unet_flops(H, W, T, B, model="musev", n_vis=1, n_ip_tokens=4, text_tokens=77, xdim=768):
+    """Algorithmic FLOPs (2 x MACs of GEMM / conv / attention-matmul terms) of one UNet3D forward -- the analytic counter
+    of SURVEY.md Appendix C, kept identical so that roofline numerators agree with BASELINE.md."""
+    F_ = B * T
+    tot = 0
+
+    def res(cin, cout, hw):
+        return F_ * (hw * (9 * cin * cout + 9 * cout * cout + (cin * cout if cin != cout else 0)) + 1280 * cout)
+
+    def tconv(c, hw):
+        return F_ * hw * 12 * c * c
+
+    def t2d(c, hw):
+        kv = hw * (1 + n_vis)
+        lin = hw * c * c * 2
+        a1_lin = hw * c * c * 2 + kv * c * c * 2
+        a1_att = 2 * hw * kv * c
+        a2_lin = hw * c * c * 2 + text_tokens * xdim * c * 2
+        a2_att = 2 * hw * text_tokens * c
+        if model == "musev_referencenet":
+            a2_lin += n_ip_tokens * xdim * c * 2
+            a2_att += 2 * hw * n_ip_tokens * c
+        return F_ * (lin + a1_lin + a2_lin + hw * 12 * c * c + a1_att + a2_att)
+
+    def tt(c, hw):
+        tok = B * hw * T
+        return tok * c * c * 22 + tok * (2 * T * c) * 2
+
+    def refer(c, hw, ref_hw):
+        kv = ref_hw + hw
+        return F_ * (hw * c * c * 2 + kv * c * c * 2 + 2 * hw * kv * c)
+
+    hw0 = (H // 8) * (W // 8)
+    hws = [hw0, hw0 // 4, hw0 // 16, hw0 // 64]
+    ch = [320, 640, 1280, 1280]
+    rn = model == "musev_referencenet"
+    tot += F_ * hw0 * 9 * 4 * 320
+    if model == "musev":
+        tot += tt(320, hw0)
+    if rn:
+        tot += refer(320, hw0, hw0)
+    cin = 320
+    for i in range(4):
+        cout, hw = ch[i], hws[i]
+        for l in range(2):
+            tot += res(cin if l == 0 else cout, cout, hw) + tconv(cout, hw)
+            if i < 3:
+                tot += t2d(cout, hw) + tt(cout, hw)
+            if rn:
+                tot += refer(cout, hw, hw)
+        if i < 3:
+            tot += F_ * hws[i + 1] * 9 * cout * cout
+            if rn:
+                tot += refer(cout, hws[i + 1], hws[i + 1])
+        cin = cout
+    hw = hws[3]
+    tot += res(1280, 1280, hw) + tconv(1280, hw) + t2d(1280, hw) + tt(1280, hw) + res(1280, 1280, hw) + tconv(1280, hw)
+    if rn:
+        tot += refer(1280, hw, hw)
+    rev = [1280, 1280, 640, 320]
+    skips = [[1280, 1280, 1280], [1280, 1280, 640], [640, 640, 320], [320, 320, 320]]
+    prev = 1280
+    for i in range(4):
+        cout, hw = rev[i], hws[3 - i]
+        for l in range(3):
+            rin = (prev if l == 0 else cout) + skips[i][l]
+            tot += res(rin, cout, hw) + tconv(cout, hw)
+            if i > 0:
+                tot += t2d(cout, hw) + tt(cout, hw)
+        if i < 3:
+            tot += F_ * hws[3 - i - 1] * 9 * cout * cout
+        prev = cout
+    tot += F_ * hw0 * 9 * 320 * 4
+    return 2 * tot
+
+
+def refer_shapes(h, w):
+    ch, out = (320, 640, 1280, 1280), [(320, h, w)]
+    hh, ww = h, w
+    for i, c in enumerate(ch):
+        out += [(c, hh, ww)] * 2
+        if i != 3:
+            hh, ww = hh // 2, ww // 2
+            out.append((c, hh, ww))
+    return out, (1280, hh, ww)
+
+
+def cpu_baseline(flavour: str, full_flops: float, frames: int, threads: int):
+    """Oracle (kind "port": plain-torch fp32 restatement of the reference) timed on the host cores on a bounded
+    sample: one UNet forward, CFG batch 2, 1 condition + 1 generated frame at 64x64 latents (same weights shape, same
+    kernels of the reference path); extrapolated to the 13-frame forward by algorithmic FLOPs."""
+    from oracle import unet3d
+    torch.set_num_threads(threads)
+    cfg = unet3d.flavour_config(flavour)
+    sd = unet3d.init_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 2, 64, 64, generator=g)
+    ehs = torch.randn(2, 77, 768, generator=g)
+    kw = dict(sample_index=torch.tensor([1]), vision_conditon_frames_sample_index=torch.tensor([0]), sample_frame_rate=8)
+    t0 = time.time()
+    with torch.no_grad():
+        unet3d.unet3d_forward(sd, cfg, x, torch.tensor(951), ehs, **kw)
+    dt = time.time() - t0
+    sample_flops = unet_flops(512, 512, 2, 2, "musev" if flavour == "musev" else "musev_referencenet")
+    t_full = dt * full_flops / sample_flops
+    return {
+        "value": frames / (DENOISE_STEPS * t_full), "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"oracle UNet3D forward, CFG batch 2, 2 frames (1 cond + 1 generated) @64x64 latents: {dt:.1f} s for "
+                  f"{sample_flops / 1e12:.2f} TFLOP ({sample_flops / dt / 1e12:.3f} TFLOP/s); extrapolated by algorithmic FLOPs to the "
+                  f"{full_flops / 1e12:.1f} TFLOP per-step workload x {DENOISE_STEPS} steps",
+        "seconds_sample": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config3", "config4", "weak"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--size", type=int, default=512)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        group = dist.group.WORLD
+
+    from musev_amd import ops
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser, shard_units, group_units
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "config2" if world == 1 else "weak"
+    flavour = "musev_referencenet" if workload == "config3" else "musev"
+    n_cond, win = 1, 12
+    if workload in ("config2", "config3"):
+        T = 12
+    elif workload == "config4":
+        T = 96
+    else:
+        T = 12 if world == 1 else 8 * world
+    h = w = args.size // 8
+
+    # ---- model: real architecture, seeded random fp16 weights (same on every rank) ----
+    torch.manual_seed(3)
+    unet = load_unet_by_name(flavour, dtype=torch.float16)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for name, p in unet.named_parameters():  # re-randomise the reference's zero-initialised parameters
+            if name.endswith("temporal_weight"):
+                p.copy_(0.1 + 0.9 * torch.rand(p.shape, generator=g))
+            elif p.ndim >= 2:
+                fan_in = p[0].numel()
+                gain = 0.3 if name.endswith(("conv2.weight", "to_out.0.weight", "ff.net.2.weight", "proj_out.weight", "conv4.3.weight")) else 1.0
+                p.copy_((torch.randn(p.shape, generator=g) * (gain / fan_in ** 0.5)).to(p.dtype))
+    unet = unet.to(dev)
+
+    g = torch.Generator().manual_seed(0)
+    latents = torch.randn(1, 4, T, h, w, generator=g).to(dev)
+    prompt = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(1)).to(dev)
+    cond = (0.18215 * torch.randn(1, 4, n_cond, h, w, generator=torch.Generator().manual_seed(2))).to(dev)
+    unet_kwargs = {}
+    if flavour == "musev_referencenet":
+        shapes, mid = refer_shapes(h, w)
+        g4 = torch.Generator().manual_seed(4)
+        unet_kwargs["down_block_refer_embs"] = [torch.randn(1, c, 1, a, b_, generator=g4).repeat(2, 1, 1, 1, 1).to(dev) for c, a, b_ in shapes]
+        unet_kwargs["mid_block_refer_emb"] = torch.randn(1, mid[0], 1, mid[1], mid[2], generator=g4).repeat(2, 1, 1, 1, 1).to(dev)
+        unet_kwargs["vision_clip_emb"] = torch.randn(2, 4, 768, generator=torch.Generator().manual_seed(5)).to(dev)
+        unet_kwargs["ip_adapter_scale"] = 1.0
+
+    den = ParallelDenoiser(unet, context_frames=win, context_overlap=4, context_stride=1, context_schedule="uniform")
+    n_windows = len(den.windows(T, DENOISE_STEPS))
+    total = args.warmup + args.steps
+
+    # The loop object runs `num_inference_steps` steps; time the last K of (W + K) through the per-step callback.
+    marks = {}
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier(group)
+            torch.cuda.synchronize(dev)
+
+    def make_cb(first_timed):
+        def cb(step, t, lat):
+            if step + 1 == first_timed:  # end of warmup
+                sync_all()
+                marks["t0"] = time.perf_counter()
+        return cb
+
+    def run_steps(n_steps, cb=None):
+        # a DDIM schedule with n_steps entries: every step does identical work, which is all the timing needs
+        return den(latents, prompt, num_inference_steps=n_steps, guidance_scale=3.5, condition_latents=cond,
+                   motion_speed=8.0, unet_kwargs=unet_kwargs, group=group, callback=cb)
+
+    if args.warmup == 0:
+        sync_all()
+        marks["t0"] = time.perf_counter()
+    out = run_steps(total, make_cb(args.warmup))
+    sync_all()
+    elapsed = time.perf_counter() - marks["t0"]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=group)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = T / (DENOISE_STEPS * ms_per_step / 1e3)
+    finite = bool(torch.isfinite(out).all())
+
+    # ---- whole-step algorithmic FLOPs (what each rank executes per step, summed over ranks) ----
+    halves = 2
+    shards = shard_units(n_windows, halves, world)
+    step_flops = 0.0
+    for s in shards:
+        for _, hs in group_units(s):
+            step_flops += unet_flops(args.size, args.size, win + n_cond, len(hs), flavour, n_vis=n_cond)
+    per_rank_flops = max(sum(unet_flops(args.size, args.size, win + n_cond, len(hs), flavour, n_vis=n_cond) for _, hs in group_units(s)) for s in shards)
+
+    roofline = None
+    if not args.no_roofline:
+        # instrumented repeat of the same K steps: HIP events around every implicit-GEMM launch on the launch stream
+        ops.GEMM_PROFILE = []
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(min(args.steps, 4))
+        sync_all()
+        instr_ms = (time.perf_counter() - t0) * 1e3 / min(args.steps, 4)
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
+        agg = {}
+        for mode, M, N, K, geglu, e0, e1 in prof:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(names[mode], [0.0, 0.0, 0])
+            a[0] += 2.0 * M * N * K
+            a[1] += ms
+            a[2] += 1
+        fam_flops = sum(a[0] for a in agg.values())
+        fam_ms = sum(a[1] for a in agg.values())
+        fam_n = sum(a[2] for a in agg.values())
+        ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_kernel<MODE,TM,TN> (implicit-GEMM family: linear / conv3x3 / tconv3)",
+            "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": fam_n / min(args.steps, 4),
+            "avg_launch_ms": fam_ms / max(fam_n, 1),
+            "algorithmic_flops_per_launch": fam_flops / max(fam_n, 1),
+            "family_ms_per_step": fam_ms / min(args.steps, 4),
+            "by_mode": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0, "ms_per_step": v[1] / min(args.steps, 4),
+                            "launches_per_step": v[2] / min(args.steps, 4)} for k, v in agg.items()},
+            "instrumented_ms_per_step": instr_ms,
+            "whole_step": {"algorithmic_tflop_per_rank_step": per_rank_flops / 1e12,
+                           "achieved_tflops_per_gpu": per_rank_flops / (ms_per_step * 1e-3) / 1e12,
+                           "frac_of_mfma_peak": per_rank_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(flavour, unet_flops(args.size, args.size, win + n_cond, 2, flavour, n_vis=n_cond), T,
+                               threads=os.cpu_count() or 1)
+        except Exception as ex:  # noqa: BLE001 -- the baseline is a report, never a reason to lose the GPU number
+            cpu = {"error": repr(ex)}
+
+    if rank == 0:
+        line = {
+            "metric": "denoised frames/sec @512x512, 12-frame window, 20 DDIM steps",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if workload == "config4" else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{workload}: {flavour}, {args.size}x{args.size}, {T} frames (+{n_cond} vision-condition frame per window), "
+                                   f"window {win} overlap 4 -> {n_windows} window(s) x 2 CFG halves = {n_windows * 2} units over {world} GPU(s), "
+                                   f"{DENOISE_STEPS} DDIM steps, guidance 3.5",
+                       "frames": T, "windows": n_windows, "units_per_gpu_max": max(len(s) for s in shards),
+                       "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
+                       "output_finite": finite},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

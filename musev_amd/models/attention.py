@@ -1,0 +1,82 @@
+"""BasicTransformerBlock of the reference (musev/models/attention.py:52-431) on HIP kernels.
+
+Spatial instance: attn1 = reference-only self-attention, attn2 = text cross-attention (+ IP-Adapter), GEGLU FF.
+Temporal instance (double_self_attention=True): attn1 and attn2 are self-attention over the T frames of each pixel.
+Not restated: the classifier-free-guidance recompute at attention.py:319-334 -- its result is overwritten before it
+is read (dead code)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from .layers import FeedForward, HipModule, IPAttention, lin_w, w16
+from .runtime import Ctx, Geo, SourceCache
+
+
+class BasicTransformerBlock(HipModule):
+    def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, cross_attention_dim: Optional[int] = None,
+                 double_self_attention: bool = False, only_cross_attention: bool = False, attention_bias: bool = False,
+                 cross_attn_temporal_cond: bool = False, ip_adapter_cross_attn: bool = False,
+                 need_t2i_facein: bool = False, need_t2i_ip_adapter_face: bool = False, processor=None, **_unused):
+        super().__init__()
+        if only_cross_attention:
+            raise NotImplementedError("only_cross_attention is not used by any shipped MuseV flavour")
+        if not only_cross_attention and double_self_attention:
+            cross_attention_dim = None  # attention.py:80-81
+        self.double_self_attention = double_self_attention
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = IPAttention(dim, None, num_attention_heads, attention_head_dim, bias=attention_bias,
+                                 cross_attn_temporal_cond=cross_attn_temporal_cond, ip_adapter_dim=attention_head_dim,
+                                 processor=processor)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = IPAttention(dim, cross_attention_dim if not double_self_attention else None, num_attention_heads,
+                                 attention_head_dim, bias=attention_bias, cross_attn_temporal_cond=ip_adapter_cross_attn,
+                                 ip_adapter_dim=cross_attention_dim if not double_self_attention else attention_head_dim,
+                                 need_t2i_facein=need_t2i_facein, need_t2i_ip_adapter_face=need_t2i_ip_adapter_face,
+                                 processor=processor)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+        self.heads, self.dim_head = num_attention_heads, attention_head_dim
+
+    def _ln(self, m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+        return ops.layernorm(x, w16(m.weight), w16(m.bias), m.eps)
+
+    # ---- spatial: rows = (frame n, pixel p), sequences = the HW pixels of one frame ----
+    def hip_forward_spatial(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool, use_ip: bool) -> torch.Tensor:
+        c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
+        a1 = self.attn1
+        qkv = ops.gemm(self._ln(self.norm1, x), a1.w_qkv())
+        k, v = qkv[:, c:2 * c], qkv[:, 2 * c:]
+        segs = [(k, v, geo.hw, 1, 1, 0)]
+        if reference_only and ctx.vis_idx is not None and geo.t > 1:
+            # attention_processor.py:431-468: append the vision-condition frame(s) of the same batch item; their K/V
+            # projections are the rows already computed for that frame
+            for ci in ctx.vis_idx:
+                segs.append((k, v, geo.hw, geo.t, geo.t, int(ci)))
+        att = ops.attention(qkv[:, :c], segs, geo.n, geo.hw, h, d, a1.scale)
+        x = a1.project_out(att, residual=x)
+
+        a2 = self.attn2
+        q = ops.gemm(self._ln(self.norm2, x), lin_w(a2.to_q))
+        cache = a2._cache()
+        # K/V of the prompt: constant over the denoise loop -> projected once per (prompt tensor, weights)
+        tkv = cache.setdefault("text_kv", SourceCache()).get(ctx.text_src, lambda _s: ops.gemm(ctx.text, a2.w_kv()))
+        att = ops.attention(q, [(tkv[:, :c], tkv[:, c:], ctx.text_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale)
+        if use_ip and a2.cross_attn_temporal_cond and ctx.clip is not None and ctx.ip_scale > 0:
+            ikv = cache.setdefault("clip_kv", SourceCache()).get(ctx.clip_src, lambda _s: ops.gemm(ctx.clip, a2.w_kv_ip()))
+            ops.attention(q, [(ikv[:, :c], ikv[:, c:], ctx.clip_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale,
+                          out=att, accumulate=True, out_scale=ctx.ip_scale)
+        x = a2.project_out(att, residual=x)
+        return self.ff.hip_forward(self._ln(self.norm3, x), residual=x)
+
+    # ---- temporal: rows stay in (b, t, p) order; sequences = the T frames of one pixel ----
+    def hip_forward_temporal(self, x: torch.Tensor, geo: Geo) -> torch.Tensor:
+        c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
+        for norm, attn in ((self.norm1, self.attn1), (self.norm2, self.attn2)):
+            qkv = ops.gemm(self._ln(norm, x), attn.w_qkv())
+            att = ops.temporal_attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], geo.b, geo.t, geo.hw, h, d, attn.scale)
+            x = attn.project_out(att, residual=x)
+        return self.ff.hip_forward(self._ln(self.norm3, x), residual=x)

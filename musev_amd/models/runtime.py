@@ -1,0 +1,80 @@
+"""Per-forward runtime context shared by the HIP-backed modules: tensor geometry, conditioning rows and caches.
+
+Activations travel as fp16 2-D "rows x channels" tensors in (b, t, y, x) row order -- i.e. the canonical
+[B, T, H, W, C] layout flattened.  All three views the reference materialises with permute copies
+("(b t) c h w", "b c t h w", "(b h w) t c"; resnet.py:106-133, temporal_transformer.py:234-279) are index
+arithmetic on this one buffer."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+
+@dataclass
+class Geo:
+    b: int
+    t: int
+    h: int
+    w: int
+
+    @property
+    def n(self) -> int:  # frames through the spatial layers
+        return self.b * self.t
+
+    @property
+    def hw(self) -> int:
+        return self.h * self.w
+
+    @property
+    def rows(self) -> int:
+        return self.b * self.t * self.h * self.w
+
+    def down(self) -> "Geo":
+        return Geo(self.b, self.t, (self.h + 2 - 3) // 2 + 1, (self.w + 2 - 3) // 2 + 1)
+
+    def up(self) -> "Geo":
+        return Geo(self.b, self.t, self.h * 2, self.w * 2)
+
+
+@dataclass
+class Ctx:
+    """Everything a block needs besides its activations."""
+    temb_act: torch.Tensor            # [N, 1280] fp16: act(temb) as consumed by ResnetBlock2D.time_emb_proj
+    femb_act: Optional[torch.Tensor]  # [B*T, 1280] fp16: SiLU(femb) as consumed by frame_emb_proj
+    text: torch.Tensor                # [B*L_text, cross_dim] fp16 rows of encoder_hidden_states
+    text_len: int
+    vis_idx: Optional[List[int]]      # vision-condition frame positions inside the window (host ints)
+    clip: Optional[torch.Tensor]      # [B*L_ip, cross_dim] fp16 rows of vision_clip_emb
+    clip_len: int
+    ip_scale: float
+    skip_temporal: bool
+    text_src: Optional[torch.Tensor] = None  # the caller's tensors the rows were made from (cache identity)
+    clip_src: Optional[torch.Tensor] = None
+
+
+def tensor_key(t: Optional[torch.Tensor]) -> tuple:
+    """Identity of a tensor's current contents for caching derived data across denoise steps: storage pointer,
+    shape/strides and the in-place version counter (shared by all views of one storage).  A key is only meaningful
+    while the tensor it was taken from is alive -- SourceCache keeps a strong reference for exactly that reason
+    (otherwise the caching allocator may hand the same address to a different tensor)."""
+    if t is None:
+        return ()
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, str(t.dtype))
+
+
+class SourceCache:
+    """value derived from a source tensor, recomputed when the source changes identity or is modified in place"""
+
+    __slots__ = ("src", "key", "value")
+
+    def __init__(self):
+        self.src, self.key, self.value = None, None, None
+
+    def get(self, src: torch.Tensor, build):
+        key = tensor_key(src)
+        if self.key != key or self.src is None:
+            self.value = build(src)
+            self.src, self.key = src, key  # the strong reference pins the storage, so the pointer cannot be recycled
+        return self.value

@@ -1,0 +1,452 @@
+"""UNet3DConditionModel: drop-in for ``musev.models.unet_3d_condition.UNet3DConditionModel``
+(reference musev/models/unet_3d_condition.py:179-1740) whose forward runs entirely in hand-written gfx950 kernels.
+
+Same constructor keywords (:213-258), forward signature (:773-803), return convention (tuple / UNet3DConditionOutput),
+attributes used by the pipeline (.dtype, .device, .config.in_channels, .ip_adapter_cross_attn,
+.set_skip_temporal_layers, .spatial_cross_attns) and the same state_dict keys, so checkpoints written for
+the reference load with ``load_state_dict``.  There is no eager fallback: the module only runs on a GPU tensor.
+
+Data layout: the network input [b, c, t, h, w] is converted once to channels-last fp16 rows [(b t h w), c]; every
+block consumes and produces that layout; the output is converted back at the end (:1008, :1263)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Dict, List, Literal, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from .. import ops
+from . import Model_Register
+from .attention_processor import (BaseIPAttnProcessor, NonParamReferenceIPXFormersAttnProcessor,  # noqa: F401 (registry)
+                                  NonParamT2ISelfReferenceXFormersAttnProcessor, ReferEmbFuseAttention,
+                                  T2IReferencenetIPAdapterXFormersAttnProcessor)
+from .layers import HipModule, TimestepEmbedding, bump_pack_epoch, w16
+from .resnet import TemporalConvLayer  # noqa: F401 (registry)
+from .runtime import Ctx, Geo, tensor_key
+from .temporal_transformer import TransformerTemporalModel  # noqa: F401 (registry)
+from .transformer_2d import Transformer2DModel
+from .unet_3d_blocks import UNetMidBlock3DCrossAttn, get_down_block, get_up_block
+
+
+@dataclass
+class UNet3DConditionOutput:
+    """reference :166-176"""
+    sample: torch.Tensor
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class UNet3DConditionModel(HipModule):
+    _supports_gradient_checkpointing = False
+
+    def __init__(
+        self,
+        sample_size: Optional[int] = None,
+        in_channels: int = 4,
+        out_channels: int = 4,
+        down_block_types: Tuple[str] = ("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
+        up_block_types: Tuple[str] = ("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"),
+        block_out_channels: Tuple[int] = (320, 640, 1280, 1280),
+        layers_per_block: int = 2,
+        downsample_padding: int = 1,
+        mid_block_scale_factor: float = 1,
+        act_fn: str = "silu",
+        norm_num_groups: Optional[int] = 32,
+        norm_eps: float = 1e-5,
+        cross_attention_dim: int = 1024,
+        attention_head_dim: Union[int, Tuple[int]] = 8,
+        temporal_conv_block: str = "TemporalConvLayer",
+        temporal_transformer: str = "TransformerTemporalModel",
+        need_spatial_position_emb: bool = False,
+        need_transformer_in: bool = True,
+        need_t2i_ip_adapter: bool = False,
+        need_adain_temporal_cond: bool = False,
+        t2i_ip_adapter_attn_processor: str = "NonParamT2ISelfReferenceXFormersAttnProcessor",
+        keep_vision_condtion: bool = False,
+        use_anivv1_cfg: bool = False,
+        resnet_2d_skip_time_act: bool = False,
+        need_zero_vis_cond_temb: bool = True,
+        norm_spatial_length: bool = False,
+        spatial_max_length: int = 2048,
+        need_refer_emb: bool = False,
+        ip_adapter_cross_attn: bool = False,
+        t2i_crossattn_ip_adapter_attn_processor: str = "T2IReferencenetIPAdapterXFormersAttnProcessor",
+        need_t2i_facein: bool = False,
+        need_t2i_ip_adapter_face: bool = False,
+        need_vis_cond_mask: bool = False,
+    ):
+        super().__init__()
+        cfg = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
+        self.config = SimpleNamespace(**cfg)  # stands in for diffusers' register_to_config
+        # ---- input checks, same messages as the reference (:313-328) ----
+        if len(down_block_types) != len(up_block_types):
+            raise ValueError(f"Must provide the same number of `down_block_types` as `up_block_types`. `down_block_types`: {down_block_types}. `up_block_types`: {up_block_types}.")
+        if len(block_out_channels) != len(down_block_types):
+            raise ValueError(f"Must provide the same number of `block_out_channels` as `down_block_types`. `block_out_channels`: {block_out_channels}. `down_block_types`: {down_block_types}.")
+        if not isinstance(attention_head_dim, int) and len(attention_head_dim) != len(down_block_types):
+            raise ValueError(f"Must provide the same number of `attention_head_dim` as `down_block_types`. `attention_head_dim`: {attention_head_dim}. `down_block_types`: {down_block_types}.")
+        if act_fn not in ("silu", "swish"):
+            raise NotImplementedError("only act_fn='silu' (SD-1.5)")
+        if need_spatial_position_emb:
+            raise NotImplementedError("need_spatial_position_emb=True is unused by all shipped configs")
+        if norm_num_groups is None:
+            raise NotImplementedError("norm_num_groups=None")
+        if mid_block_scale_factor != 1:
+            raise NotImplementedError("mid_block_scale_factor != 1")
+
+        self.keep_vision_condtion = keep_vision_condtion
+        self.use_anivv1_cfg = use_anivv1_cfg
+        self.sample_size = sample_size
+        self.resnet_2d_skip_time_act = resnet_2d_skip_time_act
+        self.need_zero_vis_cond_temb = need_zero_vis_cond_temb
+        self.need_refer_emb = need_refer_emb
+        self.ip_adapter_cross_attn = ip_adapter_cross_attn
+        self.need_t2i_facein = need_t2i_facein
+        self.need_t2i_ip_adapter_face = need_t2i_ip_adapter_face
+        self.need_spatial_position_emb = need_spatial_position_emb
+        self.need_transformer_in = need_transformer_in
+        self.need_t2i_ip_adapter = need_t2i_ip_adapter
+        self.need_adain_temporal_cond = need_adain_temporal_cond  # AdaIN is a no-op for 4-D inputs (Appendix B.1)
+        self.t2i_ip_adapter_attn_processor = t2i_ip_adapter_attn_processor
+        self.need_vis_cond_mask = need_vis_cond_mask
+        self.layers_per_block = layers_per_block
+        self.block_out_channels = block_out_channels
+
+        self.conv_in = nn.Conv2d(in_channels, block_out_channels[0], 3, padding=1)
+        time_embed_dim = block_out_channels[0] * 4
+        self.time_embedding = TimestepEmbedding(block_out_channels[0], time_embed_dim)
+        frame_embed_dim = block_out_channels[0] * 4
+        # resolve block classes by name through the registry, like the reference (:382-395)
+        tconv_cls = (Model_Register[temporal_conv_block]
+                     if isinstance(temporal_conv_block, str) and temporal_conv_block.lower() != "none" else None)
+        ttrans_cls = (Model_Register[temporal_transformer]
+                      if isinstance(temporal_transformer, str) and temporal_transformer.lower() != "none" else None)
+        self.frame_embedding = TimestepEmbedding(block_out_channels[0], frame_embed_dim) if temporal_transformer is not None else None
+
+        if need_transformer_in and ttrans_cls is not None:
+            self.transformer_in = ttrans_cls(num_attention_heads=attention_head_dim if isinstance(attention_head_dim, int) else attention_head_dim[0],
+                                             attention_head_dim=block_out_channels[0] // (attention_head_dim if isinstance(attention_head_dim, int) else attention_head_dim[0]),
+                                             in_channels=block_out_channels[0], num_layers=1, femb_channels=frame_embed_dim,
+                                             cross_attention_dim=cross_attention_dim)
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * len(down_block_types)
+
+        need_t2i_ip_adapter_param = (t2i_ip_adapter_attn_processor is not None
+                                     and "NonParam" not in t2i_ip_adapter_attn_processor and need_t2i_ip_adapter)
+        if need_t2i_ip_adapter_param:
+            raise NotImplementedError("parametric T2I IP-Adapter self-attention is not used by any shipped flavour")
+
+        if need_refer_emb:
+            self.first_refer_emb_attns = ReferEmbFuseAttention(query_dim=block_out_channels[0], heads=attention_head_dim[0],
+                                                               dim_head=block_out_channels[0] // attention_head_dim[0])
+            self.mid_block_refer_emb_attns = ReferEmbFuseAttention(query_dim=block_out_channels[-1], heads=attention_head_dim[-1],
+                                                                   dim_head=block_out_channels[-1] // attention_head_dim[-1])
+        else:
+            self.first_refer_emb_attns = None
+            self.mid_block_refer_emb_attns = None
+
+        common = dict(temb_channels=time_embed_dim, femb_channels=frame_embed_dim, resnet_eps=norm_eps,
+                      resnet_groups=norm_num_groups, cross_attention_dim=cross_attention_dim,
+                      temporal_conv_block=tconv_cls, temporal_transformer=ttrans_cls,
+                      need_t2i_ip_adapter=need_t2i_ip_adapter_param, ip_adapter_cross_attn=ip_adapter_cross_attn,
+                      need_t2i_facein=need_t2i_facein, need_t2i_ip_adapter_face=need_t2i_ip_adapter_face,
+                      resnet_2d_skip_time_act=resnet_2d_skip_time_act)
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])
+        output_channel = block_out_channels[0]
+        for i, down_block_type in enumerate(down_block_types):
+            input_channel = output_channel
+            output_channel = block_out_channels[i]
+            is_final_block = i == len(block_out_channels) - 1
+            self.down_blocks.append(get_down_block(
+                down_block_type, num_layers=layers_per_block, in_channels=input_channel, out_channels=output_channel,
+                add_downsample=not is_final_block, attn_num_head_channels=attention_head_dim[i],
+                downsample_padding=downsample_padding, need_refer_emb=need_refer_emb, **common))
+        self.mid_block = UNetMidBlock3DCrossAttn(in_channels=block_out_channels[-1],
+                                                 attn_num_head_channels=attention_head_dim[-1], **common)
+        self.num_upsamplers = 0
+        rev_ch = list(reversed(block_out_channels))
+        rev_heads = list(reversed(attention_head_dim))
+        output_channel = rev_ch[0]
+        for i, up_block_type in enumerate(up_block_types):
+            is_final_block = i == len(block_out_channels) - 1
+            prev_output_channel = output_channel
+            output_channel = rev_ch[i]
+            input_channel = rev_ch[min(i + 1, len(block_out_channels) - 1)]
+            if not is_final_block:
+                self.num_upsamplers += 1
+            self.up_blocks.append(get_up_block(
+                up_block_type, num_layers=layers_per_block + 1, in_channels=input_channel, out_channels=output_channel,
+                prev_output_channel=prev_output_channel, add_upsample=not is_final_block,
+                attn_num_head_channels=rev_heads[i], **common))
+        self.conv_norm_out = nn.GroupNorm(num_channels=block_out_channels[0], num_groups=norm_num_groups, eps=norm_eps)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(block_out_channels[0], out_channels, 3, padding=1)
+
+        # which key/value segments the spatial attn1 uses is selected by the processor name, as in
+        # hack_t2i_sd_layer_attn_with_ip (:116-137)
+        reference_only = False
+        if need_t2i_ip_adapter and t2i_ip_adapter_attn_processor is not None:
+            proc = Model_Register[t2i_ip_adapter_attn_processor]
+            reference_only = getattr(proc, "mode", "") == "self_reference"
+        if ip_adapter_cross_attn and t2i_crossattn_ip_adapter_attn_processor is not None:
+            if getattr(Model_Register[t2i_crossattn_ip_adapter_attn_processor], "mode", "") != "cross_ip":
+                raise NotImplementedError(f"unsupported cross-attn processor {t2i_crossattn_ip_adapter_attn_processor}")
+        for m in self.modules():
+            if isinstance(m, Transformer2DModel):
+                m.reference_only = reference_only
+        self.insert_spatial_self_attn_idx()
+        self.skip_refer_downblock_emb = False
+        self._param_version = None
+        self._collect = None  # tests: dict receiving named block outputs (channels-last rows + geometry)
+
+    # ---- introspection used by the reference's loaders -------------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.conv_in.weight.device
+
+    def _spatial_blocks(self):
+        out = []
+        for name, m in self.named_modules():
+            if isinstance(m, Transformer2DModel):
+                for i, blk in enumerate(m.transformer_blocks):
+                    out.append((f"{name}.transformer_blocks.{i}", blk))
+        return out
+
+    @property
+    def spatial_self_attns(self):
+        """(attn1 modules, their BasicTransformerBlocks) of the spatial transformers (reference :1677-1700)"""
+        blocks = self._spatial_blocks()
+        return [(n + ".attn1", b.attn1) for n, b in blocks], blocks
+
+    @property
+    def spatial_cross_attns(self):
+        """used by ip_adapter_loader.update_unet_ip_adapter_cross_attn_param (ip_adapter_loader.py:308-340)"""
+        blocks = self._spatial_blocks()
+        return [(n + ".attn2", b.attn2) for n, b in blocks], blocks
+
+    def insert_spatial_self_attn_idx(self):
+        attns, blocks = self.spatial_self_attns
+        self.self_attn_num = len(attns)
+        for i, (_, layer) in enumerate(attns):
+            layer.spatial_self_attn_idx = i
+        for i, (_, layer) in enumerate(blocks):
+            layer.spatial_self_attn_idx = i
+
+    def set_skip_temporal_layers(self, valid: bool) -> None:
+        """reference :1639-1661: every module exposing ``skip_temporal_layers`` gets the flag"""
+        for m in self.modules():
+            if hasattr(m, "skip_temporal_layers"):
+                m.skip_temporal_layers = valid
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):  # pipeline compatibility no-op
+        return None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        bump_pack_epoch()  # packed weights live on the old device / dtype
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        bump_pack_epoch()
+        return out
+
+    def _check_param_versions(self):
+        v = 0
+        for p in self.parameters():
+            v += p._version
+        if v != self._param_version:
+            if self._param_version is not None:
+                bump_pack_epoch()  # some weight was edited in place (e.g. LoRA merge): re-pack lazily
+            self._param_version = v
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+        self,
+        sample: torch.FloatTensor,
+        timestep: Union[torch.Tensor, float, int],
+        encoder_hidden_states: torch.Tensor,
+        class_labels: Optional[torch.Tensor] = None,
+        timestep_cond: Optional[torch.Tensor] = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+        down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
+        mid_block_additional_residual: Optional[torch.Tensor] = None,
+        return_dict: bool = True,
+        sample_index: torch.LongTensor = None,
+        vision_condition_frames_sample: torch.Tensor = None,
+        vision_conditon_frames_sample_index: torch.LongTensor = None,
+        sample_frame_rate: int = 10,
+        skip_temporal_layers: bool = None,
+        frame_index: torch.LongTensor = None,
+        down_block_refer_embs: Optional[Tuple[torch.Tensor]] = None,
+        mid_block_refer_emb: Optional[torch.Tensor] = None,
+        refer_self_attn_emb: Optional[List[torch.Tensor]] = None,
+        refer_self_attn_emb_mode: Literal["read", "write"] = "read",
+        vision_clip_emb: torch.Tensor = None,
+        ip_adapter_scale: float = 1.0,
+        face_emb: torch.Tensor = None,
+        facein_scale: float = 1.0,
+        ip_adapter_face_emb: torch.Tensor = None,
+        ip_adapter_face_scale: float = 1.0,
+        do_classifier_free_guidance: bool = False,
+        pose_guider_emb: torch.Tensor = None,
+    ) -> Union[UNet3DConditionOutput, Tuple]:
+        if not sample.is_cuda:
+            raise RuntimeError("musev_amd.UNet3DConditionModel runs only on an MI355X (HIP) device; there is no CPU path")
+        if sample.ndim != 5:
+            raise ValueError(f"sample must be b c t h w, got ndim={sample.ndim}")
+        b, _, t, h, w = sample.shape
+        rows = self.forward_rows(
+            ops.bcthw_to_bthwc(sample), b, t, h, w, timestep, encoder_hidden_states, class_labels=class_labels,
+            timestep_cond=timestep_cond, attention_mask=attention_mask,
+            down_block_additional_residuals=down_block_additional_residuals,
+            mid_block_additional_residual=mid_block_additional_residual, sample_index=sample_index,
+            vision_condition_frames_sample=vision_condition_frames_sample,
+            vision_conditon_frames_sample_index=vision_conditon_frames_sample_index, sample_frame_rate=sample_frame_rate,
+            skip_temporal_layers=skip_temporal_layers, frame_index=frame_index, down_block_refer_embs=down_block_refer_embs,
+            mid_block_refer_emb=mid_block_refer_emb, refer_self_attn_emb=refer_self_attn_emb, vision_clip_emb=vision_clip_emb,
+            ip_adapter_scale=ip_adapter_scale, face_emb=face_emb, ip_adapter_face_emb=ip_adapter_face_emb,
+            pose_guider_emb=pose_guider_emb)
+        out_dtype = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float32
+        out = ops.bthwc_to_bcthw(rows, b, t, h, w, dtype=out_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    @torch.no_grad()
+    def forward_rows(self, x: torch.Tensor, b: int, t: int, h: int, w: int, timestep, encoder_hidden_states: torch.Tensor, *,
+                     class_labels=None, timestep_cond=None, attention_mask=None, down_block_additional_residuals=None,
+                     mid_block_additional_residual=None, sample_index=None, vision_condition_frames_sample=None,
+                     vision_conditon_frames_sample_index=None, sample_frame_rate=10, skip_temporal_layers=None,
+                     frame_index=None, down_block_refer_embs=None, mid_block_refer_emb=None, refer_self_attn_emb=None,
+                     vision_clip_emb=None, ip_adapter_scale: float = 1.0, face_emb=None, ip_adapter_face_emb=None,
+                     pose_guider_emb=None) -> torch.Tensor:
+        """The network on channels-last rows: x fp16 [(b t h w), in_channels] -> fp16 [(b t h w), out_channels].
+        Used directly by musev_amd.pipelines.parallel_denoise (which builds window inputs in this layout)."""
+        for name, val in (("class_labels", class_labels), ("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
+                          ("vision_condition_frames_sample", vision_condition_frames_sample), ("frame_index", frame_index),
+                          ("refer_self_attn_emb", refer_self_attn_emb), ("face_emb", face_emb),
+                          ("ip_adapter_face_emb", ip_adapter_face_emb)):
+            if val is not None:
+                raise NotImplementedError(f"{name} is outside the hot-path scope of this build (SURVEY.md 8)")
+        if skip_temporal_layers is not None:
+            self.set_skip_temporal_layers(skip_temporal_layers)
+        self._check_param_versions()
+
+        if any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w)):
+            raise NotImplementedError("latent height/width must be multiples of 2**num_upsamplers")
+        geo = Geo(b, t, h, w)
+        dev = x.device
+        ch0 = self.block_out_channels[0]
+
+        # ---- 1. time embedding (:887-906) ----
+        if not torch.is_tensor(timestep):
+            tt = torch.tensor([float(timestep)], dtype=torch.float32, device=dev)
+        else:
+            tt = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        tt = tt.expand(b).repeat_interleave(t).contiguous()  # one row per frame: emb.repeat_interleave(num_frames)
+        emb = self.time_embedding.hip_forward(ops.timestep_embedding(tt, ch0), final_silu=self.use_anivv1_cfg)
+        vis_idx = None
+        if vision_conditon_frames_sample_index is not None:
+            vis_idx = [int(i) for i in vision_conditon_frames_sample_index.reshape(-1).tolist()]
+        if self.keep_vision_condtion and t > 1 and sample_index is not None and vis_idx is not None:
+            rows = torch.tensor([bi * t + i for bi in range(b) for i in vis_idx], dtype=torch.int32, device=dev)
+            ops.zero_rows(emb, rows)
+        temb_act = emb if self.resnet_2d_skip_time_act else ops.silu(emb)  # ResnetBlock2D applies SiLU unless skip_time_act
+
+        # ---- frame embedding (:909-937): window-local positions ----
+        femb_act = None
+        if self.frame_embedding is not None:
+            fi = torch.arange(t, dtype=torch.float32, device=dev)
+            if self.use_anivv1_cfg:
+                fi = (torch.arange(t, device=dev) * sample_frame_rate).to(dtype=torch.long).to(torch.float32)
+            fi = fi.repeat(b).contiguous()  # rows (b, t)
+            femb = self.frame_embedding.hip_forward(ops.timestep_embedding(fi, ch0), final_silu=self.use_anivv1_cfg)
+            femb_act = ops.silu(femb)  # TransformerTemporalModel.nonlinearity (temporal_transformer.py:247-249)
+
+        # ---- conditioning rows ----
+        if encoder_hidden_states.ndim != 3:
+            raise NotImplementedError("only 3-D encoder_hidden_states [b, n, q] (per-frame 4-D text is outside this build)")
+        if encoder_hidden_states.shape[0] != b:
+            raise ValueError(f"encoder_hidden_states batch {encoder_hidden_states.shape[0]} != sample batch {b}")
+        text = encoder_hidden_states.to(dtype=torch.float16).reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
+        clip, clip_len = None, 0
+        if self.ip_adapter_cross_attn and vision_clip_emb is not None:
+            if vision_clip_emb.ndim != 3 or vision_clip_emb.shape[0] != b:
+                raise NotImplementedError("vision_clip_emb must be [b, n, q]")
+            clip = vision_clip_emb.to(dtype=torch.float16).reshape(-1, vision_clip_emb.shape[-1]).contiguous()
+            clip_len = vision_clip_emb.shape[1]
+        ctx = Ctx(temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
+                  clip=clip, clip_len=clip_len, ip_scale=float(ip_adapter_scale), skip_temporal=False,
+                  text_src=encoder_hidden_states, clip_src=vision_clip_emb)
+
+        # ---- 2. pre-process (:1008-1063) ----
+        pose = None
+        if pose_guider_emb is not None:
+            pose = pose_guider_emb.to(torch.float16).permute(0, 2, 3, 1).reshape(geo.rows, ch0).contiguous()
+        w_in = self.packed("conv_in", lambda: ops.pack_conv_weight(self.conv_in.weight.detach()))
+        x = ops.conv3x3_cin_small(x, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose)
+        self._tap("conv_in", x, geo)
+        if self.need_transformer_in:
+            x = self.transformer_in.hip_forward(x, ctx, geo)
+            self._tap("transformer_in", x, geo)
+        use_refer = self.need_refer_emb and down_block_refer_embs is not None and not self.skip_refer_downblock_emb
+        if use_refer:
+            x = self.first_refer_emb_attns.hip_forward(x, down_block_refer_embs[0], geo)
+
+        # ---- 3. down (:1076-1156) ----
+        skips: List[torch.Tensor] = [x]
+        for i, blk in enumerate(self.down_blocks):
+            refer = None
+            if use_refer:
+                is_final_block = i == len(self.block_out_channels) - 1
+                num_block = self.layers_per_block + int(not is_final_block * 1)  # reference quirk (:1090-1095)
+                start = 1 + num_block * i
+                refer = down_block_refer_embs[start:start + num_block]
+            x, geo, outs = blk.hip_forward(x, ctx, geo, refer)
+            skips.extend(o for o, _ in outs)
+            for j, (o, g_) in enumerate(outs):
+                self._tap(f"down_blocks.{i}.out{j}", o, g_)
+        if down_block_additional_residuals is not None:
+            skips = [ops.add(s, self._nchw_rows(r)) for s, r in zip(skips, down_block_additional_residuals)]
+
+        # ---- 4. mid (:1159-1195) ----
+        x = self.mid_block.hip_forward(x, ctx, geo)
+        if self.mid_block_refer_emb_attns is not None and mid_block_refer_emb is not None and not self.skip_refer_downblock_emb:
+            x = self.mid_block_refer_emb_attns.hip_forward(x, mid_block_refer_emb, geo)
+        if mid_block_additional_residual is not None:
+            x = ops.add(x, self._nchw_rows(mid_block_additional_residual))
+        self._tap("mid", x, geo)
+
+        # ---- 5. up (:1199-1245) ----
+        for i, blk in enumerate(self.up_blocks):
+            x, geo = blk.hip_forward(x, skips, ctx, geo)
+            self._tap(f"up_blocks.{i}", x, geo)
+
+        # ---- 6. post-process (:1258-1263) ----
+        x = ops.groupnorm(x, w16(self.conv_norm_out.weight), w16(self.conv_norm_out.bias), geo.n, geo.hw,
+                          eps=self.conv_norm_out.eps, silu=True, groups=self.conv_norm_out.num_groups)
+        w_out = self.packed("conv_out", lambda: ops.pack_conv_weight(self.conv_out.weight.detach()))
+        x = ops.conv3x3_cout_small(x, w_out, w16(self.conv_out.bias), geo.n, geo.h, geo.w)
+        if skip_temporal_layers is not None:
+            self.set_skip_temporal_layers(not skip_temporal_layers)
+        return x
+
+    def _tap(self, name: str, x: torch.Tensor, geo: Geo) -> None:
+        if self._collect is not None:
+            self._collect[name] = x.float().reshape(geo.n, geo.h, geo.w, -1).permute(0, 3, 1, 2).cpu()
+
+    @staticmethod
+    def _nchw_rows(r: torch.Tensor) -> torch.Tensor:
+        """ControlNet residual [(b t), c, h, w] -> channels-last fp16 rows (config 5 only; layout glue)"""
+        return r.to(torch.float16).permute(0, 2, 3, 1).reshape(-1, r.shape[1]).contiguous()

@@ -30,6 +30,24 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional live instrumentation (bench.py): HIP events around every implicit-GEMM launch ---------------------
+# The events are recorded on the stream the kernels are launched on (torch's current stream), so elapsed_time() is
+# the device-side duration of that launch.  Off by default; bench.py turns it on for its roofline pass only.
+GEMM_PROFILE: Optional[list] = None
+
+
+def _launch_gemm(d: GemmDesc, what: str) -> None:
+    lib = _lib.load()
+    if GEMM_PROFILE is None:
+        check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
+    e1.record()
+    GEMM_PROFILE.append((int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu), e0, e1))
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -109,7 +127,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     d.M, d.N, d.K = M, N, K
     d.mode, d.geglu = MV_GEMM_LINEAR, int(geglu)
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, alpha, act, cols)
-    check(_lib.load().mv_gemm_f16(C.byref(d), _stream()), "mv_gemm_f16")
+    _launch_gemm(d, "mv_gemm_f16")
     return o
 
 
@@ -147,7 +165,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2
     d.mode, d.stride, d.upsample = MV_GEMM_CONV3X3, stride, int(upsample)
     d.hin, d.win, d.hout, d.wout = h, w_, ho, wo
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, None, MV_ACT_NONE, N)
-    check(_lib.load().mv_gemm_f16(C.byref(d), _stream()), "mv_gemm_f16(conv3x3)")
+    _launch_gemm(d, "mv_gemm_f16(conv3x3)")
     return o
 
 
@@ -169,7 +187,7 @@ def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=No
     d.M, d.N, d.K = M, N, K
     d.mode, d.t, d.hw = MV_GEMM_TCONV3, t, hw
     _fill_epilogue(d, N, M, bias, None, 0, residual, alpha, MV_ACT_NONE, N)
-    check(_lib.load().mv_gemm_f16(C.byref(d), _stream()), "mv_gemm_f16(tconv3)")
+    _launch_gemm(d, "mv_gemm_f16(tconv3)")
     return o
 
 

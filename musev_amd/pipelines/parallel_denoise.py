@@ -1,0 +1,179 @@
+"""Visual-conditioned parallel denoising: the hot loop of MusevControlNetPipeline.__call__
+(reference musev/pipelines/pipeline_controlnet.py:1832-2156) on HIP kernels, optionally sharded over the GPUs of one
+node.
+
+Per denoise step the reference (:1847-2117)
+  zeroes an accumulator, loops over the windows of ``prepare_global_context`` (gather frames, duplicate for CFG,
+  prepend the vision-condition latents, UNet, drop the condition frames, scatter-add the prediction and a coverage
+  counter), divides, applies classifier-free guidance and calls ``scheduler.step``.
+Here
+  * the window input is built directly in the UNet's channels-last layout by one kernel (mv_window_gather),
+  * every (window, CFG half) pair is an independent *unit* of work: a rank owns a contiguous slice of the unit list,
+    runs the UNet on its units (both halves of a window batched when it owns both) and contributes the predictions
+    to ONE all_gather_into_tensor per step (RCCL; <= 393 KB per unit) -- there is no other collective,
+  * every rank then performs the identical, order-fixed scatter-add / average / CFG / DDIM update
+    (mv_window_scatter_add + mv_cfg_ddim_step), so the replicated latents stay bit-identical across ranks.
+Latents are kept in fp32 [C, T, HW]; the reference keeps them in the model dtype (fp16 on GPU)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+from ..schedulers.scheduling_ddim import DDIMScheduler
+from .context import prepare_global_context
+
+
+@dataclass
+class Unit:
+    window: int
+    half: int  # 0 = unconditional, 1 = text-conditioned (prompt_embeds order, text_emb_util.py:428)
+
+
+def shard_units(n_windows: int, halves: int, world: int) -> List[List[Unit]]:
+    """contiguous slices of the (window-major) unit list; sizes differ by at most one"""
+    units = [Unit(w, hf) for w in range(n_windows) for hf in range(halves)]
+    per, rem = divmod(len(units), world)
+    out, s = [], 0
+    for r in range(world):
+        n = per + (1 if r < rem else 0)
+        out.append(units[s:s + n])
+        s += n
+    return out
+
+
+def group_units(units: Sequence[Unit]) -> List[Tuple[int, List[int]]]:
+    """[(window, [halves...])]: halves of the same window are batched into one UNet call"""
+    out: List[Tuple[int, List[int]]] = []
+    for u in units:
+        if out and out[-1][0] == u.window:
+            out[-1][1].append(u.half)
+        else:
+            out.append((u.window, [u.half]))
+    return out
+
+
+class ParallelDenoiser:
+    _device_check = True  # tests of the sharding logic (gloo, CPU, fake kernels) switch this off
+
+    def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, *, context_frames: int = 12,
+                 context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
+                 context_batch_size: int = 1):
+        self.unet = unet
+        self.scheduler = scheduler or DDIMScheduler()
+        self.context_frames, self.context_overlap = context_frames, context_overlap
+        self.context_stride, self.context_schedule = context_stride, context_schedule
+        if context_batch_size != 1:
+            # with vision-condition latents the reference itself only supports one window per batch (Appendix B.7)
+            raise NotImplementedError("context_batch_size != 1")
+
+    def windows(self, time_size: int, num_inference_steps: int) -> List[List[int]]:
+        gc = prepare_global_context(self.context_schedule, num_inference_steps, time_size, self.context_frames,
+                                    self.context_stride, self.context_overlap, 1)
+        return [c[0] for c in gc]
+
+    @torch.no_grad()
+    def __call__(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, *, num_inference_steps: int = 20,
+                 guidance_scale: float = 7.5, condition_latents: Optional[torch.Tensor] = None, motion_speed: float = 8.0,
+                 unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
+                 reinsert_condition: bool = True) -> torch.Tensor:
+        """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
+        [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
+        ``group``: torch.distributed process group to shard the units over (None = this process alone).
+        Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
+        if latents.ndim != 5 or latents.shape[0] != 1:
+            raise ValueError("latents must be [1, c, T, h, w]")
+        if self._device_check and not latents.is_cuda:
+            raise RuntimeError("ParallelDenoiser runs on the GPU only")
+        dev = latents.device
+        _, c, T, h, w = latents.shape
+        hw = h * w
+        do_cfg = guidance_scale > 1.0
+        halves = 2 if do_cfg else 1
+        if prompt_embeds.shape[0] != halves:
+            raise ValueError(f"prompt_embeds batch must be {halves} for guidance_scale={guidance_scale}")
+        if condition_latents is not None and not do_cfg:
+            # the reference substitutes `latents` for the condition in this branch (:1922-1926), which only works by
+            # accident; parity is defined for the CFG path
+            raise NotImplementedError("vision-condition latents without classifier-free guidance")
+        unet_kwargs = dict(unet_kwargs or {})
+        n_cond = 0 if condition_latents is None else condition_latents.shape[2]
+        lat = latents.detach().to(torch.float32).reshape(c, T, hw).contiguous().clone()
+        cond = None if condition_latents is None else condition_latents.detach().to(torch.float32).reshape(c, n_cond, hw).contiguous()
+
+        sched = self.scheduler
+        sched.set_timesteps(num_inference_steps)
+        timesteps = [int(t) for t in sched.timesteps.tolist()]
+        wins = self.windows(T, num_inference_steps)
+        win_len = len(wins[0])
+        if any(len(wd) != win_len for wd in wins):
+            raise NotImplementedError("windows of unequal length")
+        idx_dev = [torch.tensor(wd, dtype=torch.int32, device=dev) for wd in wins]
+        counter = torch.zeros(T, dtype=torch.float32, device=dev)
+        for wd in wins:  # coverage count is the same at every step: computed once (:2078)
+            counter[torch.tensor(wd, device=dev, dtype=torch.long)] += 1.0
+        if bool((counter == 0).any()):
+            raise RuntimeError("window schedule leaves frames uncovered")
+
+        world, rank = 1, 0
+        if group is not None:
+            world = torch.distributed.get_world_size(group)
+            rank = torch.distributed.get_rank(group)
+        shards = shard_units(len(wins), halves, world)
+        my_groups = group_units(shards[rank])
+        max_units = max(len(s) for s in shards)
+        unit_elems = win_len * hw * c
+        send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float16, device=dev) if world > 1 else None
+        recv = torch.empty((world * max_units, win_len * hw, c), dtype=torch.float16, device=dev) if world > 1 else None
+
+        vis_idx = torch.arange(n_cond, dtype=torch.long, device=dev) if n_cond else None
+        sub_idx = (torch.arange(win_len, dtype=torch.long, device=dev) + n_cond) if n_cond else None
+        embeds = prompt_embeds.to(dev)
+        eps_acc = torch.empty((halves, c, T, hw), dtype=torch.float32, device=dev)
+        tw = n_cond + win_len
+
+        for step, t in enumerate(timesteps):
+            eps_acc.zero_()
+            t_dev = torch.tensor([float(t)], dtype=torch.float32, device=dev)
+            slot = 0
+            for wi, hs in my_groups:
+                x = ops.window_gather(lat, cond, idx_dev[wi], n_cond, len(hs))  # scale_model_input is the identity (DDIM)
+                ehs = embeds[hs[0]:hs[-1] + 1] if len(hs) == 2 else embeds[hs[0]:hs[0] + 1]
+                kw = {k: (self._slice_half(v, hs, halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()}
+                eps = self.unet.forward_rows(x, len(hs), tw, h, w, t_dev, ehs, sample_index=sub_idx,
+                                             vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **kw)
+                if world == 1:
+                    for k, hf in enumerate(hs):
+                        ops.window_scatter_add(eps[k * tw * hw:(k + 1) * tw * hw], idx_dev[wi], n_cond, 1, hf, eps_acc, counter, False)
+                else:
+                    for k, hf in enumerate(hs):
+                        send[slot].copy_(eps[(k * tw + n_cond) * hw:(k + 1) * tw * hw])
+                        slot += 1
+            if world > 1:
+                torch.distributed.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+                for r in range(world):  # fixed accumulation order on every rank -> bit-identical replicas
+                    for k, u in enumerate(shards[r]):
+                        ops.window_scatter_add(recv[r * max_units + k], idx_dev[u.window], 0, 1, u.half, eps_acc, counter, False)
+            a_t, a_prev = sched.alphas_for(t)
+            ops.cfg_ddim_step(lat, eps_acc, counter, float(guidance_scale), a_t, a_prev)
+            if callback is not None:
+                callback(step, t, lat)
+
+        out = lat.view(1, c, T, h, w)
+        if cond is not None and reinsert_condition:
+            out = torch.cat([cond.view(1, c, n_cond, h, w), out], dim=2)
+        return out
+
+    @staticmethod
+    def _slice_half(v, hs: List[int], halves: int):
+        """conditioning tensors batched over the CFG halves ([uncond, cond] on dim 0) are sliced to the owned halves"""
+        if v is None or halves == 1 or len(hs) == halves:
+            return v
+        if torch.is_tensor(v):
+            return v[hs[0]:hs[0] + 1]
+        return [self_v[hs[0]:hs[0] + 1] for self_v in v]
+
+
+_PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb")

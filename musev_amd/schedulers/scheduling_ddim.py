@@ -1,0 +1,90 @@
+"""DDIMScheduler with the interface the reference pipeline uses (musev/schedulers/scheduling_ddim.py:136-302 on top of
+diffusers' DDIMScheduler): ``set_timesteps``, ``timesteps``, ``scale_model_input`` (identity), ``init_noise_sigma``,
+``step(...).prev_sample``.  Constants (betas, alphas_cumprod, timestep table) are host-side; the elementwise update
+itself runs in the fused HIP kernel ``mv_cfg_ddim_step`` (no torch elementwise fallback).
+
+Scope: epsilon prediction, eta = 0, no clipping/thresholding -- the SD-1.5 configuration BASELINE.json's metric is
+quoted on.  Other prediction types / eta > 0 / video-fusion noise raise NotImplementedError ("next" row)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+@dataclass
+class DDIMSchedulerOutput:
+    prev_sample: torch.Tensor
+    pred_original_sample: Optional[torch.Tensor] = None
+
+
+class DDIMScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 beta_schedule: str = "scaled_linear", clip_sample: bool = False, set_alpha_to_one: bool = False,
+                 steps_offset: int = 1, prediction_type: str = "epsilon", timestep_spacing: str = "leading"):
+        # constants are built with torch on the host exactly like diffusers does (fp32 linspace / cumprod), so that
+        # alpha_bar_t matches the reference bit for bit
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"{beta_schedule} is not implemented for {self.__class__}")
+        if prediction_type != "epsilon" or clip_sample:
+            raise NotImplementedError("only epsilon prediction without clipping (SD-1.5 config)")
+        if timestep_spacing != "leading":
+            raise NotImplementedError("only 'leading' timestep spacing (SD-1.5 config)")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+                                      steps_offset=steps_offset, prediction_type=prediction_type,
+                                      timestep_spacing=timestep_spacing)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None) -> None:
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError("`num_inference_steps` cannot be larger than `num_train_timesteps`")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
+
+    def alphas_for(self, timestep: int) -> Tuple[float, float]:
+        """(alpha_prod_t, alpha_prod_t_prev) of reference :198-208"""
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        prev = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[timestep])
+        a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
+        return a_t, a_prev
+
+    def step(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0,
+             use_clipped_model_output: bool = False, generator=None, variance_noise=None, return_dict: bool = True,
+             w_ind_noise: float = 0.5, noise_type: str = "random") -> Union[DDIMSchedulerOutput, Tuple]:
+        if eta != 0.0 or use_clipped_model_output or variance_noise is not None:
+            raise NotImplementedError("eta > 0 / clipped model output are outside the DDIM scope of this build")
+        if not sample.is_cuda:
+            raise RuntimeError("DDIMScheduler.step runs on the GPU only")
+        a_t, a_prev = self.alphas_for(int(timestep))
+        shape = sample.shape
+        x = sample.detach().to(torch.float32).reshape(1, -1, 1, 1).clone().view(-1, 1, 1)   # [C=n, T=1, HW=1] view of all elements
+        eps = model_output.detach().to(torch.float32).reshape(1, -1, 1, 1).contiguous()
+        ones = torch.ones(1, dtype=torch.float32, device=sample.device)
+        ops.cfg_ddim_step(x, eps, ones, 0.0, a_t, a_prev)
+        prev = x.view(shape).to(sample.dtype)
+        if not return_dict:
+            return (prev,)
+        return DDIMSchedulerOutput(prev_sample=prev)

@@ -1,0 +1,175 @@
+"""ORACLE -- test infrastructure only (see oracle/unet3d.py for the rules).
+
+Plain-PyTorch/numpy CPU restatement of the sliding-window "visual conditioned parallel denoise" loop:
+  * window schedulers      musev/pipelines/context.py:12-149
+  * DDIM scheduler         musev/schedulers/scheduling_ddim.py:136-302 (+ diffusers DDIMScheduler base: betas,
+                           alphas_cumprod, set_timesteps("leading"), SURVEY.md 8c -- un-vendored, UNPINNED)
+  * denoise loop           musev/pipelines/pipeline_controlnet.py:1832-2147 (the parts in scope: window gather, CFG
+                           duplication, vision-condition prepend, UNet call, scatter-add / counter average, CFG
+                           combine, scheduler step, final cond re-insert :2149-2156)
+Pinned: `uniform` / `drop_last_repeat_context` / `prepare_global_context` against the reference's own context.py
+executed with the mmcm import stubbed, and DDIMScheduler.step against the reference's scheduling_ddim.py executed
+with a stand-in diffusers base (tests/golden/make_reference_goldens.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+
+
+# ---- context.py ------------------------------------------------------------------------------------------
+def ordered_halving(val: int) -> float:
+    """context.py:12-17: bit-reversed fraction of a 64-bit integer."""
+    return int(f"{val:064b}"[::-1], 2) / (1 << 64)
+
+
+def uniform(step: int, num_steps: Optional[int], num_frames: int, context_size: int, context_stride: int = 3,
+            context_overlap: int = 4, closed_loop: bool = True):
+    """context.py:21-48."""
+    if num_frames <= context_size:
+        yield list(range(num_frames))
+        return
+    context_stride = min(context_stride, int(np.ceil(np.log2(num_frames / context_size))) + 1)
+    for context_step in 1 << np.arange(context_stride):
+        pad = int(round(num_frames * ordered_halving(step)))
+        for j in range(int(ordered_halving(step) * context_step) + pad,
+                       num_frames + pad + (0 if closed_loop else -context_overlap),
+                       (context_size * context_step - context_overlap)):
+            yield [e % num_frames for e in range(j, j + context_size * context_step, context_step)]
+
+
+def generate_sample_idxs(total: int, window_size: int, step: int, sample_rate: int = 1, drop_last: bool = False):
+    """mmcm.utils.itertools_util.generate_sample_idxs (un-vendored; semantics inferred from the call site
+    context.py:60-66 and drop_last_repeat_context :105-117 -- UNPINNED)."""
+    out = []
+    s = 0
+    while s < total:
+        e = min(s + window_size * sample_rate, total)
+        idx = list(range(s, e, sample_rate))
+        if len(idx) < window_size and drop_last:
+            break
+        out.append(idx)
+        s += step
+    return out
+
+
+def uniform_v2(step, num_steps, num_frames, context_size, context_stride=3, context_overlap=4, closed_loop=True):
+    return generate_sample_idxs(num_frames, context_size, context_size - context_overlap, 1, False)
+
+
+def drop_last_repeat_context(contexts: List[List[int]]) -> List[List[int]]:
+    """context.py:105-117."""
+    if len(contexts) >= 2 and contexts[-1][-1] == contexts[-2][-1]:
+        return contexts[:-1]
+    return contexts
+
+
+def prepare_global_context(context_schedule: str, num_inference_steps: int, time_size: int, context_frames: int,
+                           context_stride: int, context_overlap: int, context_batch_size: int) -> List[List[List[int]]]:
+    """context.py:120-149 (always called with step = 0, pipeline_controlnet.py:1832-1840)."""
+    sched: Callable = {"uniform": uniform, "uniform_v2": uniform_v2}[context_schedule]
+    queue = list(sched(0, num_inference_steps, time_size, context_frames, context_stride, context_overlap))
+    queue = drop_last_repeat_context(queue)
+    n = math.ceil(len(queue) / context_batch_size)
+    return [queue[i * context_batch_size:(i + 1) * context_batch_size] for i in range(n)]
+
+
+# ---- DDIM ------------------------------------------------------------------------------------------------
+class DDIMOracle:
+    """SD-1.5 scheduler config (scaled_linear 0.00085 -> 0.012, 1000 steps, steps_offset 1, clip_sample False,
+    set_alpha_to_one False, epsilon prediction, "leading" spacing), eta = 0."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 set_alpha_to_one=False):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_train_timesteps = num_train_timesteps
+        self.steps_offset = steps_offset
+        self.num_inference_steps = None
+        self.timesteps = None
+
+    def set_timesteps(self, n: int):
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+
+    def alphas(self, t: int):
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps  # scheduling_ddim.py:198-200
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod  # :203-208
+        return float(a_t), float(a_prev)
+
+    def step(self, model_output: Tensor, t: int, sample: Tensor) -> Tensor:
+        """scheduling_ddim.py:198-264 with eta = 0, epsilon prediction, no clipping."""
+        a_t, a_prev = self.alphas(int(t))
+        beta_t = 1 - a_t
+        x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5  # :214-218
+        direction = (1 - a_prev) ** 0.5 * model_output              # :257-259 (std_dev_t = 0)
+        return a_prev ** 0.5 * x0 + direction                       # :262-264
+
+
+# ---- the loop --------------------------------------------------------------------------------------------
+def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds: Tensor, *, num_inference_steps: int,
+                 guidance_scale: float, condition_latents: Optional[Tensor] = None, context_frames: int = 12,
+                 context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
+                 context_batch_size: int = 1, motion_speed: float = 8.0, unet_kwargs: Optional[dict] = None,
+                 record: Optional[list] = None) -> Tensor:
+    """pipeline_controlnet.py:1832-2156.  latents [1, c, T, h, w] (generated frames only); condition_latents
+    [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
+    vision_conditon_frames_sample_index=, sample_frame_rate=, **unet_kwargs) -> eps [2, c, n_cond + win, h, w].
+    Returns the final latents with the condition frames re-inserted in front (:2149-2156)."""
+    do_cfg = guidance_scale > 1.0
+    unet_kwargs = unet_kwargs or {}
+    sched = DDIMOracle()
+    sched.set_timesteps(num_inference_steps)
+    n_cond = 0 if condition_latents is None else condition_latents.shape[2]
+    vis_idx = torch.arange(n_cond, dtype=torch.long) if n_cond else None      # vision_condition_latent_index
+    T = latents.shape[2]
+    latent_index = torch.arange(n_cond, n_cond + T, dtype=torch.long) if n_cond else None
+    gscales = [guidance_scale] * num_inference_steps                            # timesteps_util.py:12-13
+    global_context = prepare_global_context(context_schedule, num_inference_steps, T, context_frames, context_stride,
+                                            context_overlap, context_batch_size)
+    for i, t in enumerate(sched.timesteps):
+        noise_pred = torch.zeros((latents.shape[0] * (2 if do_cfg else 1), *latents.shape[1:]), dtype=latents.dtype)
+        counter = torch.zeros((1, 1, T, 1, 1), dtype=latents.dtype)
+        for context in global_context:
+            latents_c = torch.cat([latents[:, :, c] for c in context])                       # :1902
+            x = latents_c.repeat(2 if do_cfg else 1, 1, 1, 1, 1)                              # :1908-1910
+            # scale_model_input is the identity for DDIM (:1911)
+            sub_idx = None
+            if latent_index is not None:
+                win = len(context[0])
+                sub_idx = torch.arange(win, dtype=torch.long) + n_cond                       # :1914-1920
+            if condition_latents is not None:
+                cond = torch.cat([condition_latents] * 2) if do_cfg else latents             # :1922-1926
+                full = torch.zeros((x.shape[0], x.shape[1], n_cond + x.shape[2], *x.shape[3:]), dtype=x.dtype)
+                full.index_copy_(2, vis_idx, cond)                                            # data_util.py:242-268
+                full.index_copy_(2, sub_idx, x)
+                x = full
+            eps = unet_fn(x, t, prompt_embeds, sample_index=sub_idx, vision_conditon_frames_sample_index=vis_idx,
+                          sample_frame_rate=motion_speed, **unet_kwargs)                      # :2045-2067
+            if condition_latents is not None:
+                eps = eps.index_select(2, sub_idx)                                            # :2068-2071
+            for j, c in enumerate(context):
+                noise_pred[:, :, c] = noise_pred[:, :, c] + eps                              # :2076-2078
+                counter[:, :, c] = counter[:, :, c] + 1
+        noise_pred = noise_pred / counter                                                     # :2079
+        if do_cfg:
+            u, tx = noise_pred.chunk(2)
+            noise_pred = u + gscales[i] * (tx - u)                                            # :2101-2105
+        if record is not None:
+            record.append(noise_pred.clone())
+        latents = sched.step(noise_pred, int(t), latents)                                     # :2112-2117
+    if condition_latents is not None:
+        out = torch.zeros((latents.shape[0], latents.shape[1], n_cond + T, *latents.shape[3:]), dtype=latents.dtype)
+        out.index_copy_(2, vis_idx, condition_latents)
+        out.index_copy_(2, latent_index, latents)
+        latents = out
+    return latents
