@@ -1,0 +1,52 @@
+"""Test doubles for the loop-glue kernels (torch on CPU) and a closed-form fake UNet, so that the ORCHESTRATION of
+musev_amd.pipelines.parallel_denoise (unit sharding, all-gather layout, fixed-order accumulation, DDIM bookkeeping) can
+be exercised under gloo without a GPU.  Test infrastructure only: the product path never imports this module."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def window_gather(latents, cond, idx, n_cond, copies):
+    frames = latents[:, idx.long()]
+    if n_cond:
+        frames = torch.cat([cond, frames], dim=1)
+    rows = frames.permute(1, 2, 0).reshape(-1, latents.shape[0])
+    return torch.cat([rows] * copies, dim=0).to(torch.float16)
+
+
+def window_scatter_add(eps_win, idx, n_cond, halves, half_offset, eps_acc, counter, add_counter):
+    _, c, t_total, hw = eps_acc.shape
+    win = idx.numel()
+    e = eps_win.float().reshape(halves, n_cond + win, hw, c)[:, n_cond:].permute(0, 3, 1, 2)
+    eps_acc[half_offset:half_offset + halves, :, idx.long()] += e
+    if add_counter:
+        counter[idx.long()] += 1
+
+
+def cfg_ddim_step(latents, eps_acc, counter, guidance, a_t, a_prev):
+    eps = eps_acc / counter[None, None, :, None]
+    e = eps[0] + guidance * (eps[1] - eps[0]) if eps.shape[0] == 2 else eps[0]
+    x0 = (latents - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    latents.copy_(math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * e)
+
+
+class FakeUNet:
+    """eps = tanh(0.5 x) * (1 + 0.1 * mean(text)) + 0.01 * (timestep / 1000) + 0.05 * frame_position -- depends on the
+    input frames, the CFG half's prompt, the timestep and the window-local frame position, like the real network."""
+
+    def forward_rows(self, x, b, t, h, w, timestep, ehs, **kw):
+        c = x.shape[1]
+        v = x.float().reshape(b, t, h * w, c)
+        s = 1.0 + 0.1 * ehs.float().mean(dim=(1, 2)).reshape(b, 1, 1, 1)
+        pos = torch.arange(t, dtype=torch.float32).reshape(1, t, 1, 1)
+        out = torch.tanh(0.5 * v) * s + 0.01 * float(timestep.reshape(-1)[0]) / 1000.0 + 0.05 * pos
+        return out.reshape(b * t * h * w, c).to(torch.float16)
+
+    def nchw(self, x, t, ehs, **kw):
+        """the same function on the reference layout [b, c, t, h, w] (for the oracle loop)"""
+        b, c, tt, h, w = x.shape
+        rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).to(torch.float16)
+        y = self.forward_rows(rows, b, tt, h, w, torch.as_tensor(float(t)), ehs)
+        return y.float().reshape(b, tt, h, w, c).permute(0, 4, 1, 2, 3)

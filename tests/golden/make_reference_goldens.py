@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz / *.json by EXECUTING THE REFERENCE'S OWN SOURCE (/root/reference/musev) in this
+container, with the un-vendored third-party packages replaced by tests/golden/refshim.py.
+
+Run:  python tests/golden/make_reference_goldens.py          (needs /root/reference; not available on the GPU box)
+
+What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and tests/test_model_gpu.py):
+  * reference_context.json      musev/pipelines/context.py  prepare_global_context / uniform / ordered_halving
+  * reference_unet_<case>.npz   musev/models/unet_3d_condition.py UNet3DConditionModel.forward (+ unet_3d_blocks,
+                                resnet.TemporalConvLayer, temporal_transformer, transformer_2d, attention,
+                                attention_processor: reference-only self-attn, IP-Adapter cross-attn,
+                                ReferEmbFuseAttention, data_util helpers) on seeded weights/inputs.  The weights are
+                                the oracle's seeded state dict, loaded with strict=True -> the key/shape inventory of
+                                oracle.unet3d.param_shapes is checked against the reference constructor as well.
+  * reference_ddim.npz          musev/schedulers/scheduling_ddim.py DDIMScheduler.step (eta = 0, epsilon)
+  * reference_datautil.npz      musev/data/data_util.py index helpers used by the loop
+Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import refshim  # noqa: E402
+
+refshim.install("/root/reference")
+logging.disable(logging.CRITICAL)
+
+from oracle import unet3d  # noqa: E402
+
+# ---- the golden UNet cases (shared with the tests through golden_cases.py) ----
+from golden_cases import UNET_CASES, case_config, case_inputs, FLAVOUR_CTOR_KWARGS  # noqa: E402
+
+
+def gen_context():
+    from musev.pipelines import context as rc
+    table = []
+    for sched in ("uniform", "uniform_v2"):
+        for (T, size, ov, stride, bs) in [(96, 12, 4, 1, 1), (48, 12, 4, 1, 1), (24, 12, 4, 1, 1), (12, 12, 4, 1, 1), (7, 12, 4, 1, 1),
+                                          (13, 12, 4, 1, 1), (64, 12, 4, 1, 1), (100, 16, 4, 3, 2), (37, 8, 2, 2, 1), (20, 12, 4, 1, 3)]:
+            gc = rc.prepare_global_context(sched, 20, T, size, stride, ov, bs)
+            table.append(dict(schedule=sched, time_size=T, context_frames=size, context_overlap=ov, context_stride=stride,
+                              context_batch_size=bs, global_context=gc))
+    halving = {str(v): rc.ordered_halving(v) for v in (0, 1, 2, 3, 5, 8, 13, 19, 1000)}
+    stepped = {str(s): [list(map(int, wdw)) for wdw in rc.uniform(s, 20, 48, 12, 3, 4)] for s in (0, 1, 2, 7)}
+    with open(os.path.join(HERE, "reference_context.json"), "w") as f:
+        json.dump(dict(table=table, ordered_halving=halving, uniform_steps=stepped), f)
+    print("context:", len(table), "entries")
+
+
+def gen_unet():
+    from musev.models.unet_3d_condition import UNet3DConditionModel
+    for name, case in UNET_CASES.items():
+        cfg = case_config(case)
+        sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+        ctor = dict(FLAVOUR_CTOR_KWARGS[case["flavour"]])
+        ctor.update(block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg["layers_per_block"],
+                    down_block_types=tuple(cfg["down_block_types"]), up_block_types=tuple(cfg["up_block_types"]),
+                    cross_attention_dim=cfg["cross_attention_dim"], attention_head_dim=cfg["attention_head_dim"])
+        model = UNet3DConditionModel(**ctor).eval()
+        missing, unexpected = model.load_state_dict(sd, strict=True)
+        x, t, ehs, kw = case_inputs(case, cfg)
+        with torch.no_grad():
+            out = model(x, t, encoder_hidden_states=ehs, return_dict=False, **kw)[0]
+            extra = {}
+            if case.get("check_cfg_flag"):
+                out_cfg = model(x, t, encoder_hidden_states=ehs, return_dict=False, do_classifier_free_guidance=True, **kw)[0]
+                extra["cfg_flag_max_abs_diff"] = np.float32((out - out_cfg).abs().max().item())
+        np.savez_compressed(os.path.join(HERE, f"reference_unet_{name}.npz"), out=out.numpy().astype(np.float32), **extra)
+        print("unet", name, tuple(out.shape), "absmax", out.abs().max().item(), {k: float(v) for k, v in extra.items()})
+
+
+def gen_ddim():
+    # musev/schedulers/__init__.py imports every sampler (DPM-Solver, Euler, LCM ...: out of scope); load the DDIM module
+    # file alone by registering a bare package object for musev.schedulers first
+    import types
+    import musev
+    pkg = types.ModuleType("musev.schedulers")
+    pkg.__path__ = [os.path.join(os.path.dirname(musev.__file__), "schedulers")]
+    sys.modules["musev.schedulers"] = pkg
+    from musev.schedulers.scheduling_ddim import DDIMScheduler
+    s = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                      clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    s.set_timesteps(20)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 4, 6, 8, 8, generator=g)
+    eps = torch.randn(1, 4, 6, 8, 8, generator=g)
+    outs = {}
+    for t in (951, 501, 51, 1):
+        outs[f"t{t}"] = s.step(eps, t, x).prev_sample.numpy()
+    np.savez_compressed(os.path.join(HERE, "reference_ddim.npz"), timesteps=s.timesteps.numpy(),
+                        alphas_cumprod=s.alphas_cumprod.numpy(), **outs)
+    print("ddim:", s.timesteps.tolist()[:3], "...")
+
+
+def gen_datautil():
+    from musev.data import data_util as du
+    g = torch.Generator().manual_seed(88)
+    d1 = torch.randn(2, 4, 1, 3, 3, generator=g)
+    d2 = torch.randn(2, 4, 5, 3, 3, generator=g)
+    cat = du.batch_concat_two_tensor_with_index(d1, torch.tensor([0]), d2, torch.arange(1, 6), dim=2)
+    sel = du.batch_index_select(cat, dim=2, index=torch.arange(1, 6))
+    rep = du.align_repeat_tensor_single_dim(torch.arange(6.0).reshape(2, 3), 8, dim=0)
+    adain_in = torch.randn(10, 4, 3, 3, generator=g)
+    adain_out = du.batch_adain_conditioned_tensor(adain_in, num_frames=5, need_style_fidelity=False,
+                                                  src_index=torch.arange(1, 5), dst_index=torch.tensor([0]))
+    np.savez_compressed(os.path.join(HERE, "reference_datautil.npz"), cat=cat.numpy(), sel=sel.numpy(), rep=rep.numpy(),
+                        adain_is_identity=np.array(bool(torch.equal(adain_in, adain_out))))
+    print("datautil: adain identity =", bool(torch.equal(adain_in, adain_out)))
+
+
+if __name__ == "__main__":
+    gen_context()
+    gen_ddim()
+    gen_datautil()
+    gen_unet()

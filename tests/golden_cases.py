@@ -1,0 +1,79 @@
+"""Definitions of the reference-generated golden UNet cases, shared by tests/golden/make_reference_goldens.py (which
+runs the reference's own source) and the tests that replay them (oracle on CPU, HIP model on GPU).  Only seeds and
+shapes live here; weights and inputs are regenerated from the seeds."""
+from __future__ import annotations
+
+import torch
+
+# constructor keywords of the shipped flavours (musev/models/unet_loader.py:232-268)
+FLAVOUR_CTOR_KWARGS = {
+    "musev": dict(need_spatial_position_emb=False, need_t2i_ip_adapter=True, need_adain_temporal_cond=True,
+                  t2i_ip_adapter_attn_processor="NonParamReferenceIPXFormersAttnProcessor"),
+    "musev_referencenet": dict(temporal_conv_block="TemporalConvLayer", need_transformer_in=False,
+                               temporal_transformer="TransformerTemporalModel", use_anivv1_cfg=True,
+                               resnet_2d_skip_time_act=True, need_t2i_ip_adapter=True, need_adain_temporal_cond=True,
+                               keep_vision_condtion=True, t2i_ip_adapter_attn_processor="NonParamReferenceIPXFormersAttnProcessor",
+                               need_refer_emb=True, need_zero_vis_cond_temb=True, ip_adapter_cross_attn=True,
+                               t2i_crossattn_ip_adapter_attn_processor="T2IReferencenetIPAdapterXFormersAttnProcessor"),
+}
+
+_NARROW = dict(block_out_channels=(64, 128, 256, 256))  # SD-1.5 topology at 1/5 width (head dims 8/16/32: oracle only)
+_HIPW = dict(block_out_channels=(320, 640), layers_per_block=1,  # widths the HIP attention kernels support (d = 40 / 80)
+             down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"), up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
+_HIPW3 = dict(block_out_channels=(320, 640, 640), layers_per_block=1,
+              down_block_types=("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
+              up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"))
+
+UNET_CASES = {
+    # name: flavour, architecture overrides, input geometry, seeds
+    "musev_narrow": dict(flavour="musev", arch=_NARROW, b=2, t=5, h=16, w=16, n_cond=1, weight_seed=3, input_seed=11, timestep=601,
+                         check_cfg_flag=True),
+    "musev_narrow_nocond": dict(flavour="musev", arch=_NARROW, b=2, t=4, h=16, w=16, n_cond=0, weight_seed=3, input_seed=12, timestep=951),
+    "musev_narrow_2d": dict(flavour="musev", arch=_NARROW, b=2, t=1, h=16, w=16, n_cond=0, weight_seed=3, input_seed=13, timestep=1,
+                            skip_temporal_layers=True),
+    "refnet_narrow": dict(flavour="musev_referencenet", arch=_NARROW, b=2, t=5, h=16, w=16, n_cond=1, weight_seed=4, input_seed=14,
+                          timestep=301, check_cfg_flag=True),
+    "refnet_narrow_2cond": dict(flavour="musev_referencenet", arch=_NARROW, b=2, t=6, h=16, w=16, n_cond=2, weight_seed=4,
+                                input_seed=15, timestep=51),
+    "musev_hipw": dict(flavour="musev", arch=_HIPW, b=2, t=5, h=16, w=16, n_cond=1, weight_seed=5, input_seed=16, timestep=601),
+    "refnet_hipw": dict(flavour="musev_referencenet", arch=_HIPW3, b=2, t=5, h=16, w=16, n_cond=1, weight_seed=6, input_seed=17,
+                        timestep=401),
+}
+
+
+def case_config(case: dict) -> dict:
+    from oracle import unet3d
+    return unet3d.flavour_config(case["flavour"], **case["arch"])
+
+
+def refer_shapes(cfg, h, w):
+    ch, L = cfg["block_out_channels"], cfg["layers_per_block"]
+    out = [(ch[0], h, w)]
+    hh, ww = h, w
+    for i, c in enumerate(ch):
+        out += [(c, hh, ww)] * L
+        if i != len(ch) - 1:
+            hh, ww = hh // 2, ww // 2
+            out.append((c, hh, ww))
+    return out, (ch[-1], hh, ww)
+
+
+def case_inputs(case: dict, cfg: dict):
+    g = torch.Generator().manual_seed(case["input_seed"])
+    b, t, h, w, n_cond = case["b"], case["t"], case["h"], case["w"], case["n_cond"]
+    x = torch.randn(b, cfg["in_channels"], t, h, w, generator=g)
+    ehs = torch.randn(b, 77, cfg["cross_attention_dim"], generator=g)
+    kw = dict(sample_frame_rate=8)
+    if n_cond:
+        kw["vision_conditon_frames_sample_index"] = torch.arange(n_cond)
+        kw["sample_index"] = torch.arange(n_cond, t)
+    if cfg["need_refer_emb"]:
+        shapes, mid = refer_shapes(cfg, h, w)
+        kw["down_block_refer_embs"] = [torch.randn(1, c, 1, a, b_, generator=g).repeat(b, 1, 1, 1, 1) for c, a, b_ in shapes]
+        kw["mid_block_refer_emb"] = torch.randn(1, mid[0], 1, mid[1], mid[2], generator=g).repeat(b, 1, 1, 1, 1)
+    if cfg["ip_adapter_cross_attn"]:
+        kw["vision_clip_emb"] = torch.randn(b, 4, cfg["cross_attention_dim"], generator=g)
+        kw["ip_adapter_scale"] = 0.8
+    if case.get("skip_temporal_layers") is not None:
+        kw["skip_temporal_layers"] = case["skip_temporal_layers"]
+    return x, torch.tensor(case["timestep"]), ehs, kw

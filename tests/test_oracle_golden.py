@@ -1,0 +1,105 @@
+"""CPU (-m "not gpu"): the oracle against golden vectors produced by EXECUTING THE REFERENCE'S OWN SOURCE
+(tests/golden/make_reference_goldens.py, third-party deps replaced by tests/golden/refshim.py).  fp32 vs fp32 on the
+same host: tolerance 2e-4 absolute on O(1) outputs (different but equivalent op orders / SDPA kernels)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import UNET_CASES, case_config, case_inputs
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_oracle_unet_matches_reference(name):
+    from oracle import unet3d
+    case = UNET_CASES[name]
+    cfg = case_config(case)
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs, kw = case_inputs(case, cfg)
+    with torch.no_grad():
+        got = unet3d.unet3d_forward(sd, cfg, x, t, ehs, **kw)
+    g = np.load(os.path.join(GOLD, f"reference_unet_{name}.npz"))
+    want = torch.from_numpy(g["out"])
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err < 2e-4, f"{name}: oracle deviates from the reference by {err}"
+    if "cfg_flag_max_abs_diff" in g:
+        # the reference's do_classifier_free_guidance recompute (attention.py:319-334) must be dead code
+        assert float(g["cfg_flag_max_abs_diff"]) == 0.0
+
+
+def test_context_matches_reference():
+    from oracle import pipeline as opipe
+    from musev_amd.pipelines import context as pctx
+    with open(os.path.join(GOLD, "reference_context.json")) as f:
+        ref = json.load(f)
+    for e in ref["table"]:
+        args = (e["schedule"], 20, e["time_size"], e["context_frames"], e["context_stride"], e["context_overlap"], e["context_batch_size"])
+        assert opipe.prepare_global_context(*args) == e["global_context"], e
+        assert pctx.prepare_global_context(*args) == e["global_context"], e
+    for k, v in ref["ordered_halving"].items():
+        assert opipe.ordered_halving(int(k)) == v
+        assert pctx.ordered_halving(int(k)) == v
+    for s, wins in ref["uniform_steps"].items():
+        assert [list(w) for w in opipe.uniform(int(s), 20, 48, 12, 3, 4)] == wins
+        assert [list(w) for w in pctx.uniform(int(s), 20, 48, 12, 3, 4)] == wins
+
+
+def test_context_known_answers():
+    """T=96, window 12, overlap 4 -> 12 windows, the last wraps to frame 0; coverage 2,2,2,2,1,1,1,1"""
+    from musev_amd.pipelines.context import prepare_global_context
+    gc = prepare_global_context("uniform", 20, 96, 12, 1, 4, 1)
+    wins = [c[0] for c in gc]
+    assert len(wins) == 12
+    assert wins[0] == list(range(12)) and wins[1] == list(range(8, 20))
+    assert wins[-1] == [88, 89, 90, 91, 92, 93, 94, 95, 0, 1, 2, 3]
+    cov = [0] * 96
+    for wd in wins:
+        for i in wd:
+            cov[i] += 1
+    assert cov == [2, 2, 2, 2, 1, 1, 1, 1] * 12
+    assert len(prepare_global_context("uniform", 20, 48, 12, 1, 4, 1)) == 6
+    assert len(prepare_global_context("uniform", 20, 24, 12, 1, 4, 1)) == 3
+    assert prepare_global_context("uniform", 20, 12, 12, 1, 4, 1) == [[list(range(12))]]
+    assert prepare_global_context("uniform", 20, 5, 12, 1, 4, 1) == [[list(range(5))]]   # ragged: shorter than one window
+
+
+def test_ddim_matches_reference():
+    from oracle import pipeline as opipe
+    from musev_amd.schedulers import DDIMScheduler
+    g = np.load(os.path.join(GOLD, "reference_ddim.npz"))
+    o = opipe.DDIMOracle()
+    o.set_timesteps(20)
+    p = DDIMScheduler()
+    p.set_timesteps(20)
+    assert o.timesteps.tolist() == g["timesteps"].tolist() == p.timesteps.tolist()
+    assert np.array_equal(o.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    assert np.array_equal(p.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 4, 6, 8, 8, generator=gen)
+    eps = torch.randn(1, 4, 6, 8, 8, generator=gen)
+    for t in (951, 501, 51, 1):
+        want = torch.from_numpy(g[f"t{t}"])
+        got = o.step(eps, t, x)
+        assert (got - want).abs().max().item() < 1e-5, t
+        assert p.alphas_for(t) == o.alphas(t)
+
+
+def test_datautil_semantics():
+    """the index helpers the loop relies on (data_util.py:242-292,413-437,605-652) and the AdaIN no-op (:550-602)"""
+    from oracle import unet3d
+    g = np.load(os.path.join(GOLD, "reference_datautil.npz"))
+    assert bool(g["adain_is_identity"])
+    gen = torch.Generator().manual_seed(88)
+    d1 = torch.randn(2, 4, 1, 3, 3, generator=gen)
+    d2 = torch.randn(2, 4, 5, 3, 3, generator=gen)
+    cat = torch.zeros(2, 4, 6, 3, 3)
+    cat.index_copy_(2, torch.tensor([0]), d1)
+    cat.index_copy_(2, torch.arange(1, 6), d2)
+    assert np.array_equal(cat.numpy(), g["cat"])
+    assert np.array_equal(cat.index_select(2, torch.arange(1, 6)).numpy(), g["sel"])
+    assert np.array_equal(unet3d.align_repeat(torch.arange(6.0).reshape(2, 3), 8, dim=0).numpy(), g["rep"])
