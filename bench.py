@@ -129,29 +129,45 @@ def refer_shapes(h, w):
     return out, (1280, hh, ww)
 
 
-def cpu_baseline(flavour: str, full_flops: float, frames: int, threads: int):
+def cpu_baseline(flavour: str, full_flops: float, frames: int, threads: int, state_dict, win_frames: int = 13):
     """Oracle (kind "port": plain-torch fp32 restatement of the reference) timed on the host cores on a bounded
-    sample: one UNet forward, CFG batch 2, 1 condition + 1 generated frame at 64x64 latents (same weights shape, same
-    kernels of the reference path); extrapolated to the 13-frame forward by algorithmic FLOPs."""
+    sample of the same workload: ONE UNet3D forward of the full window (CFG batch 2, 1 condition + 12 generated
+    frames, same weights as the GPU run) at 128x128 px (16x16 latents) instead of 512x512 -- ~2 TFLOP, 10-30 s of CPU
+    work -- extrapolated to the 512x512 forward by algorithmic FLOPs and to the 20-step denoise by x20."""
     from oracle import unet3d
     torch.set_num_threads(threads)
     cfg = unet3d.flavour_config(flavour)
-    sd = unet3d.init_state_dict(cfg, 3)
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}  # same weights as the GPU run, fp32 on the host
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, 2, 64, 64, generator=g)
+    size = 128
+    x = torch.randn(2, 4, win_frames, size // 8, size // 8, generator=g)
     ehs = torch.randn(2, 77, 768, generator=g)
-    kw = dict(sample_index=torch.tensor([1]), vision_conditon_frames_sample_index=torch.tensor([0]), sample_frame_rate=8)
-    t0 = time.time()
-    with torch.no_grad():
-        unet3d.unet3d_forward(sd, cfg, x, torch.tensor(951), ehs, **kw)
-    dt = time.time() - t0
-    sample_flops = unet_flops(512, 512, 2, 2, "musev" if flavour == "musev" else "musev_referencenet")
+    kw = dict(sample_index=torch.arange(1, win_frames), vision_conditon_frames_sample_index=torch.tensor([0]), sample_frame_rate=8)
+    if flavour == "musev_referencenet":
+        shapes, mid = refer_shapes(size // 8, size // 8)
+        kw["down_block_refer_embs"] = [torch.randn(1, c, 1, a, b_, generator=g).repeat(2, 1, 1, 1, 1) for c, a, b_ in shapes]
+        kw["mid_block_refer_emb"] = torch.randn(1, mid[0], 1, mid[1], mid[2], generator=g).repeat(2, 1, 1, 1, 1)
+        kw["vision_clip_emb"] = torch.randn(2, 4, 768, generator=g)
+        kw["ip_adapter_scale"] = 1.0
+    # torch's intra-op pool scales badly past a few dozen threads on these small fp32 ops: time the sample at a few
+    # thread counts (bounded by the cores present) and report the fastest, with the thread count it used
+    dt, best = None, threads
+    for th in sorted({min(threads, 16), min(threads, 64), threads}):
+        torch.set_num_threads(th)
+        t0 = time.time()
+        with torch.no_grad():
+            unet3d.unet3d_forward(sd, cfg, x, torch.tensor(951), ehs, **kw)
+        d = time.time() - t0
+        if dt is None or d < dt:
+            dt, best = d, th
+    threads = best
+    sample_flops = unet_flops(size, size, win_frames, 2, "musev" if flavour == "musev" else "musev_referencenet")
     t_full = dt * full_flops / sample_flops
     return {
         "value": frames / (DENOISE_STEPS * t_full), "unit": "frames/s", "cores": threads, "kind": "port",
-        "sample": f"oracle UNet3D forward, CFG batch 2, 2 frames (1 cond + 1 generated) @64x64 latents: {dt:.1f} s for "
-                  f"{sample_flops / 1e12:.2f} TFLOP ({sample_flops / dt / 1e12:.3f} TFLOP/s); extrapolated by algorithmic FLOPs to the "
-                  f"{full_flops / 1e12:.1f} TFLOP per-step workload x {DENOISE_STEPS} steps",
+        "sample": f"oracle UNet3D forward, CFG batch 2, {win_frames} frames (1 cond + {win_frames - 1} generated) @{size}x{size} px "
+                  f"({size // 8}x{size // 8} latents): {dt:.1f} s for {sample_flops / 1e12:.2f} TFLOP ({sample_flops / dt / 1e12:.3f} TFLOP/s); "
+                  f"extrapolated by algorithmic FLOPs to the {full_flops / 1e12:.1f} TFLOP 512x512 forward x {DENOISE_STEPS} steps",
         "seconds_sample": dt,
     }
 
@@ -201,18 +217,27 @@ def main():
     h = w = args.size // 8
 
     # ---- model: real architecture, seeded random fp16 weights (same on every rank) ----
-    torch.manual_seed(3)
-    unet = load_unet_by_name(flavour, dtype=torch.float16)
-    g = torch.Generator().manual_seed(3)
+    # built on the meta device and materialised + randomised directly on the GPU (a CPU init of 1.42 B parameters
+    # would burn minutes of GPU-box time); the philox generator gives every rank identical weights
+    with torch.device("meta"):
+        unet = load_unet_by_name(flavour, dtype=torch.float16)
+    unet = unet.to_empty(device=dev)
+    gg = torch.Generator(device=dev).manual_seed(3)
+    res_out = ("conv2.weight", "to_out.0.weight", "ff.net.2.weight", "proj_out.weight", "conv4.3.weight")
     with torch.no_grad():
-        for name, p in unet.named_parameters():  # re-randomise the reference's zero-initialised parameters
-            if name.endswith("temporal_weight"):
-                p.copy_(0.1 + 0.9 * torch.rand(p.shape, generator=g))
+        for name, p in unet.named_parameters():
+            if name.endswith("temporal_weight"):   # the reference zero-initialises these branches: re-randomise
+                p.copy_(0.1 + 0.9 * torch.rand(p.shape, generator=gg, device=dev))
             elif p.ndim >= 2:
-                fan_in = p[0].numel()
-                gain = 0.3 if name.endswith(("conv2.weight", "to_out.0.weight", "ff.net.2.weight", "proj_out.weight", "conv4.3.weight")) else 1.0
-                p.copy_((torch.randn(p.shape, generator=g) * (gain / fan_in ** 0.5)).to(p.dtype))
-    unet = unet.to(dev)
+                gain = 0.3 if name.endswith(res_out) else 1.0
+                p.copy_(torch.randn(p.shape, generator=gg, device=dev) * (gain / p[0].numel() ** 0.5))
+            elif name.endswith(".weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=gg, device=dev))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=gg, device=dev))
+    unet.eval()
+    from musev_amd.models.layers import bump_pack_epoch
+    bump_pack_epoch()
 
     g = torch.Generator().manual_seed(0)
     latents = torch.randn(1, 4, T, h, w, generator=g).to(dev)
@@ -316,7 +341,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(flavour, unet_flops(args.size, args.size, win + n_cond, 2, flavour, n_vis=n_cond), T,
-                               threads=os.cpu_count() or 1)
+                               threads=os.cpu_count() or 1, state_dict=unet.state_dict())
         except Exception as ex:  # noqa: BLE001 -- the baseline is a report, never a reason to lose the GPU number
             cpu = {"error": repr(ex)}
 

@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 1
+#define MV_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -74,6 +74,8 @@ typedef struct mv_gemm_desc {
 } mv_gemm_desc;
 
 int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
+/* tuning knob: 0 = register-staged global->LDS copies, 1 = LDS-DMA (global_load_lds, default) */
+int mv_set_gemm_variant(int variant);
 
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
  * replaces: torch.nn.GroupNorm(32, C)(+SiLU) in ResnetBlock2D.norm1/norm2, Transformer2DModel.norm
@@ -149,8 +151,9 @@ int mv_geglu_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows,
 int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
                              const void* add /* optional [rows][cout] (pose_guider_emb) */, void* y,
                              int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
+/* y: [rows][cout] fp16, or fp32 when y_is_f32 (the UNet's noise prediction leaves the network unrounded) */
 int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
-                              void* y, int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
+                              void* y, int32_t y_is_f32, int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
 
 /* ---- elementwise helpers -------------------------------------------------------------------------------*/
 /* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift=0): out[i, :] = [cos(t_i f), sin(t_i f)]           */
@@ -165,7 +168,8 @@ int mv_zero_rows_f16(void* x, int32_t ld, const int32_t* row_idx, int32_t n_idx,
 /* layout: [B, C, T, H, W] (fp16 or fp32) -> channels-last fp16 [B, T, H, W, C] and back                    */
 /* replaces: rearrange(sample, "b c t h w -> (b t) c h w") and its inverse (unet_3d_condition.py:1008,1263) */
 int mv_bcthw_to_bthwc_f16(const void* x, int32_t x_is_f32, void* y, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);
-int mv_bthwc_to_bcthw_f16(const void* x, void* y, int32_t y_is_f32, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);
+int mv_bthwc_to_bcthw_f16(const void* x, int32_t x_is_f32, void* y, int32_t y_is_f32, int32_t b, int32_t c, int32_t t, int32_t hw,
+                          void* stream);
 
 /* ---- sliding-window denoise loop glue (K12) -----------------------------------------------------------
  * mv_window_gather: builds the UNet input of one window, channels-last fp16 [2?][n_cond + win][HW][C]:
@@ -176,10 +180,10 @@ int mv_bthwc_to_bcthw_f16(const void* x, void* y, int32_t y_is_f32, int32_t b, i
  */
 int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
                      int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, void* out, void* stream);
-/* mv_window_scatter_add: eps_acc[half][C][T_total][HW] += eps_win (channels-last fp16 [halves][n_cond+win][HW][C],
+/* mv_window_scatter_add: eps_acc[half][C][T_total][HW] += eps_win (channels-last fp16|fp32 [halves][n_cond+win][HW][C],
  *   cond frames dropped); counter[T_total] += 1.
  * replaces: pipeline_controlnet.py:2068-2078. */
-int mv_window_scatter_add(const void* eps_win, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
+int mv_window_scatter_add(const void* eps_win, int32_t eps_is_f32, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
                           int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset,
                           float* eps_acc, float* counter, int32_t add_counter, void* stream);
 /* mv_cfg_ddim_step: eps = acc / counter; eps = eps_u + g (eps_t - eps_u); DDIM (eta = 0, epsilon prediction):

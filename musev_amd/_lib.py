@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmusev_hip.so")
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 1
+MV_ABI_VERSION = 2
 
 
 class MuseVHipError(RuntimeError):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "mv_abi_version": (_i32, []),
     "mv_last_error": (C.c_char_p, []),
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
+    "mv_set_gemm_variant": (_i32, [_i32]),
     "mv_groupnorm_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
                                 _vp, _i32, _vp, _vp]),
     "mv_groupnorm_partial_floats": (_i64, [_i64, _i32, _i32]),
@@ -70,15 +71,15 @@ SIGNATURES = {
                                          _f32, _vp]),
     "mv_geglu_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "mv_conv3x3_cin_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
-    "mv_conv3x3_cout_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "mv_conv3x3_cout_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
     "mv_timestep_embedding_f16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "mv_silu_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "mv_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "mv_zero_rows_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     "mv_bcthw_to_bthwc_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "mv_bthwc_to_bcthw_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mv_bthwc_to_bcthw_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mv_window_gather": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "mv_window_scatter_add": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mv_window_scatter_add": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mv_cfg_ddim_step": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
     "mv_pack_conv_weight_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "mv_probe_tr16": (_i32, [_vp, _vp, _vp]),
@@ -103,6 +104,9 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.mv_abi_version() != MV_ABI_VERSION:
         raise MuseVHipError(f"ABI mismatch: library {lib.mv_abi_version()} vs binding {MV_ABI_VERSION}")
+    variant = os.environ.get("MUSEV_GEMM_VARIANT")  # tuning knob for A/B runs (see mv_set_gemm_variant)
+    if variant is not None:
+        lib.mv_set_gemm_variant(int(variant))
     _lib = lib
     return lib
 

@@ -85,8 +85,8 @@ __global__ void bcthw_to_bthwc_kernel(const SrcT* x, half_t* y, int b, int c, in
         y[i] = (half_t)(float)x[(((long)bi * c + ci) * t + ti) * hw + p];
     }
 }
-template <typename DstT>
-__global__ void bthwc_to_bcthw_kernel(const half_t* x, DstT* y, int b, int c, int t, int hw) {
+template <typename SrcT, typename DstT>
+__global__ void bthwc_to_bcthw_kernel(const SrcT* x, DstT* y, int b, int c, int t, int hw) {
     const long total = (long)b * t * hw * c;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         // i indexes the destination [b][c][t][hw] so that stores are coalesced
@@ -147,8 +147,9 @@ __global__ void conv3x3_cin_small_kernel(const half_t* x, int cin, const half_t*
 }
 
 // ---- conv3x3 with tiny Cout (conv_out: 320 -> 4): one wave per output pixel, lanes split the 9*Cin reduction ----
+template <typename OutT>
 __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x, int cin, const half_t* w,
-                                                                 const half_t* bias, half_t* y, int cout, long n_img,
+                                                                 const half_t* bias, OutT* y, int cout, long n_img,
                                                                  int h, int wd) {
     extern __shared__ __attribute__((aligned(16))) half_t swh[];  // [cout][9*cin]
     const int kk = 9 * cin;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x
             for (int j = 0; j < 8; ++j)
                 if (lane == j) v = acc[j];
             if (bias) v += (float)bias[lane];
-            y[pix * cout + lane] = (half_t)v;
+            y[pix * cout + lane] = (OutT)v;
         }
     }
 }
@@ -213,7 +214,8 @@ __global__ void window_gather_kernel(const float* latents, const float* cond, co
 }
 
 // eps_acc[half_offset + k][c][t_total][hw] += eps_win[k][n_cond + j][hw][c]  for window frame j -> idx[j]
-__global__ void window_scatter_add_kernel(const half_t* eps_win, const int* idx, int win, int n_cond, int c, int t_total,
+template <typename EpsT>
+__global__ void window_scatter_add_kernel(const EpsT* eps_win, const int* idx, int win, int n_cond, int c, int t_total,
                                           int hw, int halves, int half_offset, float* eps_acc, float* counter,
                                           int add_counter) {
     const long total = (long)halves * c * win * hw;
@@ -324,11 +326,16 @@ extern "C" int mv_bcthw_to_bthwc_f16(const void* x, int32_t x_is_f32, void* y, i
     return MV_OK;
 }
 
-extern "C" int mv_bthwc_to_bcthw_f16(const void* x, void* y, int32_t y_is_f32, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream) {
+extern "C" int mv_bthwc_to_bcthw_f16(const void* x, int32_t x_is_f32, void* y, int32_t y_is_f32, int32_t b, int32_t c, int32_t t,
+                                     int32_t hw, void* stream) {
     MV_REQUIRE(x && y && b > 0 && c > 0 && t > 0 && hw > 0, "mv_bthwc_to_bcthw_f16: bad args");
     const long n = (long)b * c * t * hw;
-    if (y_is_f32) hipLaunchKernelGGL(bthwc_to_bcthw_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, (float*)y, b, c, t, hw);
-    else hipLaunchKernelGGL(bthwc_to_bcthw_kernel<half_t>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, b, c, t, hw);
+    const dim3 g(grid_for(n)), blk(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_is_f32 && y_is_f32) hipLaunchKernelGGL((bthwc_to_bcthw_kernel<float, float>), g, blk, 0, s, (const float*)x, (float*)y, b, c, t, hw);
+    else if (x_is_f32) hipLaunchKernelGGL((bthwc_to_bcthw_kernel<float, half_t>), g, blk, 0, s, (const float*)x, (half_t*)y, b, c, t, hw);
+    else if (y_is_f32) hipLaunchKernelGGL((bthwc_to_bcthw_kernel<half_t, float>), g, blk, 0, s, (const half_t*)x, (float*)y, b, c, t, hw);
+    else hipLaunchKernelGGL((bthwc_to_bcthw_kernel<half_t, half_t>), g, blk, 0, s, (const half_t*)x, (half_t*)y, b, c, t, hw);
     MV_CHECK_LAUNCH("mv_bthwc_to_bcthw_f16");
     return MV_OK;
 }
@@ -344,15 +351,19 @@ extern "C" int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* 
     return MV_OK;
 }
 
-extern "C" int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w, const void* bias, void* y, int32_t cout,
-                                         int64_t n_img, int32_t h, int32_t w_, void* stream) {
+extern "C" int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w, const void* bias, void* y, int32_t y_is_f32,
+                                         int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream) {
     MV_REQUIRE(x && w && y && cin % 8 == 0 && cout > 0 && cout <= 8 && n_img > 0 && h > 0 && w_ > 0, "mv_conv3x3_cout_small_f16: bad args (cin=%d cout=%d)", cin, cout);
     const size_t smem = (size_t)9 * cin * cout * sizeof(half_t);
     MV_REQUIRE(smem <= 64 * 1024, "mv_conv3x3_cout_small_f16: weights do not fit LDS");
     long g = (n_img * h * w_ + 3) / 4;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(conv3x3_cout_small_kernel, dim3((unsigned)g), dim3(kBlock), smem, (hipStream_t)stream,
-                       (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_);
+    if (y_is_f32)
+        hipLaunchKernelGGL(conv3x3_cout_small_kernel<float>, dim3((unsigned)g), dim3(kBlock), smem, (hipStream_t)stream,
+                           (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (float*)y, cout, (long)n_img, h, w_);
+    else
+        hipLaunchKernelGGL(conv3x3_cout_small_kernel<half_t>, dim3((unsigned)g), dim3(kBlock), smem, (hipStream_t)stream,
+                           (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_);
     MV_CHECK_LAUNCH("mv_conv3x3_cout_small_f16");
     return MV_OK;
 }
@@ -367,12 +378,17 @@ extern "C" int mv_window_gather(const float* latents, const float* cond, const i
     return MV_OK;
 }
 
-extern "C" int mv_window_scatter_add(const void* eps_win, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
-                                     int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset, float* eps_acc,
+extern "C" int mv_window_scatter_add(const void* eps_win, int32_t eps_is_f32, const int32_t* idx, int32_t win, int32_t n_cond,
+                                     int32_t c, int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset, float* eps_acc,
                                      float* counter, int32_t add_counter, void* stream) {
     MV_REQUIRE(eps_win && idx && eps_acc && counter && win > 0 && win <= kBlock && halves > 0, "mv_window_scatter_add: bad args");
-    hipLaunchKernelGGL(window_scatter_add_kernel, dim3(grid_for((long)halves * c * win * hw)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (const half_t*)eps_win, idx, win, n_cond, c, t_total, hw, halves, half_offset, eps_acc, counter, add_counter);
+    const dim3 g(grid_for((long)halves * c * win * hw));
+    if (eps_is_f32)
+        hipLaunchKernelGGL(window_scatter_add_kernel<float>, g, dim3(kBlock), 0, (hipStream_t)stream, (const float*)eps_win, idx, win,
+                           n_cond, c, t_total, hw, halves, half_offset, eps_acc, counter, add_counter);
+    else
+        hipLaunchKernelGGL(window_scatter_add_kernel<half_t>, g, dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)eps_win, idx, win,
+                           n_cond, c, t_total, hw, halves, half_offset, eps_acc, counter, add_counter);
     MV_CHECK_LAUNCH("mv_window_scatter_add");
     return MV_OK;
 }

@@ -148,7 +148,76 @@ __device__ __forceinline__ void mma_tile(const half_t* cA, const half_t* cB, flo
     }
 }
 
+
+// ---- LDS-DMA staging variant -------------------------------------------------------------------------------------
+// global_load_lds_dwordx4 writes LDS at (wave-uniform base + lane*16): one wave instruction fills 8 rows x 128 B.
+// The XOR swizzle therefore moves to the SOURCE side: lane l of chunk c owns row 8c + l/8 and LDS slot l%8, and fetches
+// the logical slot (l%8) ^ (l/8) of that row -- still one full 128-byte line per 8 lanes.  Predicated-off lanes (conv
+// halo, ragged M/N/K) point at the zero page, which an LDS-DMA can express because the source address is per lane.
 template <int MODE, int TM, int TN>
+__device__ __forceinline__ void issue_tiles(const GemmArgs& p, const RowInfo<TM>& ri, half_t* dA, half_t* dB, int kt,
+                                            int& kc, int& tap, int n0, int wave, int lane, const half_t* zero) {
+    constexpr int BK = 64;
+    const int lslot = (lane & 7) ^ (lane >> 3);  // logical 16-byte slot this lane fetches
+    const bool second = (p.a2 != nullptr) && (kc >= p.c1);
+    const half_t* src = second ? p.a2 : p.a;
+    const long ld = second ? p.lda2 : p.lda;
+    const long coff = (second ? kc - p.c1 : kc) + lslot * 8;
+    const long zdelta = zero - src;
+    const bool kok = (MODE != MV_GEMM_LINEAR) || (kc + lslot * 8 < p.cin);
+    int dy = 0, dx = 0;
+    if (MODE == MV_GEMM_CONV3X3) {
+        dy = tap / 3 - 1;
+        dx = tap - (tap / 3) * 3 - 1;
+    } else if (MODE == MV_GEMM_TCONV3) {
+        dy = tap - 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        bool ok = ri.ok[i] && kok;
+        long row;
+        if (MODE == MV_GEMM_LINEAR) {
+            row = ri.base[i];
+        } else if (MODE == MV_GEMM_CONV3X3) {
+            int iy = ri.y[i] + dy, ix = ri.x[i] + dx;
+            if (p.upsample) {
+                ok = ok && iy >= 0 && iy < 2 * p.hin && ix >= 0 && ix < 2 * p.win;
+                iy >>= 1;
+                ix >>= 1;
+            } else {
+                ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
+            }
+            row = ri.base[i] + (long)(iy * p.win + ix);
+        } else {
+            int tt = ri.y[i] + dy;
+            ok = ok && tt >= 0 && tt < p.t;
+            row = ri.base[i] + (long)dy * p.hw;
+        }
+        long off = row * ld + coff;
+        off = ok ? off : zdelta;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                         (__attribute__((address_space(3))) void*)(dA + (wave * TM + i) * (8 * BK)), 16, 0, 0);
+    }
+    const int kg = kt * BK + lslot * 8;
+    const bool wk_ok = kg < p.K;
+    const long wz = zero - p.w;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + (wave * TN + j) * 8 + (lane >> 3);
+        bool ok = wk_ok && n < p.N;
+        long off = (long)n * p.K + kg;
+        off = ok ? off : wz;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + off),
+                                         (__attribute__((address_space(3))) void*)(dB + (wave * TN + j) * (8 * BK)), 16, 0, 0);
+    }
+    kc += BK;
+    if (MODE != MV_GEMM_LINEAR && kc >= p.cin) {
+        kc -= p.cin;
+        ++tap;
+    }
+}
+
+template <int MODE, int TM, int TN, int STAGE>  // STAGE 0: register staging, 1: LDS-DMA (global_load_lds)
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -176,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     RowInfo<TM> ri;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        long gm = m0 + lrow + 32 * i;
+        long gm = (STAGE == 0) ? (m0 + lrow + 32 * i) : (m0 + (wave * TM + i) * 8 + (lane >> 3));
         ri.ok[i] = gm < p.M;
         if (MODE == MV_GEMM_LINEAR) {
             ri.base[i] = gm;
@@ -206,21 +275,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tiles<MODE, TM, TN>(p, ri, ra, rb, 0, kc, tap, n0, lrow, lslot, zero);
-    store_tiles<TM, TN>(sA, sB, ra, rb, lrow, sw_off);
-    __syncthreads();
-
     // fragment read offsets (halfs): row = tile base + l15 ; slot = kk*4 + g ; swizzle with row & 7 == l15 & 7
     const int a_row0 = wm * 16 * TM + l15;
     const int b_row0 = wn * 16 * TN + l15;
     const int swz = l15 & 7;
-
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        const int cur = kt & 1;
-        load_tiles<MODE, TM, TN>(p, ri, ra, rb, kt + 1, kc, tap, n0, lrow, lslot, zero);
-        mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
-        store_tiles<TM, TN>(sA + (cur ^ 1) * (BM * BK), sB + (cur ^ 1) * (BN * BK), ra, rb, lrow, sw_off);
+    if constexpr (STAGE == 0) {
+        load_tiles<MODE, TM, TN>(p, ri, ra, rb, 0, kc, tap, n0, lrow, lslot, zero);
+        store_tiles<TM, TN>(sA, sB, ra, rb, lrow, sw_off);
         __syncthreads();
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            const int cur = kt & 1;
+            load_tiles<MODE, TM, TN>(p, ri, ra, rb, kt + 1, kc, tap, n0, lrow, lslot, zero);
+            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+            store_tiles<TM, TN>(sA + (cur ^ 1) * (BM * BK), sB + (cur ^ 1) * (BN * BK), ra, rb, lrow, sw_off);
+            __syncthreads();
+        }
+    } else {
+        issue_tiles<MODE, TM, TN>(p, ri, sA, sB, 0, kc, tap, n0, wave, lane, zero);
+        __syncthreads();  // the compiler drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            const int cur = kt & 1;
+            issue_tiles<MODE, TM, TN>(p, ri, sA + (cur ^ 1) * (BM * BK), sB + (cur ^ 1) * (BN * BK), kt + 1, kc, tap, n0,
+                                      wave, lane, zero);
+            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+            __syncthreads();
+        }
     }
     {
         const int cur = (nk - 1) & 1;
@@ -282,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <int MODE, int TM, int TN>
-int launch_cfg(const GemmArgs& a0, hipStream_t stream) {
+template <int MODE, int TM, int TN, int STAGE>
+int launch_cfg_s(const GemmArgs& a0, hipStream_t stream) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
     constexpr int smem = 2 * (BM + BN) * 64 * (int)sizeof(half_t);
     GemmArgs a = a0;
@@ -291,7 +370,7 @@ int launch_cfg(const GemmArgs& a0, hipStream_t stream) {
     a.tiles_n = (a.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, TM, TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, TM, TN, STAGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             mv_set_error("mv_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -300,9 +379,16 @@ int launch_cfg(const GemmArgs& a0, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-    hipLaunchKernelGGL((gemm_kernel<MODE, TM, TN>), grid, dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE, TM, TN, STAGE>), grid, dim3(256), smem, stream, a);
     MV_CHECK_LAUNCH("mv_gemm_f16");
     return MV_OK;
+}
+
+int g_gemm_stage = 1;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA
+
+template <int MODE, int TM, int TN>
+int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    return g_gemm_stage == 0 ? launch_cfg_s<MODE, TM, TN, 0>(a, stream) : launch_cfg_s<MODE, TM, TN, 1>(a, stream);
 }
 
 template <int MODE>
@@ -319,6 +405,11 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int mv_set_gemm_variant(int v) {
+    g_gemm_stage = v ? 1 : 0;
+    return MV_OK;
+}
 
 extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
     MV_REQUIRE(d != nullptr, "mv_gemm_f16: null descriptor");

@@ -331,7 +331,8 @@ class UNet3DConditionModel(HipModule):
                      frame_index=None, down_block_refer_embs=None, mid_block_refer_emb=None, refer_self_attn_emb=None,
                      vision_clip_emb=None, ip_adapter_scale: float = 1.0, face_emb=None, ip_adapter_face_emb=None,
                      pose_guider_emb=None) -> torch.Tensor:
-        """The network on channels-last rows: x fp16 [(b t h w), in_channels] -> fp16 [(b t h w), out_channels].
+        """The network on channels-last rows: x fp16 [(b t h w), in_channels] -> fp32 [(b t h w), out_channels] (the
+        fp32 accumulator of conv_out, unrounded: CFG and the scheduler amplify the prediction's last-bit error).
         Used directly by musev_amd.pipelines.parallel_denoise (which builds window inputs in this layout)."""
         for name, val in (("class_labels", class_labels), ("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
                           ("vision_condition_frames_sample", vision_condition_frames_sample), ("frame_index", frame_index),
@@ -437,7 +438,7 @@ class UNet3DConditionModel(HipModule):
         x = ops.groupnorm(x, w16(self.conv_norm_out.weight), w16(self.conv_norm_out.bias), geo.n, geo.hw,
                           eps=self.conv_norm_out.eps, silu=True, groups=self.conv_norm_out.num_groups)
         w_out = self.packed("conv_out", lambda: ops.pack_conv_weight(self.conv_out.weight.detach()))
-        x = ops.conv3x3_cout_small(x, w_out, w16(self.conv_out.bias), geo.n, geo.h, geo.w)
+        x = ops.conv3x3_cout_small(x, w_out, w16(self.conv_out.bias), geo.n, geo.h, geo.w, out_dtype=torch.float32)
         if skip_temporal_layers is not None:
             self.set_skip_temporal_layers(not skip_temporal_layers)
         return x

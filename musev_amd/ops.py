@@ -312,15 +312,21 @@ def conv3x3_cin_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int
     return y
 
 
-def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int) -> torch.Tensor:
+def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int,
+                       out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """conv_out (C -> 4): ``out_dtype=torch.float32`` keeps the fp32 accumulator (the noise prediction feeds CFG and
+    the scheduler, which amplify a final fp16 rounding several times)."""
     x = _mat(x, "x")
     w = _mat(w, "w")
     cin, cout = x.shape[1], w.shape[0]
     if not x.is_contiguous() or w.shape[1] != 9 * cin:
         raise ValueError("conv3x3_cout_small: bad shapes")
-    y = torch.empty((n_img * h * w_, cout), dtype=torch.float16, device=x.device)
+    if out_dtype not in (torch.float16, torch.float32):
+        raise ValueError("conv3x3_cout_small: out_dtype must be fp16 or fp32")
+    y = torch.empty((n_img * h * w_, cout), dtype=out_dtype, device=x.device)
     check(_lib.load().mv_conv3x3_cout_small_f16(x.data_ptr(), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
-                                                y.data_ptr(), cout, n_img, h, w_, _stream()), "mv_conv3x3_cout_small_f16")
+                                                y.data_ptr(), int(out_dtype == torch.float32), cout, n_img, h, w_, _stream()),
+          "mv_conv3x3_cout_small_f16")
     return y
 
 
@@ -352,13 +358,12 @@ def bcthw_to_bthwc(x: torch.Tensor) -> torch.Tensor:
 
 
 def bthwc_to_bcthw(x: torch.Tensor, b: int, t: int, h: int, w: int, dtype=torch.float16) -> torch.Tensor:
-    x = _mat(x, "x")
+    if x.dim() != 2 or not x.is_contiguous() or not x.is_cuda or x.dtype not in (torch.float16, torch.float32):
+        raise ValueError("bthwc_to_bcthw: contiguous 2-D CUDA fp16|fp32 input expected")
     c = x.shape[1]
-    if not x.is_contiguous():
-        raise ValueError("bthwc_to_bcthw: contiguous input expected")
     y = torch.empty((b, c, t, h, w), dtype=dtype, device=x.device)
-    check(_lib.load().mv_bthwc_to_bcthw_f16(x.data_ptr(), y.data_ptr(), int(dtype == torch.float32), b, c, t, h * w,
-                                            _stream()), "mv_bthwc_to_bcthw_f16")
+    check(_lib.load().mv_bthwc_to_bcthw_f16(x.data_ptr(), int(x.dtype == torch.float32), y.data_ptr(),
+                                            int(dtype == torch.float32), b, c, t, h * w, _stream()), "mv_bthwc_to_bcthw_f16")
     return y
 
 
@@ -374,10 +379,13 @@ def window_gather(latents: torch.Tensor, cond: Optional[torch.Tensor], idx: torc
 
 def window_scatter_add(eps_win: torch.Tensor, idx: torch.Tensor, n_cond: int, halves: int, half_offset: int,
                        eps_acc: torch.Tensor, counter: torch.Tensor, add_counter: bool) -> None:
-    """eps_win fp16 [halves*(n_cond+win)*HW, C]; eps_acc fp32 [H, C, T_total, HW]; counter fp32 [T_total]."""
+    """eps_win fp16|fp32 [halves*(n_cond+win)*HW, C]; eps_acc fp32 [H, C, T_total, HW]; counter fp32 [T_total]."""
     _, c, t_total, hw = eps_acc.shape
     win = idx.numel()
-    check(_lib.load().mv_window_scatter_add(eps_win.data_ptr(), idx.data_ptr(), win, n_cond, c, t_total, hw, halves,
+    if eps_win.dtype not in (torch.float16, torch.float32) or not eps_win.is_contiguous():
+        raise ValueError("window_scatter_add: contiguous fp16|fp32 predictions expected")
+    check(_lib.load().mv_window_scatter_add(eps_win.data_ptr(), int(eps_win.dtype == torch.float32), idx.data_ptr(), win,
+                                            n_cond, c, t_total, hw, halves,
                                             half_offset, eps_acc.data_ptr(), counter.data_ptr(), int(add_counter),
                                             _stream()), "mv_window_scatter_add")
 

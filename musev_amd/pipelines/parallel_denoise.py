@@ -10,7 +10,7 @@ Here
   * the window input is built directly in the UNet's channels-last layout by one kernel (mv_window_gather),
   * every (window, CFG half) pair is an independent *unit* of work: a rank owns a contiguous slice of the unit list,
     runs the UNet on its units (both halves of a window batched when it owns both) and contributes the predictions
-    to ONE all_gather_into_tensor per step (RCCL; <= 393 KB per unit) -- there is no other collective,
+    to ONE all_gather_into_tensor per step (RCCL; fp32 predictions, <= 786 KB per unit) -- there is no other collective,
   * every rank then performs the identical, order-fixed scatter-add / average / CFG / DDIM update
     (mv_window_scatter_add + mv_cfg_ddim_step), so the replicated latents stay bit-identical across ranks.
 Latents are kept in fp32 [C, T, HW]; the reference keeps them in the model dtype (fp16 on GPU)."""
@@ -125,8 +125,8 @@ class ParallelDenoiser:
         my_groups = group_units(shards[rank])
         max_units = max(len(s) for s in shards)
         unit_elems = win_len * hw * c
-        send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float16, device=dev) if world > 1 else None
-        recv = torch.empty((world * max_units, win_len * hw, c), dtype=torch.float16, device=dev) if world > 1 else None
+        send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
+        recv = torch.empty((world * max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
 
         vis_idx = torch.arange(n_cond, dtype=torch.long, device=dev) if n_cond else None
         sub_idx = (torch.arange(win_len, dtype=torch.long, device=dev) + n_cond) if n_cond else None

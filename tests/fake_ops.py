@@ -42,7 +42,7 @@ class FakeUNet:
         s = 1.0 + 0.1 * ehs.float().mean(dim=(1, 2)).reshape(b, 1, 1, 1)
         pos = torch.arange(t, dtype=torch.float32).reshape(1, t, 1, 1)
         out = torch.tanh(0.5 * v) * s + 0.01 * float(timestep.reshape(-1)[0]) / 1000.0 + 0.05 * pos
-        return out.reshape(b * t * h * w, c).to(torch.float16)
+        return out.reshape(b * t * h * w, c)  # fp32 rows, like UNet3DConditionModel.forward_rows
 
     def nchw(self, x, t, ehs, **kw):
         """the same function on the reference layout [b, c, t, h, w] (for the oracle loop)"""

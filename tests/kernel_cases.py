@@ -277,6 +277,9 @@ def case_conv_in_out():
     yl = y.permute(0, 2, 3, 1).reshape(n * h * w, 320).contiguous()
     got2 = ops.conv3x3_cout_small(yl, ops.pack_conv_weight(wo), bo, n, h, w)
     r2 = _cmp("conv_out 320->4", got2, ref2, atol=3e-3)
+    got3 = ops.conv3x3_cout_small(yl, ops.pack_conv_weight(wo), bo, n, h, w, out_dtype=torch.float32)  # unrounded accumulator
+    r3 = _cmp("conv_out 320->4 fp32 out", got3, ref2, atol=2e-4)
+    r2["ok"] = r2["ok"] and r3["ok"] and got3.dtype == torch.float32
     r1["ok"] = r1["ok"] and r2["ok"]
     r1["name"] = "conv_in/conv_out"
     r1["max_abs_err"] = max(r1["max_abs_err"], r2["max_abs_err"])
@@ -302,6 +305,9 @@ def case_layout_and_misc():
     r = _cmp("bcthw_to_bthwc", y, ref, atol=1e-3)
     back = ops.bthwc_to_bcthw(y, 2, 5, 6, 7, dtype=torch.float32)
     r2 = _cmp("bthwc_to_bcthw", back, x.half().float(), atol=1e-6)
+    back32 = ops.bthwc_to_bcthw(ref.contiguous(), 2, 5, 6, 7, dtype=torch.float32)  # fp32 rows -> fp32 b c t h w: exact
+    r2b = _cmp("bthwc_to_bcthw fp32 src", back32, x, atol=0.0)
+    r2["ok"] = r2["ok"] and r2b["ok"]
     a = _rand((64, 40), 121)
     s = ops.silu(a)
     r3 = _cmp("silu", s, F.silu(a.float()), atol=1e-3)
@@ -341,6 +347,13 @@ def case_window_loop():
     ref_cnt = torch.zeros_like(cnt)
     ref_cnt[idx.long()] += 2
     r2 = _cmp("window_scatter_add", acc, ref_acc, atol=1e-6)
+    acc32 = torch.zeros_like(acc)
+    eps32 = torch.randn((2 * (n_cond + win) * hw, c), generator=g).to(DEV)  # fp32 predictions (the product path)
+    ops.window_scatter_add(eps32, idx, n_cond, 2, 0, acc32, cnt.clone(), False)
+    ref32 = torch.zeros_like(acc)
+    ref32[:, :, idx.long()] += eps32.reshape(2, n_cond + win, hw, c)[:, n_cond:].permute(0, 3, 1, 2)
+    r2b = _cmp("window_scatter_add fp32", acc32, ref32, atol=0.0)
+    r2["ok"] = r2["ok"] and r2b["ok"]
     r3 = _cmp("counter", cnt, ref_cnt, atol=0.0)
     # step on the covered frames only (others have counter 0): fill counter to avoid 0-division in the check
     cnt2 = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
