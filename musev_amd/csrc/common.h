@@ -38,7 +38,8 @@ void mv_set_error(const char* fmt, ...);
     } while (0)
 
 // device helpers -------------------------------------------------------------------------------------
-__device__ __forceinline__ float mv_silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x); the reciprocal is the hardware v_rcp_f32 (1 ulp) -- results are rounded to fp16 anyway
+__device__ __forceinline__ float mv_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) gelu, matching torch.nn.functional.gelu default used by diffusers GEGLU
 __device__ __forceinline__ float mv_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

@@ -384,11 +384,406 @@ int launch_cfg_s(const GemmArgs& a0, hipStream_t stream) {
     return MV_OK;
 }
 
-int g_gemm_stage = 1;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA
+int g_gemm_stage = 1;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles
 
 template <int MODE, int TM, int TN>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
-    return g_gemm_stage == 0 ? launch_cfg_s<MODE, TM, TN, 0>(a, stream) : launch_cfg_s<MODE, TM, TN, 1>(a, stream);
+    return g_gemm_stage == 0 ? launch_cfg_s<MODE, TM, TN, 0>(a, stream) : launch_cfg_s<MODE, TM, TN, 1>(a, stream);  // 1: also the fallback of v2
+}
+
+
+// =====================================================================================================================
+// v2 kernel: same tiling / LDS image / MFMA schedule as above, with the per-K-step address arithmetic removed.
+//   * global->LDS copies are buffer_load_dwordx4 ... lds through three buffer descriptors (source 1, source 2,
+//     weights): a lane's byte offset is a 32-bit VGPR that only changes when the conv tap (or the concat source)
+//     changes; the K advance is the scalar soffset.  Predicated-off lanes (conv halo, ragged M/N/K) carry the offset
+//     0x80000000, which is out of range for every descriptor (sizes are checked < 2 GiB on the host) and therefore
+//     reads as zero -- no zero page, no per-lane pointer selects.
+//   * the weight rows of every pair of 16-row MFMA tiles are interleaved in LDS so that a lane ends up holding 8
+//     CONSECUTIVE output channels of its row: 16-byte epilogue stores / residual / bias loads (64 contiguous bytes per
+//     row per wave instruction instead of 32).
+//   * block shape is a template parameter (WGM x WGN waves): 2x2 waves (2 blocks per CU) or 4x2 waves (one
+//     512-thread block per CU, A/B tiles shared by twice as many waves).
+constexpr unsigned kOOB = 0x80000000u;
+
+struct GemmArgs2 {
+    GemmArgs g;
+    unsigned a_bytes, a2_bytes, w_bytes;
+    int wide;  // 1: N, ldc, ldr, ldrb multiples of 8 and 16-byte aligned pointers -> interleaved tiles + 16-byte epilogue
+};
+
+template <int MODE, int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, BK = 64;
+    constexpr int CA = BM / 8, CB = BN / 8;  // 8-row x 128-byte DMA chunks per tile
+    constexpr int AI = (CA + NW - 1) / NW, BI = (CB + NW - 1) / NW;
+    const GemmArgs& p = q.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sA = reinterpret_cast<half_t*>(smem);  // [2][BM*BK]
+    half_t* sB = sA + 2 * BM * BK;                  // [2][BN*BK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int id = mv_xcd_remap(blockIdx.x, nwg);
+    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int Mi = (int)p.M;
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, q.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? q.a2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, q.w_bytes, 0x00020000);
+
+    const int lrow = lane >> 3;                          // row inside an 8-row chunk
+    const unsigned lsl = (unsigned)((lane & 7) ^ lrow);  // logical 16-byte slot this lane fetches (source-side swizzle)
+    const bool perm = q.wide && !p.geglu;
+
+    // ---- A rows owned by this lane: chunk c = wave + NW*i ----
+    int a_row[AI];   // LINEAR/TCONV: global row; CONV: image base pixel n*hin*win
+    int a_y[AI], a_x[AI];
+    bool a_ok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int c = wave + NW * i;
+        const int gm = m0 + 8 * c + lrow;
+        a_ok[i] = (c < CA) && (gm < Mi);
+        if (MODE == MV_GEMM_LINEAR) {
+            a_row[i] = gm;
+            a_y[i] = a_x[i] = 0;
+        } else if (MODE == MV_GEMM_CONV3X3) {
+            const int hwo = p.hout * p.wout;
+            const int n = gm / hwo;
+            const int rem = gm - n * hwo;
+            const int oy = rem / p.wout, ox = rem - oy * p.wout;
+            a_row[i] = n * (p.hin * p.win);
+            a_y[i] = oy * p.stride;
+            a_x[i] = ox * p.stride;
+        } else {
+            a_row[i] = gm;
+            a_y[i] = (gm / p.hw) % p.t;
+            a_x[i] = 0;
+        }
+    }
+    // ---- weight rows owned by this lane (with the pair interleave) ----
+    unsigned b_off[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int c = wave + NW * j;
+        const int rr = 8 * c + lrow;  // LDS row of the B tile
+        const int wnt = rr / (16 * TN);
+        const int within = rr - wnt * (16 * TN);
+        const int jt = within >> 4, r16 = within & 15;
+        int nl = 16 * jt + r16;
+        if (perm && jt < (TN & ~1)) nl = 32 * (jt >> 1) + 8 * (r16 >> 2) + 4 * (jt & 1) + (r16 & 3);
+        const int n = n0 + wnt * (16 * TN) + nl;
+        const bool ok = (c < CB) && (n < p.N);
+        b_off[j] = ok ? ((unsigned)n * (unsigned)p.K + lsl * 8u) * 2u : kOOB;
+    }
+
+    float4v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    const bool ragged = (p.K & (BK - 1)) != 0;
+    unsigned a_off[AI];  // current byte offsets (valid for the current tap / source)
+    int kc = 0, tap = 0;
+
+    auto stage = [&](int buf, int kt) {
+        const bool second = (p.a2 != nullptr) && (kc >= p.c1);
+        if (kc == 0 || (second && kc == p.c1)) {  // tap or source changed: rebuild the lane offsets (wave-uniform branch)
+            const unsigned ldb = (unsigned)(second ? p.lda2 : p.lda) * 2u;
+            int dy = 0, dx = 0;
+            if (MODE == MV_GEMM_CONV3X3) {
+                dy = tap / 3 - 1;
+                dx = tap - (tap / 3) * 3 - 1;
+            } else if (MODE == MV_GEMM_TCONV3) {
+                dy = tap - 1;
+            }
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                bool ok = a_ok[i];
+                int row;
+                if (MODE == MV_GEMM_LINEAR) {
+                    row = a_row[i];
+                } else if (MODE == MV_GEMM_CONV3X3) {
+                    int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                    if (p.upsample) {
+                        ok = ok && iy >= 0 && iy < 2 * p.hin && ix >= 0 && ix < 2 * p.win;
+                        iy >>= 1;
+                        ix >>= 1;
+                    } else {
+                        ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
+                    }
+                    row = a_row[i] + iy * p.win + ix;
+                } else {
+                    const int tt = a_y[i] + dy;
+                    ok = ok && tt >= 0 && tt < p.t;
+                    row = a_row[i] + dy * p.hw;
+                }
+                a_off[i] = ok ? (unsigned)row * ldb + lsl * 16u : kOOB;
+            }
+        }
+        const unsigned soa = (unsigned)(second ? kc - p.c1 : kc) * 2u;
+        const unsigned sob = (unsigned)kt * (BK * 2u);
+        // ragged K (LINEAR only; conv modes need cin % 64 == 0): slots past K read as zero in the last step
+        const bool kcut = ragged && (kt == nk - 1) && ((int)(kt * BK + lsl * 8) >= p.K);
+        half_t* dA = sA + buf * (BM * BK);
+        half_t* dB = sB + buf * (BN * BK);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int c = wave + NW * i;
+            if ((CA % NW) != 0 && c >= CA) break;
+            const unsigned vo = kcut ? kOOB : a_off[i];
+            auto dst = (__attribute__((address_space(3))) void*)(dA + c * (8 * BK));
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, dst, 16, (int)vo, (int)soa, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, (int)vo, (int)soa, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int c = wave + NW * j;
+            if ((CB % NW) != 0 && c >= CB) break;
+            const unsigned vo = kcut ? kOOB : b_off[j];
+            auto dst = (__attribute__((address_space(3))) void*)(dB + c * (8 * BK));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, dst, 16, (int)vo, (int)sob, 0, 0);
+        }
+        kc += BK;
+        if (MODE != MV_GEMM_LINEAR && kc >= p.cin) {
+            kc -= p.cin;
+            ++tap;
+        }
+    };
+
+    const int a_row0 = wm * 16 * TM + l15;
+    const int b_row0 = wn * 16 * TN + l15;
+    const int swz = l15 & 7;
+
+    stage(0, 0);
+    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        const int cur = kt & 1;
+        stage(cur ^ 1, kt + 1);
+        mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+        __syncthreads();
+    }
+    {
+        const int cur = (nk - 1) & 1;
+        mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+    }
+
+    // ---- epilogue ----
+    // All global loads of a row tile (rowbias, residual) are issued together ahead of the arithmetic, under at most
+    // one wave-uniform branch per operand, so their latencies overlap instead of serialising per 8-channel group.
+    const float alpha = p.alpha ? fabsf(*p.alpha) : 1.0f;
+    const int nw0 = n0 + wn * 16 * TN;
+    if (p.geglu) {
+        if constexpr ((TN & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * 16 * TM + 16 * i + l15;
+                if (m >= Mi) continue;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int nb = nw0 + 16 * j;  // packed column of the value tile
+                    if (nb >= p.N) continue;
+                    float4v v = acc[i][j], gt = acc[i][j + 1];
+                    if (p.bias) {
+                        half4v b = *reinterpret_cast<const half4v*>(p.bias + nb + 4 * g);
+                        half4v bg = *reinterpret_cast<const half4v*>(p.bias + nb + 16 + 4 * g);
+                        v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        gt += float4v{(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+                    }
+                    half4v o = {(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
+                                (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
+                    *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + (nb >> 1) + 4 * g) = o;
+                }
+            }
+        }
+        return;
+    }
+    // column groups of this lane: NG groups of W channels (W = 8 for interleaved tile pairs, else 4)
+    constexpr int NP = TN / 2, ODD = TN & 1;
+    if (perm) {
+        float bsum[NP + ODD][8];
+#pragma unroll
+        for (int pp = 0; pp < NP + ODD; ++pp) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bsum[pp][r] = 0.f;
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const int n = nw0 + 32 * pp + 8 * g;
+                if (n < p.N) {
+                    half8v b = *reinterpret_cast<const half8v*>(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) bsum[pp][r] = (float)b[r];
+                }
+            }
+            if constexpr (ODD) {
+                const int n = nw0 + 16 * (TN - 1) + 4 * g;
+                if (n < p.N) {
+                    half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bsum[NP][r] = (float)b[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * 16 * TM + 16 * i + l15;
+            if (m >= Mi) continue;
+            half8v rb[NP + ODD], rs[NP + ODD];
+#pragma unroll
+            for (int pp = 0; pp < NP + ODD; ++pp) {
+                rb[pp] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+                rs[pp] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            if (p.rowbias) {
+                const half_t* rbp = p.rowbias + (long)(m / p.rows_per_group) * p.ldrb;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int n = nw0 + 32 * pp + 8 * g;
+                    if (n < p.N) rb[pp] = *reinterpret_cast<const half8v*>(rbp + n);
+                }
+                if constexpr (ODD) {
+                    const int n = nw0 + 16 * (TN - 1) + 4 * g;
+                    if (n < p.N) {
+                        half4v t4 = *reinterpret_cast<const half4v*>(rbp + n);
+                        rb[NP] = half8v{t4[0], t4[1], t4[2], t4[3], 0, 0, 0, 0};
+                    }
+                }
+            }
+            if (p.residual) {
+                const half_t* rsp = p.residual + (long)m * p.ldr;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int n = nw0 + 32 * pp + 8 * g;
+                    if (n < p.N) rs[pp] = *reinterpret_cast<const half8v*>(rsp + n);
+                }
+                if constexpr (ODD) {
+                    const int n = nw0 + 16 * (TN - 1) + 4 * g;
+                    if (n < p.N) {
+                        half4v t4 = *reinterpret_cast<const half4v*>(rsp + n);
+                        rs[NP] = half8v{t4[0], t4[1], t4[2], t4[3], 0, 0, 0, 0};
+                    }
+                }
+            }
+            half_t* crow = p.c + (long)m * p.ldc;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const int n = nw0 + 32 * pp + 8 * g;  // tile 2pp holds channels +0..3, tile 2pp+1 channels +4..7
+                if (n >= p.N) continue;
+                half8v o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float v = (r < 4 ? acc[i][2 * pp][r] : acc[i][2 * pp + 1][r - 4]) + bsum[pp][r] + (float)rb[pp][r];
+                    v *= alpha;
+                    if (p.act == MV_ACT_SILU) v = mv_silu(v);
+                    o[r] = (half_t)(v + (float)rs[pp][r]);
+                }
+                *reinterpret_cast<half8v*>(crow + n) = o;
+            }
+            if constexpr (ODD) {
+                const int n = nw0 + 16 * (TN - 1) + 4 * g;
+                if (n < p.N) {
+                    half4v o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][TN - 1][r] + bsum[NP][r] + (float)rb[NP][r];
+                        v *= alpha;
+                        if (p.act == MV_ACT_SILU) v = mv_silu(v);
+                        o[r] = (half_t)(v + (float)rs[NP][r]);
+                    }
+                    *reinterpret_cast<half4v*>(crow + n) = o;
+                }
+            }
+        }
+    } else {
+        // narrow path (N or a leading dimension not a multiple of 8): identity tile order, 8-byte accesses
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * 16 * TM + 16 * i + l15;
+            if (m >= Mi) continue;
+            const long grp = p.rowbias ? (m / p.rows_per_group) : 0;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nw0 + 16 * j + 4 * g;
+                if (n >= p.N) continue;
+                float4v v = acc[i][j];
+                if (p.bias) {
+                    half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
+                    v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                }
+                if (p.rowbias) {
+                    half4v b = *reinterpret_cast<const half4v*>(p.rowbias + grp * p.ldrb + n);
+                    v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                }
+                v *= alpha;
+                if (p.act == MV_ACT_SILU) {
+                    v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
+                }
+                if (p.residual) {
+                    half4v r = *reinterpret_cast<const half4v*>(p.residual + (long)m * p.ldr + n);
+                    v += float4v{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                }
+                half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int MODE, int TM, int TN, int WGM, int WGN>
+int launch_cfg2(const GemmArgs2& a0, hipStream_t stream) {
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int smem = 2 * (BM + BN) * 64 * (int)sizeof(half_t);
+    static_assert(smem <= 160 * 1024, "tile does not fit LDS");
+    GemmArgs2 a = a0;
+    a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
+    a.g.tiles_n = (a.g.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            mv_set_error("mv_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return MV_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(a.g.tiles_m * a.g.tiles_n));
+    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, a);
+    MV_CHECK_LAUNCH("mv_gemm_f16");
+    return MV_OK;
+}
+
+// tile selection for the v2 kernel.  variant 2: the 4-wave tiles of v1; variant 3: 8-wave 256x160 tiles where the grid
+// still fills the chip (>= 2 blocks per CU worth of work).
+template <int MODE>
+int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
+    const GemmArgs& g = a.g;
+    if (g.geglu) {
+        if (variant >= 3 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 512) return launch_cfg2<MODE, 4, 4, 4, 2>(a, stream);
+        return launch_cfg2<MODE, 4, 4, 2, 2>(a, stream);
+    }
+    const bool n160 = (g.N % 160) == 0;
+    const long tiles_n = n160 ? g.N / 160 : (g.N + 127) / 128;
+    const long tiles_m128 = (g.M + 127) / 128;
+    const bool small = tiles_m128 * tiles_n < 512;
+    if (n160) {
+        if (variant >= 3 && (g.M + 255) / 256 * tiles_n >= 512) return launch_cfg2<MODE, 4, 5, 4, 2>(a, stream);
+        return small ? launch_cfg2<MODE, 2, 5, 2, 2>(a, stream) : launch_cfg2<MODE, 4, 5, 2, 2>(a, stream);
+    }
+    return small ? launch_cfg2<MODE, 2, 4, 2, 2>(a, stream) : launch_cfg2<MODE, 4, 4, 2, 2>(a, stream);
 }
 
 template <int MODE>
@@ -407,7 +802,8 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    g_gemm_stage = v ? 1 : 0;
+    MV_REQUIRE(v >= 0 && v <= 3, "mv_set_gemm_variant: variant %d not in [0, 3]", v);
+    g_gemm_stage = v;
     return MV_OK;
 }
 
@@ -452,11 +848,31 @@ extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
         MV_REQUIRE(!(d->upsample && d->stride != 1), "mv_gemm_f16: upsample requires stride 1");
         MV_REQUIRE(d->hin > 0 && d->win > 0 && d->hout > 0 && d->wout > 0, "mv_gemm_f16: conv geometry missing");
         MV_REQUIRE(d->M % ((long)d->hout * d->wout) == 0, "mv_gemm_f16: M is not a whole number of output images");
-        return launch_mode<MV_GEMM_CONV3X3>(a, s);
     }
-    if (d->mode == MV_GEMM_TCONV3) {
+    if (d->mode == MV_GEMM_TCONV3)
         MV_REQUIRE(d->t > 0 && d->hw > 0 && d->M % ((long)d->t * d->hw) == 0, "mv_gemm_f16: tconv geometry: M must be B*T*HW");
-        return launch_mode<MV_GEMM_TCONV3>(a, s);
+
+    // v2 (buffer-descriptor LDS-DMA) needs every source to span < 2 GiB (32-bit byte offsets, 0x80000000 = "zero" marker)
+    if (g_gemm_stage >= 2) {
+        const long rows_in = d->mode == MV_GEMM_CONV3X3 ? (d->M / ((long)d->hout * d->wout)) * d->hin * d->win : d->M;
+        const long a_bytes = ((rows_in - 1) * (long)d->lda + d->c1) * 2;
+        const long a2_bytes = d->a2 ? ((rows_in - 1) * (long)d->lda2 + c2) * 2 : 0;
+        const long w_bytes = (long)d->N * d->K * 2;
+        const long lim = 0x7fffffffL;
+        if (a_bytes < lim && a2_bytes < lim && w_bytes < lim && d->M < lim) {
+            GemmArgs2 b;
+            b.g = a;
+            b.a_bytes = (unsigned)a_bytes; b.a2_bytes = (unsigned)a2_bytes; b.w_bytes = (unsigned)w_bytes;
+            auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+            b.wide = (d->N % 8 == 0) && (d->ldc % 8 == 0) && al16(d->c) && (!d->bias || al16(d->bias)) &&
+                     (!d->rowbias || (d->ldrb % 8 == 0 && al16(d->rowbias))) &&
+                     (!d->residual || (d->ldr % 8 == 0 && al16(d->residual)));
+            if (d->mode == MV_GEMM_CONV3X3) return launch_mode2<MV_GEMM_CONV3X3>(b, s, g_gemm_stage);
+            if (d->mode == MV_GEMM_TCONV3) return launch_mode2<MV_GEMM_TCONV3>(b, s, g_gemm_stage);
+            return launch_mode2<MV_GEMM_LINEAR>(b, s, g_gemm_stage);
+        }
     }
+    if (d->mode == MV_GEMM_CONV3X3) return launch_mode<MV_GEMM_CONV3X3>(a, s);
+    if (d->mode == MV_GEMM_TCONV3) return launch_mode<MV_GEMM_TCONV3>(a, s);
     return launch_mode<MV_GEMM_LINEAR>(a, s);
 }

@@ -5,7 +5,7 @@
 //   1. gn_stats    : per (item, row-split) per-CHANNEL partial sum / sum-of-squares (fp32).  Per-channel, not
 //                    per-group, because on the up path the input is the channel concat of two tensors and
 //                    groups of 30 / 60 channels straddle both the 8-channel vectors and the concat seam.
-//   2. gn_finalize : per item: fold splits, fold channels into the 32 groups (double), emit per-channel
+//   2. gn_finalize : per (item, group): fold splits and the group's channels (double), emit per-channel
 //                    scale = rstd*gamma and shift = beta - mean*rstd*gamma.
 //   3. gn_apply    : y = silu?(x*scale + shift), writing the concatenated [rows][c1+c2] tensor (this is the only
 //                    place the up-path concat is ever materialised, already normalised).
@@ -83,41 +83,49 @@ __global__ void gn_stats_kernel(const GnArgs a) {
     }
 }
 
-__global__ void gn_finalize_kernel(const GnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][C] channel totals, then [2][groups]
+// one block per (item, group): fold the row-split partials of the group's channels (fixed order -> deterministic),
+// reduce across the block in double, emit scale/shift for the group's channels.  (A single block per item folding
+// nsplit x C partials serially was 24 % of the whole UNet step: 1024 splits x 2 items at the temporal layers.)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a) {
+    __shared__ double red[2][4];
+    __shared__ float stat[2];
     const int C = a.oc * 8;
-    const long item = blockIdx.x;
-    float* tot = sm;
-    float* gstat = sm + 2 * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float ts = 0.f, tss = 0.f;
-        const float* pp = a.partial + item * a.nsplit * 2 * C;
-        for (int k = 0; k < a.nsplit; ++k) {
-            ts += pp[(long)k * 2 * C + c];
-            tss += pp[(long)k * 2 * C + C + c];
-        }
-        tot[c] = ts;
-        tot[C + c] = tss;
-    }
-    __syncthreads();
+    const long item = blockIdx.y;
+    const int gI = blockIdx.x;
     const int cpg = C / a.groups;
-    for (int gI = threadIdx.x; gI < a.groups; gI += blockDim.x) {
-        double ts = 0.0, tss = 0.0;
-        for (int c = gI * cpg; c < (gI + 1) * cpg; ++c) {
-            ts += (double)tot[c];
-            tss += (double)tot[C + c];
-        }
-        const double n = (double)cpg * (double)a.rows;
-        const double mean = ts / n;
-        double var = tss / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        gstat[2 * gI] = (float)mean;
-        gstat[2 * gI + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    const int c0 = gI * cpg;
+    const float* pp = a.partial + item * a.nsplit * 2 * C;
+    double ts = 0.0, tss = 0.0;
+    const int total = a.nsplit * cpg;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int k = i / cpg, c = c0 + (i - k * cpg);
+        ts += (double)pp[(long)k * 2 * C + c];
+        tss += (double)pp[(long)k * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ts += __shfl_xor(ts, o, 64);
+        tss += __shfl_xor(tss, o, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wave] = ts;
+        red[1][wave] = tss;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int gI = c / cpg;
-        const float mean = gstat[2 * gI], rstd = gstat[2 * gI + 1];
+    if (threadIdx.x == 0) {
+        const double s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const double s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double n = (double)cpg * (double)a.rows;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    for (int c = c0 + threadIdx.x; c < c0 + cpg; c += 256) {
         const float sc = rstd * (float)a.gamma[c];
         a.scale_shift[item * 2 * C + c] = sc;
         a.scale_shift[item * 2 * C + C + c] = (float)a.beta[c] - mean * sc;
@@ -201,8 +209,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
 }  // namespace
 
 extern "C" int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c) {
-    // aim for ~2048 workgroups in the stats / apply passes, each streaming at least ~32 rows
-    long want = (2048 + n_items - 1) / n_items;
+    // aim for ~1024 workgroups (4 per CU) in the stats / apply passes, each streaming at least ~32 rows
+    long want = (1024 + n_items - 1) / n_items;
     long maxsplit = rows / 32;
     if (maxsplit < 1) maxsplit = 1;
     if (want > maxsplit) want = maxsplit;
@@ -240,7 +248,7 @@ extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int3
     const int bs = oc * rl;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), (size_t)bs * 16 * sizeof(float), s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(stats)");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)n_items), dim3(256), (size_t)(2 * C + 2 * num_groups) * sizeof(float), s, a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)num_groups, (unsigned)n_items), dim3(256), 0, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(finalize)");
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(apply)");

@@ -78,10 +78,11 @@ class ParallelDenoiser:
     def __call__(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, *, num_inference_steps: int = 20,
                  guidance_scale: float = 7.5, condition_latents: Optional[torch.Tensor] = None, motion_speed: float = 8.0,
                  unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
-                 reinsert_condition: bool = True) -> torch.Tensor:
+                 reinsert_condition: bool = True, max_steps: Optional[int] = None) -> torch.Tensor:
         """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
         [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
         ``group``: torch.distributed process group to shard the units over (None = this process alone).
+        ``max_steps``: run only the first max_steps steps of the num_inference_steps-long schedule (smoke / bench helper).
         Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
         if latents.ndim != 5 or latents.shape[0] != 1:
             raise ValueError("latents must be [1, c, T, h, w]")
@@ -135,6 +136,8 @@ class ParallelDenoiser:
         tw = n_cond + win_len
 
         for step, t in enumerate(timesteps):
+            if max_steps is not None and step >= max_steps:
+                break
             eps_acc.zero_()
             t_dev = torch.tensor([float(t)], dtype=torch.float32, device=dev)
             slot = 0

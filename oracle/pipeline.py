@@ -120,8 +120,9 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                  guidance_scale: float, condition_latents: Optional[Tensor] = None, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
                  context_batch_size: int = 1, motion_speed: float = 8.0, unet_kwargs: Optional[dict] = None,
-                 record: Optional[list] = None) -> Tensor:
-    """pipeline_controlnet.py:1832-2156.  latents [1, c, T, h, w] (generated frames only); condition_latents
+                 record: Optional[list] = None, max_steps: Optional[int] = None) -> Tensor:
+    """pipeline_controlnet.py:1832-2156.  ``max_steps`` (test helper, not in the reference): stop after the first
+    max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
     vision_conditon_frames_sample_index=, sample_frame_rate=, **unet_kwargs) -> eps [2, c, n_cond + win, h, w].
     Returns the final latents with the condition frames re-inserted in front (:2149-2156)."""
@@ -137,6 +138,8 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
     global_context = prepare_global_context(context_schedule, num_inference_steps, T, context_frames, context_stride,
                                             context_overlap, context_batch_size)
     for i, t in enumerate(sched.timesteps):
+        if max_steps is not None and i >= max_steps:
+            break
         noise_pred = torch.zeros((latents.shape[0] * (2 if do_cfg else 1), *latents.shape[1:]), dtype=latents.dtype)
         counter = torch.zeros((1, 1, T, 1, 1), dtype=latents.dtype)
         for context in global_context:
