@@ -259,10 +259,19 @@ class UNet3DConditionModel(HipModule):
         bump_pack_epoch()
         return out
 
-    def _check_param_versions(self):
+    def param_epoch(self) -> int:
+        """sum of the parameters' in-place version counters: changes when a weight is edited (LoRA merge, load_state_dict)"""
+        plist = self.__dict__.get("_plist")
+        if plist is None or self.__dict__.get("_plist_training") is not self.training:
+            plist = list(self.parameters())
+            self.__dict__["_plist"], self.__dict__["_plist_training"] = plist, self.training
         v = 0
-        for p in self.parameters():
+        for p in plist:
             v += p._version
+        return v
+
+    def _check_param_versions(self):
+        v = self.param_epoch()
         if v != self._param_version:
             if self._param_version is not None:
                 bump_pack_epoch()  # some weight was edited in place (e.g. LoRA merge): re-pack lazily
@@ -359,10 +368,12 @@ class UNet3DConditionModel(HipModule):
         emb = self.time_embedding.hip_forward(ops.timestep_embedding(tt, ch0), final_silu=self.use_anivv1_cfg)
         vis_idx = None
         if vision_conditon_frames_sample_index is not None:
-            vis_idx = [int(i) for i in vision_conditon_frames_sample_index.reshape(-1).tolist()]
+            if torch.is_tensor(vision_conditon_frames_sample_index):  # the reference passes a LongTensor (device sync)
+                vis_idx = [int(i) for i in vision_conditon_frames_sample_index.reshape(-1).tolist()]
+            else:  # host ints: no device round trip (what the parallel-denoise loop passes; hipGraph-capture safe)
+                vis_idx = [int(i) for i in vision_conditon_frames_sample_index]
         if self.keep_vision_condtion and t > 1 and sample_index is not None and vis_idx is not None:
-            rows = torch.tensor([bi * t + i for bi in range(b) for i in vis_idx], dtype=torch.int32, device=dev)
-            ops.zero_rows(emb, rows)
+            ops.zero_rows(emb, self._const_rows(tuple(bi * t + i for bi in range(b) for i in vis_idx), dev))
         temb_act = emb if self.resnet_2d_skip_time_act else ops.silu(emb)  # ResnetBlock2D applies SiLU unless skip_time_act
 
         # ---- frame embedding (:909-937): window-local positions ----
@@ -442,6 +453,14 @@ class UNet3DConditionModel(HipModule):
         if skip_temporal_layers is not None:
             self.set_skip_temporal_layers(not skip_temporal_layers)
         return x
+
+    def _const_rows(self, rows: tuple, dev: torch.device) -> torch.Tensor:
+        """small constant index tensors, uploaded once (a host->device copy per forward would break graph capture)"""
+        cache = self.__dict__.setdefault("_const_idx", {})
+        key = (rows, str(dev))
+        if key not in cache:
+            cache[key] = torch.tensor(list(rows), dtype=torch.int32, device=dev)
+        return cache[key]
 
     def _tap(self, name: str, x: torch.Tensor, geo: Geo) -> None:
         if self._collect is not None:

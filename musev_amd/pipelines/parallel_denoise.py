@@ -60,8 +60,12 @@ class ParallelDenoiser:
 
     def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, *, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
-                 context_batch_size: int = 1):
+                 context_batch_size: int = 1, use_graphs: bool = True):
         self.unet = unet
+        # hipGraph capture of the per-window UNet forward (~1 500 kernel launches): replayed once per window and step,
+        # so the host only issues the loop glue.  Falls back to eager launches when capture is unavailable.
+        self.use_graphs = use_graphs
+        self._graphs: Dict[tuple, "_GraphedForward"] = {}
         self.scheduler = scheduler or DDIMScheduler()
         self.context_frames, self.context_overlap = context_frames, context_overlap
         self.context_stride, self.context_schedule = context_stride, context_schedule
@@ -129,8 +133,9 @@ class ParallelDenoiser:
         send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
         recv = torch.empty((world * max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
 
-        vis_idx = torch.arange(n_cond, dtype=torch.long, device=dev) if n_cond else None
+        vis_idx = list(range(n_cond)) if n_cond else None  # host ints (vision_condition_latent_index, :1914-1920)
         sub_idx = (torch.arange(win_len, dtype=torch.long, device=dev) + n_cond) if n_cond else None
+        t_dev = torch.zeros(1, dtype=torch.float32, device=dev)  # static timestep buffer (graph input)
         embeds = prompt_embeds.to(dev)
         eps_acc = torch.empty((halves, c, T, hw), dtype=torch.float32, device=dev)
         tw = n_cond + win_len
@@ -139,14 +144,11 @@ class ParallelDenoiser:
             if max_steps is not None and step >= max_steps:
                 break
             eps_acc.zero_()
-            t_dev = torch.tensor([float(t)], dtype=torch.float32, device=dev)
+            t_dev.fill_(float(t))
             slot = 0
             for wi, hs in my_groups:
                 x = ops.window_gather(lat, cond, idx_dev[wi], n_cond, len(hs))  # scale_model_input is the identity (DDIM)
-                ehs = embeds[hs[0]:hs[-1] + 1] if len(hs) == 2 else embeds[hs[0]:hs[0] + 1]
-                kw = {k: (self._slice_half(v, hs, halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()}
-                eps = self.unet.forward_rows(x, len(hs), tw, h, w, t_dev, ehs, sample_index=sub_idx,
-                                             vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **kw)
+                eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx, vis_idx, motion_speed, unet_kwargs)
                 if world == 1:
                     for k, hf in enumerate(hs):
                         ops.window_scatter_add(eps[k * tw * hw:(k + 1) * tw * hw], idx_dev[wi], n_cond, 1, hf, eps_acc, counter, False)
@@ -169,6 +171,30 @@ class ParallelDenoiser:
             out = torch.cat([cond.view(1, c, n_cond, h, w), out], dim=2)
         return out
 
+    def _unet_rows(self, x, hs: tuple, halves: int, tw: int, h: int, w: int, t_dev, embeds, sub_idx, vis_idx, motion_speed,
+                   unet_kwargs: dict) -> torch.Tensor:
+        """one UNet forward on window rows; hipGraph-replayed when the call signature was captured before"""
+        ehs = embeds[hs[0]:hs[-1] + 1] if len(hs) == 2 else embeds[hs[0]:hs[0] + 1]
+        kw = {k: (self._slice_half(v, list(hs), halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()}
+
+        def eager(inp):
+            return self.unet.forward_rows(inp, len(hs), tw, h, w, t_dev, ehs, sample_index=sub_idx,
+                                          vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **kw)
+
+        if not (self.use_graphs and x.is_cuda and hasattr(torch.cuda, "CUDAGraph")):
+            return eager(x)
+        # a captured graph is only valid for the exact tensors it was recorded with: key on their identities
+        key = (hs, tw, h, w, float(motion_speed), t_dev.data_ptr(), embeds.data_ptr(), tuple(vis_idx or ()),
+               tuple(sorted((k, _ident(v)) for k, v in kw.items())), tuple(x.shape), _param_epoch(self.unet))
+        gf = self._graphs.get(key)
+        if gf is None:
+            if len(self._graphs) >= 8:  # stale captures (other prompts / sizes) would pin their activation pools
+                self._graphs.clear()
+            gf = _GraphedForward(eager, x)
+            self._graphs[key] = gf
+            return gf.first_result
+        return gf(x)
+
     @staticmethod
     def _slice_half(v, hs: List[int], halves: int):
         """conditioning tensors batched over the CFG halves ([uncond, cond] on dim 0) are sliced to the owned halves"""
@@ -180,3 +206,49 @@ class ParallelDenoiser:
 
 
 _PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb")
+
+
+def _ident(v) -> tuple:
+    if torch.is_tensor(v):
+        return (v.data_ptr(), tuple(v.shape), v._version)
+    if isinstance(v, (list, tuple)):
+        return tuple(_ident(e) for e in v)
+    return (repr(v),)
+
+
+def _param_epoch(unet) -> int:
+    """changes when any parameter of the model is modified in place (LoRA merge, new checkpoint): captured graphs hold
+    pointers into the packed weight copies, which are rebuilt on such a change"""
+    fn = getattr(unet, "param_epoch", None)
+    return int(fn()) if callable(fn) else 0
+
+
+class _GraphedForward:
+    """Warm-up (eager: fills the packed-weight / conditioning caches and the allocator), then capture of fn(static_in)
+    into a hipGraph through torch.cuda.CUDAGraph.  Every kernel of libmusev_hip is launched on torch's current stream,
+    which is the capture stream inside torch.cuda.graph()."""
+
+    def __init__(self, fn, example: torch.Tensor):
+        self.static_in = example.clone()
+        self.first_result = fn(self.static_in)  # eager warm-up; also the result of this first call
+        self.graph = None
+        self.static_out = None
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.static_out = fn(self.static_in)
+            self.graph = g
+        except Exception as ex:  # noqa: BLE001 -- capture is an optimisation; eager launches remain correct
+            import warnings
+            warnings.warn(f"musev_amd: hipGraph capture failed ({ex!r}); running eager")
+            self.graph, self.fn = None, fn
+            torch.cuda.synchronize()
+        self.fn = fn
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.graph is None:
+            return self.fn(x)
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_out
