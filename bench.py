@@ -304,6 +304,7 @@ def main():
     if not args.no_roofline:
         # instrumented repeat of the same K steps: HIP events around every implicit-GEMM launch on the launch stream
         ops.GEMM_PROFILE = []
+        den.use_graphs = False  # per-launch events need eager launches (the timed region above replays hipGraphs)
         sync_all()
         t0 = time.perf_counter()
         run_steps(min(args.steps, 4))
@@ -323,7 +324,7 @@ def main():
         fam_n = sum(a[2] for a in agg.values())
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "gemm_kernel<MODE,TM,TN> (implicit-GEMM family: linear / conv3x3 / tconv3)",
+            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None,
             "launches_per_step": fam_n / min(args.steps, 4),
             "avg_launch_ms": fam_ms / max(fam_n, 1),

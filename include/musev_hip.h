@@ -74,7 +74,8 @@ typedef struct mv_gemm_desc {
 } mv_gemm_desc;
 
 int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
-/* tuning knob: 0 = register-staged global->LDS copies, 1 = LDS-DMA (global_load_lds, default) */
+/* tuning knob (A/B runs): 0 = v1 register-staged copies, 1 = v1 LDS-DMA, 2 = v2 buffer-descriptor LDS-DMA (default),
+ * 3 = v2 + 8-wave 256x160 tiles; +8 = pinned DMA/MFMA interleave in the v2 K loop */
 int mv_set_gemm_variant(int variant);
 
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------

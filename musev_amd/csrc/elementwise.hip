@@ -123,15 +123,40 @@ __global__ void conv3x3_cin_small_kernel(const half_t* x, int cin, const half_t*
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = bias ? (float)bias[o8 * 8 + j] : 0.f;
-        for (int tap = 0; tap < 9; ++tap) {
-            const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
-            if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
-            const half_t* src = x + ((img * h + iy) * wd + ix) * cin;
-            for (int ci = 0; ci < cin; ++ci) {
-                const float xv = (float)src[ci];
-                const float* wp = sw + (tap * cin + ci) * cout + o8 * 8;
+        if (cin == 4) {  // the latent case: one 8-byte load per tap, all 9 issued before the arithmetic
+            half4v xv[9];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+                const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < wd;
+                xv[tap] = half4v{0, 0, 0, 0};
+                if (ok) xv[tap] = *reinterpret_cast<const half4v*>(x + ((img * h + iy) * wd + ix) * 4);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    const float xf = (float)xv[tap][ci];
+                    const float4v w0 = *reinterpret_cast<const float4v*>(sw + (tap * 4 + ci) * cout + o8 * 8);
+                    const float4v w1 = *reinterpret_cast<const float4v*>(sw + (tap * 4 + ci) * cout + o8 * 8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = fmaf(xf, w0[j], acc[j]);
+                        acc[4 + j] = fmaf(xf, w1[j], acc[4 + j]);
+                    }
+                }
+            }
+        } else {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+                if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
+                const half_t* src = x + ((img * h + iy) * wd + ix) * cin;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float xv = (float)src[ci];
+                    const float* wp = sw + (tap * cin + ci) * cout + o8 * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
+                }
             }
         }
         half8v o;
@@ -345,7 +370,10 @@ extern "C" int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* 
     MV_REQUIRE(x && w && y && cin > 0 && cin <= 16 && cout % 8 == 0 && n_img > 0 && h > 0 && w_ > 0, "mv_conv3x3_cin_small_f16: bad args (cin=%d cout=%d)", cin, cout);
     const size_t smem = (size_t)9 * cin * cout * sizeof(float);
     MV_REQUIRE(smem <= 64 * 1024, "mv_conv3x3_cin_small_f16: weights do not fit LDS");
-    hipLaunchKernelGGL(conv3x3_cin_small_kernel, dim3(grid_for(n_img * h * w_ * (cout / 8))), dim3(kBlock), smem, (hipStream_t)stream,
+    // persistent-ish grid: every block first converts the whole weight tensor into LDS, so few, long-lived blocks
+    long gcin = (n_img * h * w_ * (cout / 8) + kBlock - 1) / kBlock;
+    if (gcin > 768) gcin = 768;  // 3 blocks per CU (46 KB of LDS each at 4 -> 320)
+    hipLaunchKernelGGL(conv3x3_cin_small_kernel, dim3((unsigned)gcin), dim3(kBlock), smem, (hipStream_t)stream,
                        (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (const half_t*)add, (half_t*)y, cout, (long)n_img, h, w_);
     MV_CHECK_LAUNCH("mv_conv3x3_cin_small_f16");
     return MV_OK;

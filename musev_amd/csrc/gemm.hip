@@ -384,7 +384,7 @@ int launch_cfg_s(const GemmArgs& a0, hipStream_t stream) {
     return MV_OK;
 }
 
-int g_gemm_stage = 1;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles
+int g_gemm_stage = 2;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles
 
 template <int MODE, int TM, int TN>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
@@ -412,7 +412,113 @@ struct GemmArgs2 {
     int wide;  // 1: N, ldc, ldr, ldrb multiples of 8 and 16-byte aligned pointers -> interleaved tiles + 16-byte epilogue
 };
 
-template <int MODE, int TM, int TN, int WGM, int WGN>
+// LDS-staged epilogue of one wave's (16*TM) x (16*TN) accumulator tile (see the call site).  GEGLU: even tiles hold
+// values, odd tiles gates; the output has 8*TN columns per wave.  Each wave owns a private staging region, so only
+// wave-level ordering is needed between its write and read phases.
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc)[TM][TN], float* stg_base, int wave, int mw0,
+                                                int nw0, int lane, float alpha, int Mi) {
+    constexpr int W = GEGLU ? 8 * TN : 16 * TN;  // output columns of the wave tile
+    constexpr int LD = W + 4;                    // floats; +4 keeps the 16-byte row-strided writes conflict-free
+    constexpr int CPR = W / 8;                   // 8-column chunks per row
+    constexpr int IT = TM >= 2 ? 2 : 1;          // 16-row tiles per pass
+    constexpr int ROWS = 16 * IT;
+    constexpr int KI = ROWS * CPR / 64;          // read iterations per pass
+    static_assert((ROWS * CPR) % 64 == 0, "staging pass must be a whole number of wave iterations");
+    float* stg = stg_base + wave * (ROWS * LD);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Nout = GEGLU ? (p.N >> 1) : p.N;
+
+    // per-column terms in the accumulator layout
+    float4v bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = float4v{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            // GEGLU: packed bias index of tile j is (2 * nw0 + 16 j + 4 g); plain: nw0 + 16 j + 4 g
+            const int n = (GEGLU ? 2 * nw0 : nw0) + 16 * j + 4 * g;
+            if (n < p.N) {
+                half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
+                bv[j] = float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < TM / IT; ++pass) {
+        // ---- residual loads of this pass first (row-contiguous layout), so they fly under the staging writes ----
+        half8v rs[KI];
+        if (!GEGLU && p.residual) {
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+                const int idx = lane + 64 * k;
+                const int r = idx / CPR, ch = idx - r * CPR;
+                const int m = mw0 + ROWS * pass + r, n = nw0 + 8 * ch;
+                rs[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < Mi && n < Nout) rs[k] = *reinterpret_cast<const half8v*>(p.residual + (long)m * p.ldr + n);
+            }
+        }
+        // ---- write phase ----
+#pragma unroll
+        for (int ii = 0; ii < IT; ++ii) {
+            const int i = pass * IT + ii;
+            const int m = mw0 + 16 * i + l15;
+            float* row = stg + (16 * ii + l15) * LD;
+            if constexpr (GEGLU) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const float4v v = acc[i][j] + bv[j], gt = acc[i][j + 1] + bv[j + 1];
+                    *reinterpret_cast<float4v*>(row + 8 * j + 4 * g) =
+                        float4v{v[0] * mv_gelu(gt[0]), v[1] * mv_gelu(gt[1]), v[2] * mv_gelu(gt[2]), v[3] * mv_gelu(gt[3])};
+                }
+            } else {
+                const half_t* rbp = nullptr;
+                if (p.rowbias && m < Mi) rbp = p.rowbias + (long)(m / p.rows_per_group) * p.ldrb;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float4v v = acc[i][j] + bv[j];
+                    const int n = nw0 + 16 * j + 4 * g;
+                    if (rbp && n < p.N) {
+                        half4v b = *reinterpret_cast<const half4v*>(rbp + n);
+                        v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                    }
+                    v *= alpha;
+                    if (p.act == MV_ACT_SILU) {
+                        v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
+                    }
+                    *reinterpret_cast<float4v*>(row + 16 * j + 4 * g) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- read phase: lane -> (row, 8-column chunk); consecutive lanes = consecutive 16-byte pieces of a row ----
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int idx = lane + 64 * k;
+            const int r = idx / CPR, ch = idx - r * CPR;
+            const int m = mw0 + ROWS * pass + r, n = nw0 + 8 * ch;
+            const float4v f0 = *reinterpret_cast<const float4v*>(stg + r * LD + 8 * ch);
+            const float4v f1 = *reinterpret_cast<const float4v*>(stg + r * LD + 8 * ch + 4);
+            if (m < Mi && n < Nout) {
+                half8v o;
+                if (!GEGLU && p.residual) {
+                    o = half8v{(half_t)(f0[0] + (float)rs[k][0]), (half_t)(f0[1] + (float)rs[k][1]), (half_t)(f0[2] + (float)rs[k][2]),
+                               (half_t)(f0[3] + (float)rs[k][3]), (half_t)(f1[0] + (float)rs[k][4]), (half_t)(f1[1] + (float)rs[k][5]),
+                               (half_t)(f1[2] + (float)rs[k][6]), (half_t)(f1[3] + (float)rs[k][7])};
+                } else {
+                    o = half8v{(half_t)f0[0], (half_t)f0[1], (half_t)f0[2], (half_t)f0[3],
+                               (half_t)f1[0], (half_t)f1[1], (half_t)f1[2], (half_t)f1[3]};
+                }
+                *reinterpret_cast<half8v*>(p.c + (long)m * p.ldc + n) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the next pass overwrites the staging rows
+    }
+}
+
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, BK = 64;
@@ -442,7 +548,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 
     const int lrow = lane >> 3;                          // row inside an 8-row chunk
     const unsigned lsl = (unsigned)((lane & 7) ^ lrow);  // logical 16-byte slot this lane fetches (source-side swizzle)
-    const bool perm = q.wide && !p.geglu;
 
     // ---- A rows owned by this lane: chunk c = wave + NW*i ----
     int a_row[AI];   // LINEAR/TCONV: global row; CONV: image base pixel n*hin*win
@@ -470,7 +575,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             a_x[i] = 0;
         }
     }
-    // ---- weight rows owned by this lane (with the pair interleave) ----
+    // ---- weight rows owned by this lane ----
     unsigned b_off[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -479,9 +584,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         const int wnt = rr / (16 * TN);
         const int within = rr - wnt * (16 * TN);
         const int jt = within >> 4, r16 = within & 15;
-        int nl = 16 * jt + r16;
-        if (perm && jt < (TN & ~1)) nl = 32 * (jt >> 1) + 8 * (r16 >> 2) + 4 * (jt & 1) + (r16 & 3);
-        const int n = n0 + wnt * (16 * TN) + nl;
+        const int n = n0 + wnt * (16 * TN) + 16 * jt + r16;
         const bool ok = (c < CB) && (n < p.N);
         b_off[j] = ok ? ((unsigned)n * (unsigned)p.K + lsl * 8u) * 2u : kOOB;
     }
@@ -497,7 +600,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     unsigned a_off[AI];  // current byte offsets (valid for the current tap / source)
     int kc = 0, tap = 0;
 
-    auto stage = [&](int buf, int kt) {
+    bool sec = false;      // source of the tile about to be issued
+    unsigned soa = 0;      // its scalar byte offset inside a source row
+
+    // cursor step (the only branchy part of the K loop): fixes (source, offsets) of the next tile to issue
+    auto prepare = [&]() {
         const bool second = (p.a2 != nullptr) && (kc >= p.c1);
         if (kc == 0 || (second && kc == p.c1)) {  // tap or source changed: rebuild the lane offsets (wave-uniform branch)
             const unsigned ldb = (unsigned)(second ? p.lda2 : p.lda) * 2u;
@@ -532,46 +639,91 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
                 a_off[i] = ok ? (unsigned)row * ldb + lsl * 16u : kOOB;
             }
         }
-        const unsigned soa = (unsigned)(second ? kc - p.c1 : kc) * 2u;
-        const unsigned sob = (unsigned)kt * (BK * 2u);
-        // ragged K (LINEAR only; conv modes need cin % 64 == 0): slots past K read as zero in the last step
-        const bool kcut = ragged && (kt == nk - 1) && ((int)(kt * BK + lsl * 8) >= p.K);
-        half_t* dA = sA + buf * (BM * BK);
-        half_t* dB = sB + buf * (BN * BK);
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int c = wave + NW * i;
-            if ((CA % NW) != 0 && c >= CA) break;
-            const unsigned vo = kcut ? kOOB : a_off[i];
-            auto dst = (__attribute__((address_space(3))) void*)(dA + c * (8 * BK));
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, dst, 16, (int)vo, (int)soa, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, (int)vo, (int)soa, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            const int c = wave + NW * j;
-            if ((CB % NW) != 0 && c >= CB) break;
-            const unsigned vo = kcut ? kOOB : b_off[j];
-            auto dst = (__attribute__((address_space(3))) void*)(dB + c * (8 * BK));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, dst, 16, (int)vo, (int)sob, 0, 0);
-        }
+        sec = second;
+        soa = (unsigned)(second ? kc - p.c1 : kc) * 2u;
         kc += BK;
         if (MODE != MV_GEMM_LINEAR && kc >= p.cin) {
             kc -= p.cin;
             ++tap;
         }
     };
+    // branch-free issue of LDS-DMA piece d (0 .. AI+BI-1) of tile kt into stage `buf`
+    auto issue_piece = [&](int d, int buf, int kt) {
+        const bool kcut = ragged && (kt == nk - 1) && ((int)(kt * BK + lsl * 8) >= p.K);  // ragged K: zero past K (LINEAR)
+        if (d < AI) {
+            const int c = wave + NW * d;
+            if ((CA % NW) != 0 && c >= CA) return;
+            const __amdgpu_buffer_rsrc_t rCur = sec ? rA2 : rA;
+            const unsigned vo = kcut ? kOOB : a_off[d];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rCur, (__attribute__((address_space(3))) void*)(sA + buf * (BM * BK) + c * (8 * BK)), 16, (int)vo, (int)soa, 0, 0);
+        } else {
+            const int j = d - AI;
+            const int c = wave + NW * j;
+            if ((CB % NW) != 0 && c >= CB) return;
+            const unsigned vo = kcut ? kOOB : b_off[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rW, (__attribute__((address_space(3))) void*)(sB + buf * (BN * BK) + c * (8 * BK)), 16, (int)vo,
+                (int)((unsigned)kt * (BK * 2u)), 0, 0);
+        }
+    };
+    auto issue = [&](int buf, int kt) {
+#pragma unroll
+        for (int d = 0; d < AI + BI; ++d) issue_piece(d, buf, kt);
+    };
 
     const int a_row0 = wm * 16 * TM + l15;
     const int b_row0 = wn * 16 * TN + l15;
     const int swz = l15 & 7;
 
-    stage(0, 0);
+    prepare();
+    issue(0, 0);
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
     for (int kt = 0; kt < nk - 1; ++kt) {
         const int cur = kt & 1;
-        stage(cur ^ 1, kt + 1);
-        mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+        prepare();
+        if constexpr (SCHED == 0) {
+            issue(cur ^ 1, kt + 1);
+            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+        } else {
+            // An LDS-DMA issue costs the wave ~60+ cycles during which it cannot feed the matrix pipe.  Here ALL fragments
+            // of the current tile are read first (so no LDS read has to stay behind an LDS-DMA write the compiler
+            // cannot disambiguate), and the pieces of the next tile are threaded between the MFMAs, pinned by
+            // sched_group_barrier.
+            constexpr int NM = TM * TN, ND = AI + BI;
+            constexpr int MF = (2 * NM / (ND + 1)) > 0 ? (2 * NM / (ND + 1)) : 1;  // MFMAs between two pieces
+            const half_t* cA = sA + cur * (BM * BK);
+            const half_t* cB = sB + cur * (BN * BK);
+            half8v af[2][TM], wf[2][TN];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int slot_off = (((kk * 4 + g) ^ swz) << 3);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
+            }
+            int cnt = 0, d = 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+                        ++cnt;
+                        if (cnt % MF == 0 && d < ND) issue_piece(d++, cur ^ 1, kt + 1);
+                    }
+#pragma unroll
+            for (; d < ND; ++d) issue_piece(d, cur ^ 1, kt + 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);  // all fragment reads
+#pragma unroll
+            for (int dd = 0; dd < ND; ++dd) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece
+            }
+            if constexpr (2 * NM > ND * MF) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - ND * MF, 0);
+        }
         __syncthreads();
     }
     {
@@ -580,15 +732,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     }
 
     // ---- epilogue ----
-    // All global loads of a row tile (rowbias, residual) are issued together ahead of the arithmetic, under at most
-    // one wave-uniform branch per operand, so their latencies overlap instead of serialising per 8-channel group.
     const float alpha = p.alpha ? fabsf(*p.alpha) : 1.0f;
     const int nw0 = n0 + wn * 16 * TN;
+    const int mw0 = m0 + wm * 16 * TM;
+    if (q.wide) {
+        // LDS-staged: the MFMA accumulator layout gives a lane 4 channels of ONE row (a wave store instruction would
+        // touch 16 rows x 32 bytes); staging the fp32 tile through LDS turns it into 16-byte-per-lane accesses whose
+        // consecutive lanes cover consecutive bytes of a row (residual loads and output stores in whole 128-byte lines).
+        __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused
+        float* stg = reinterpret_cast<float*>(smem);
+        static_assert(NW * 32 * (16 * TN + 4) * 4 <= 2 * (BM + BN) * BK * 2, "output staging does not fit the operand LDS");
+        if (p.geglu) {
+            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
+        } else {
+            epilogue_staged<TM, TN, false>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
+        }
+        return;
+    }
+    // narrow path (N or a leading dimension not a multiple of 8, or unaligned pointers): 8-byte accesses
     if (p.geglu) {
         if constexpr ((TN & 1) == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * 16 * TM + 16 * i + l15;
+                const int m = mw0 + 16 * i + l15;
                 if (m >= Mi) continue;
 #pragma unroll
                 for (int j = 0; j < TN; j += 2) {
@@ -609,141 +775,40 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         }
         return;
     }
-    // column groups of this lane: NG groups of W channels (W = 8 for interleaved tile pairs, else 4)
-    constexpr int NP = TN / 2, ODD = TN & 1;
-    if (perm) {
-        float bsum[NP + ODD][8];
 #pragma unroll
-        for (int pp = 0; pp < NP + ODD; ++pp) {
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw0 + 16 * i + l15;
+        if (m >= Mi) continue;
+        const long grp = p.rowbias ? (m / p.rows_per_group) : 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bsum[pp][r] = 0.f;
-        }
-        if (p.bias) {
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) {
-                const int n = nw0 + 32 * pp + 8 * g;
-                if (n < p.N) {
-                    half8v b = *reinterpret_cast<const half8v*>(p.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) bsum[pp][r] = (float)b[r];
-                }
-            }
-            if constexpr (ODD) {
-                const int n = nw0 + 16 * (TN - 1) + 4 * g;
-                if (n < p.N) {
-                    half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bsum[NP][r] = (float)b[r];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 16 * TM + 16 * i + l15;
-            if (m >= Mi) continue;
-            half8v rb[NP + ODD], rs[NP + ODD];
-#pragma unroll
-            for (int pp = 0; pp < NP + ODD; ++pp) {
-                rb[pp] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-                rs[pp] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw0 + 16 * j + 4 * g;
+            if (n >= p.N) continue;
+            float4v v = acc[i][j];
+            if (p.bias) {
+                half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
+                v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
             }
             if (p.rowbias) {
-                const half_t* rbp = p.rowbias + (long)(m / p.rows_per_group) * p.ldrb;
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) {
-                    const int n = nw0 + 32 * pp + 8 * g;
-                    if (n < p.N) rb[pp] = *reinterpret_cast<const half8v*>(rbp + n);
-                }
-                if constexpr (ODD) {
-                    const int n = nw0 + 16 * (TN - 1) + 4 * g;
-                    if (n < p.N) {
-                        half4v t4 = *reinterpret_cast<const half4v*>(rbp + n);
-                        rb[NP] = half8v{t4[0], t4[1], t4[2], t4[3], 0, 0, 0, 0};
-                    }
-                }
+                half4v b = *reinterpret_cast<const half4v*>(p.rowbias + grp * p.ldrb + n);
+                v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+            v *= alpha;
+            if (p.act == MV_ACT_SILU) {
+                v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
             }
             if (p.residual) {
-                const half_t* rsp = p.residual + (long)m * p.ldr;
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) {
-                    const int n = nw0 + 32 * pp + 8 * g;
-                    if (n < p.N) rs[pp] = *reinterpret_cast<const half8v*>(rsp + n);
-                }
-                if constexpr (ODD) {
-                    const int n = nw0 + 16 * (TN - 1) + 4 * g;
-                    if (n < p.N) {
-                        half4v t4 = *reinterpret_cast<const half4v*>(rsp + n);
-                        rs[NP] = half8v{t4[0], t4[1], t4[2], t4[3], 0, 0, 0, 0};
-                    }
-                }
+                half4v r = *reinterpret_cast<const half4v*>(p.residual + (long)m * p.ldr + n);
+                v += float4v{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
             }
-            half_t* crow = p.c + (long)m * p.ldc;
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) {
-                const int n = nw0 + 32 * pp + 8 * g;  // tile 2pp holds channels +0..3, tile 2pp+1 channels +4..7
-                if (n >= p.N) continue;
-                half8v o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float v = (r < 4 ? acc[i][2 * pp][r] : acc[i][2 * pp + 1][r - 4]) + bsum[pp][r] + (float)rb[pp][r];
-                    v *= alpha;
-                    if (p.act == MV_ACT_SILU) v = mv_silu(v);
-                    o[r] = (half_t)(v + (float)rs[pp][r]);
-                }
-                *reinterpret_cast<half8v*>(crow + n) = o;
-            }
-            if constexpr (ODD) {
-                const int n = nw0 + 16 * (TN - 1) + 4 * g;
-                if (n < p.N) {
-                    half4v o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][TN - 1][r] + bsum[NP][r] + (float)rb[NP][r];
-                        v *= alpha;
-                        if (p.act == MV_ACT_SILU) v = mv_silu(v);
-                        o[r] = (half_t)(v + (float)rs[NP][r]);
-                    }
-                    *reinterpret_cast<half4v*>(crow + n) = o;
-                }
-            }
-        }
-    } else {
-        // narrow path (N or a leading dimension not a multiple of 8): identity tile order, 8-byte accesses
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 16 * TM + 16 * i + l15;
-            if (m >= Mi) continue;
-            const long grp = p.rowbias ? (m / p.rows_per_group) : 0;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = nw0 + 16 * j + 4 * g;
-                if (n >= p.N) continue;
-                float4v v = acc[i][j];
-                if (p.bias) {
-                    half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
-                    v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                }
-                if (p.rowbias) {
-                    half4v b = *reinterpret_cast<const half4v*>(p.rowbias + grp * p.ldrb + n);
-                    v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                }
-                v *= alpha;
-                if (p.act == MV_ACT_SILU) {
-                    v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
-                }
-                if (p.residual) {
-                    half4v r = *reinterpret_cast<const half4v*>(p.residual + (long)m * p.ldr + n);
-                    v += float4v{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-                }
-                half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + n) = o;
-            }
+            half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + n) = o;
         }
     }
 }
 
-template <int MODE, int TM, int TN, int WGM, int WGN>
-int launch_cfg2(const GemmArgs2& a0, hipStream_t stream) {
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
+int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
     constexpr int smem = 2 * (BM + BN) * 64 * (int)sizeof(half_t);
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
@@ -752,7 +817,7 @@ int launch_cfg2(const GemmArgs2& a0, hipStream_t stream) {
     a.g.tiles_n = (a.g.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             mv_set_error("mv_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -761,9 +826,16 @@ int launch_cfg2(const GemmArgs2& a0, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid((unsigned)(a.g.tiles_m * a.g.tiles_n));
-    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, a);
+    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED>), grid, dim3(64 * WGM * WGN), smem, stream, a);
     MV_CHECK_LAUNCH("mv_gemm_f16");
     return MV_OK;
+}
+
+int g_gemm_sched = 0;  // tuning knob (mv_set_gemm_variant bit 3): 1 = pinned DMA / MFMA interleave in the K loop
+
+template <int MODE, int TM, int TN, int WGM, int WGN>
+int launch_cfg2(const GemmArgs2& a, hipStream_t stream) {
+    return g_gemm_sched ? launch_cfg2s<MODE, TM, TN, WGM, WGN, 1>(a, stream) : launch_cfg2s<MODE, TM, TN, WGM, WGN, 0>(a, stream);
 }
 
 // tile selection for the v2 kernel.  variant 2: the 4-wave tiles of v1; variant 3: 8-wave 256x160 tiles where the grid
@@ -802,8 +874,9 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    MV_REQUIRE(v >= 0 && v <= 3, "mv_set_gemm_variant: variant %d not in [0, 3]", v);
-    g_gemm_stage = v;
+    MV_REQUIRE(v >= 0 && v <= 11 && (v & 7) <= 3, "mv_set_gemm_variant: variant %d not in {0..3} (+8)", v);
+    g_gemm_stage = v & 7;
+    g_gemm_sched = (v >> 3) & 1;
     return MV_OK;
 }
 

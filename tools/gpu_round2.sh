@@ -7,12 +7,12 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
-( timeout 900 python tools/gpu_gemm_ab.py $TAG 1 2 3 2>&1 | tail -80 ) > $OUT/${TAG}_gemm_ab.log
+( timeout 900 python tools/gpu_gemm_ab.py $TAG ${VARIANTS:-2 10 11} 2>&1 | tail -80 ) > $OUT/${TAG}_gemm_ab.log
 BEST=$(python - <<PY
 import json
 try:
     r=json.load(open("$OUT/${TAG}_gemm_ab.json"))["variants"]
-    best,bt=1,None
+    best,bt=2,None
     for v,rep in r.items():
         if not rep["all_ok"]: continue
         t=sum(b.get("ms",1e9) for b in rep["bench"].values())
