@@ -132,6 +132,8 @@ typedef struct mv_attn_desc {
 } mv_attn_desc;
 
 int mv_attention_f16(const mv_attn_desc* d, void* stream);
+/* tuning knob (A/B runs): 1 = single-buffered K/V tiles, 2 = double-buffered tiles for d <= 80 (default) */
+int mv_set_attn_variant(int variant);
 
 /* ---- temporal self-attention over T <= 32 frames per pixel (K6c) -------------------------------------
  * rows are ordered (b, t, p): sequence of pixel (b, p) = rows (b*T + t)*HW + p, t = 0..T-1.

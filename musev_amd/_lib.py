@@ -67,6 +67,7 @@ SIGNATURES = {
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),
     "mv_attention_f16": (_i32, [C.POINTER(AttnDesc), _vp]),
+    "mv_set_attn_variant": (_i32, [_i32]),
     "mv_temporal_attention_f16": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _f32, _vp]),
     "mv_geglu_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
@@ -107,6 +108,9 @@ def load() -> C.CDLL:
     variant = os.environ.get("MUSEV_GEMM_VARIANT")  # tuning knob for A/B runs (see mv_set_gemm_variant)
     if variant is not None:
         lib.mv_set_gemm_variant(int(variant))
+    variant = os.environ.get("MUSEV_ATTN_VARIANT")
+    if variant is not None:
+        lib.mv_set_attn_variant(int(variant))
     _lib = lib
     return lib
 

@@ -292,6 +292,260 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     }
 }
 
+// ---- v2 of the fused attention for d = 40 / 80: double-buffered K/V tiles (ONE barrier per 64-key tile instead of two),
+// a prefetch cursor that runs one tile ahead across segment boundaries (no exposed global round trip at a segment
+// start), exact skipping of the O rescale when no row maximum moved (alpha == 1), raised wave priority inside the MFMA
+// clusters.  Math, fragment layouts and masking are those of attn_kernel.
+struct AttnCursor {
+    int seg, base, len;
+    long ldk, ldv;
+    const half_t* kb;
+    const half_t* vb;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
+    using C = AttnCfg<D>;
+    constexpr int TILE = C::LDS_HALFS;  // halfs per (K, V) buffer
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const int n = blockIdx.z;
+    const int q0 = blockIdx.x * C::QB + wave * (16 * C::QT);
+
+    // zero both K tiles once: the padded contraction columns [D, DP) must read as 0 forever
+    for (int b = 0; b < 2; ++b)
+        for (int i = tid; i < C::KV * C::KRS / 8; i += 256) reinterpret_cast<uint4*>(lds + b * TILE)[i] = uint4{0, 0, 0, 0};
+
+    half8v qf[C::QT][C::NC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int qr = q0 + 16 * qt + l15;
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+            const int dcol = 32 * c + 8 * g;
+            half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qr < p.lq && dcol < D)
+                v = *reinterpret_cast<const half8v*>(p.q + ((long)n * p.lq + qr) * p.ldq + h * D + dcol);
+            qf[qt][c] = v;
+        }
+    }
+    float4v acc_o[C::QT][C::NDT];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
+    float m_run[C::QT], l_run[C::QT];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+    }
+
+    const half_t* zero = reinterpret_cast<const half_t*>(g_attn_zero);
+    u32x4 pf[C::PF];
+    AttnStage<D> stg;   // per-thread chunk geometry, segment independent part
+#pragma unroll
+    for (int i = 0; i < C::PF; ++i) {
+        const int idx = tid + 256 * i;
+        const bool isv = idx >= C::CHUNKS;
+        const int cidx = isv ? idx - C::CHUNKS : idx;
+        const int row = cidx / C::DCH, ch = cidx - row * C::DCH;
+        stg.isv[i] = isv;
+        stg.row[i] = (idx < 2 * C::CHUNKS) ? row : (1 << 20);
+        stg.loff[i] = isv ? C::KV * C::KRS + row * C::VRS + ch * 8 : row * C::KRS + ch * 8;
+        stg.goff[i] = ch * 8;
+    }
+    AttnStage<D> st = stg;  // with the current prefetch segment's row strides folded in
+
+    auto load_seg = [&](AttnCursor& c, int seg) {
+        c.seg = seg;
+        c.base = 0;
+        if (seg < p.nseg) {
+            c.len = ATTN_SEG_FIELD(p, seg, len);
+            c.ldk = ATTN_SEG_FIELD(p, seg, ldk);
+            c.ldv = ATTN_SEG_FIELD(p, seg, ldv);
+            const int sdiv = ATTN_SEG_FIELD(p, seg, div), smul = ATTN_SEG_FIELD(p, seg, mul), sadd = ATTN_SEG_FIELD(p, seg, add);
+            const long kvb = (long)(n / sdiv) * smul + sadd;
+            c.kb = ATTN_SEG_FIELD(p, seg, k) + kvb * c.len * c.ldk + h * D;
+            c.vb = ATTN_SEG_FIELD(p, seg, v) + kvb * c.len * c.ldv + h * D;
+        } else {
+            c.len = 0;
+            c.ldk = c.ldv = 0;
+            c.kb = c.vb = zero;
+        }
+    };
+    auto advance = [&](AttnCursor& c) {
+        c.base += C::KV;
+        if (c.base >= c.len) load_seg(c, c.seg + 1);
+    };
+    auto fold_strides = [&](const AttnCursor& c) {
+#pragma unroll
+        for (int i = 0; i < C::PF; ++i) {
+            const int r = stg.row[i] < C::KV ? stg.row[i] : 0;
+            st.goff[i] = stg.goff[i] + (long)r * (stg.isv[i] ? c.ldv : c.ldk);
+        }
+    };
+
+    AttnCursor pc, cc;  // prefetch cursor (runs ahead), compute cursor
+    load_seg(pc, 0);
+    cc = pc;
+    int st_seg = 0;
+    fold_strides(pc);
+    // tile 0 -> registers -> buffer 0 ; tile 1 -> registers
+    attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
+    advance(pc);
+    __syncthreads();  // orders the zero fill before the first commit
+    attn_commit<D>(pf, st, lds);
+    bool pf_valid = pc.seg < p.nseg;
+    if (pf_valid) {
+        if (pc.seg != st_seg) {
+            fold_strides(pc);
+            st_seg = pc.seg;
+        }
+        attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
+        advance(pc);
+    }
+    __syncthreads();
+
+    for (int t = 0; cc.seg < p.nseg; ++t) {
+        half_t* cur = lds + (t & 1) * TILE;
+        half_t* nxt = lds + ((t + 1) & 1) * TILE;
+        const half_t* sK = cur;
+        const half_t* sV = cur + C::KV * C::KRS;
+        // tile t+1: registers -> the other buffer (last read in iteration t-1, which every wave has left);
+        // tile t+2: global -> registers, a whole tile of MFMAs ahead of its commit
+        if (pf_valid) attn_commit<D>(pf, st, nxt);
+        pf_valid = pc.seg < p.nseg;
+        if (pf_valid) {
+            if (pc.seg != st_seg) {
+                fold_strides(pc);
+                st_seg = pc.seg;
+            }
+            attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
+            advance(pc);
+        }
+
+        // ---- S^T = K Q^T ----
+        float4v acc_s[C::QT][4];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc_s[qt][s4] = float4v{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                half8v kf = *reinterpret_cast<const half8v*>(sK + (16 * s4 + l15) * C::KRS + 32 * c + 8 * g);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_s[qt][s4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][c], acc_s[qt][s4], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (cc.base + C::KV > cc.len) {  // tail of the segment
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (cc.base + 16 * s4 + 4 * g + r >= cc.len) {
+#pragma unroll
+                        for (int qt = 0; qt < C::QT; ++qt) acc_s[qt][s4][r] = -INFINITY;
+                    }
+                }
+        }
+        // ---- online softmax ----
+        half8v pfrag[C::QT][2];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[qt][s4][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx * p.scale_log2e);
+            // alpha == exp2(0) == 1 exactly when no row maximum of this wave moved: skipping the rescale is bit-exact
+            if (__any(m_new != m_run[qt])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
+                m_run[qt] = m_new;
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = __builtin_amdgcn_exp2f(fmaf(acc_s[qt][s4][r], p.scale_log2e, -m_new));
+                    acc_s[qt][s4][r] = e;
+                    ps += e;
+                }
+            l_run[qt] += ps;
+#pragma unroll
+            for (int cc2 = 0; cc2 < 2; ++cc2) {
+                half8v f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (half_t)acc_s[qt][2 * cc2][r];
+                    f[4 + r] = (half_t)acc_s[qt][2 * cc2 + 1][r];
+                }
+                pfrag[qt][cc2] = f;
+            }
+        }
+        // ---- O^T += V^T P^T ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int cc2 = 0; cc2 < 2; ++cc2) {
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt) {
+                const half_t* b0p = sV + (32 * cc2 + 4 * g + (l15 >> 2)) * C::VRS + 16 * dt + (l15 & 3) * 4;
+                short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0p));
+                short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0p + 16 * C::VRS));
+                typedef short short8v __attribute__((ext_vector_type(8)));
+                short8v tv = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                half8v vf = __builtin_bit_cast(half8v, tv);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfrag[qt][cc2], acc_o[qt][dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        advance(cc);
+        __syncthreads();  // tile t consumed by every wave; tile t+1 (committed above) visible
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qr = q0 + 16 * qt + l15;
+        if (qr >= p.lq) continue;
+        half_t* orow = p.out + ((long)n * p.lq + qr) * p.ldo + h * D;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+            const int dcol = 16 * dt + 4 * g;
+            if (dcol >= D) continue;
+            float4v o = acc_o[qt][dt] * inv;
+            if (p.accumulate) {
+                half4v prev = *reinterpret_cast<const half4v*>(orow + dcol);
+                o = float4v{(float)prev[0], (float)prev[1], (float)prev[2], (float)prev[3]} + o * p.out_scale;
+            }
+            half4v w = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *reinterpret_cast<half4v*>(orow + dcol) = w;
+        }
+    }
+}
+
+int g_attn_variant = 2;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
+
 // ------------------------------------------------------------------------------------------------------
 struct TAttnArgs {
     const half_t* q;
@@ -387,6 +641,12 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs a) {
 
 }  // namespace
 
+extern "C" int mv_set_attn_variant(int v) {
+    MV_REQUIRE(v == 1 || v == 2, "mv_set_attn_variant: variant %d not in {1, 2}", v);
+    g_attn_variant = v;
+    return MV_OK;
+}
+
 extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     MV_REQUIRE(d && d->q && d->out, "mv_attention_f16: null pointer");
     MV_REQUIRE(d->nseg >= 1 && d->nseg <= MV_ATTN_MAX_SEG, "mv_attention_f16: nseg=%d out of range", d->nseg);
@@ -412,7 +672,9 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     const int qb = d->d > 80 ? 64 : 128;  // AttnCfg<D>::QB
     dim3 grid((unsigned)((d->lq + qb - 1) / qb), (unsigned)d->heads, (unsigned)d->nb);
     hipStream_t s = (hipStream_t)stream;
-    if (d->d == 40) hipLaunchKernelGGL(attn_kernel<40>, grid, dim3(256), 0, s, a);
+    if (d->d == 40 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<40>, grid, dim3(256), 0, s, a);
+    else if (d->d == 80 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<80>, grid, dim3(256), 0, s, a);
+    else if (d->d == 40) hipLaunchKernelGGL(attn_kernel<40>, grid, dim3(256), 0, s, a);
     else if (d->d == 80) hipLaunchKernelGGL(attn_kernel<80>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(attn_kernel<160>, grid, dim3(256), 0, s, a);
     MV_CHECK_LAUNCH("mv_attention_f16");

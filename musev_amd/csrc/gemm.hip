@@ -412,19 +412,81 @@ struct GemmArgs2 {
     int wide;  // 1: N, ldc, ldr, ldrb multiples of 8 and 16-byte aligned pointers -> interleaved tiles + 16-byte epilogue
 };
 
+// narrow epilogue (N or a leading dimension not a multiple of 8, or unaligned pointers): 8-byte accesses straight from
+// the accumulator layout (lane = one row, 4 channels per 16-wide tile)
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_narrow(const GemmArgs& p, float4v (&acc)[TM][TN], int mw0, int nw0, int lane, float alpha,
+                                                int Mi) {
+    const int l15 = lane & 15, g = lane >> 4;
+    if (p.geglu) {
+        if constexpr ((TN & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mw0 + 16 * i + l15;
+                if (m >= Mi) continue;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int nb = nw0 + 16 * j;  // packed column of the value tile
+                    if (nb >= p.N) continue;
+                    float4v v = acc[i][j], gt = acc[i][j + 1];
+                    if (p.bias) {
+                        half4v b = *reinterpret_cast<const half4v*>(p.bias + nb + 4 * g);
+                        half4v bg = *reinterpret_cast<const half4v*>(p.bias + nb + 16 + 4 * g);
+                        v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        gt += float4v{(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+                    }
+                    half4v o = {(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
+                                (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
+                    *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + (nb >> 1) + 4 * g) = o;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw0 + 16 * i + l15;
+        if (m >= Mi) continue;
+        const long grp = p.rowbias ? (m / p.rows_per_group) : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw0 + 16 * j + 4 * g;
+            if (n >= p.N) continue;
+            float4v v = acc[i][j];
+            if (p.bias) {
+                half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
+                v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+            if (p.rowbias) {
+                half4v b = *reinterpret_cast<const half4v*>(p.rowbias + grp * p.ldrb + n);
+                v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+            v *= alpha;
+            if (p.act == MV_ACT_SILU) {
+                v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
+            }
+            if (p.residual) {
+                half4v r = *reinterpret_cast<const half4v*>(p.residual + (long)m * p.ldr + n);
+                v += float4v{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+            }
+            half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
 // LDS-staged epilogue of one wave's (16*TM) x (16*TN) accumulator tile (see the call site).  GEGLU: even tiles hold
 // values, odd tiles gates; the output has 8*TN columns per wave.  Each wave owns a private staging region, so only
 // wave-level ordering is needed between its write and read phases.
-template <int TM, int TN, bool GEGLU>
+template <int TM, int TN, bool GEGLU, int IT>  // IT = 16-row tiles staged per pass
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc)[TM][TN], float* stg_base, int wave, int mw0,
                                                 int nw0, int lane, float alpha, int Mi) {
     constexpr int W = GEGLU ? 8 * TN : 16 * TN;  // output columns of the wave tile
     constexpr int LD = W + 4;                    // floats; +4 keeps the 16-byte row-strided writes conflict-free
     constexpr int CPR = W / 8;                   // 8-column chunks per row
-    constexpr int IT = TM >= 2 ? 2 : 1;          // 16-row tiles per pass
     constexpr int ROWS = 16 * IT;
-    constexpr int KI = ROWS * CPR / 64;          // read iterations per pass
-    static_assert((ROWS * CPR) % 64 == 0, "staging pass must be a whole number of wave iterations");
+    constexpr int KI = (ROWS * CPR + 63) / 64;   // read iterations per pass (the last one may be partial)
+    static_assert(TM % IT == 0, "passes must tile the wave rows");
     float* stg = stg_base + wave * (ROWS * LD);
     const int l15 = lane & 15, g = lane >> 4;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
@@ -455,7 +517,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
                 const int r = idx / CPR, ch = idx - r * CPR;
                 const int m = mw0 + ROWS * pass + r, n = nw0 + 8 * ch;
                 rs[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-                if (m < Mi && n < Nout) rs[k] = *reinterpret_cast<const half8v*>(p.residual + (long)m * p.ldr + n);
+                if (idx < ROWS * CPR && m < Mi && n < Nout) rs[k] = *reinterpret_cast<const half8v*>(p.residual + (long)m * p.ldr + n);
             }
         }
         // ---- write phase ----
@@ -498,6 +560,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
             const int idx = lane + 64 * k;
             const int r = idx / CPR, ch = idx - r * CPR;
             const int m = mw0 + ROWS * pass + r, n = nw0 + 8 * ch;
+            if (idx >= ROWS * CPR) continue;
             const float4v f0 = *reinterpret_cast<const float4v*>(stg + r * LD + 8 * ch);
             const float4v f1 = *reinterpret_cast<const float4v*>(stg + r * LD + 8 * ch + 4);
             if (m < Mi && n < Nout) {
@@ -743,68 +806,271 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         float* stg = reinterpret_cast<float*>(smem);
         static_assert(NW * 32 * (16 * TN + 4) * 4 <= 2 * (BM + BN) * BK * 2, "output staging does not fit the operand LDS");
         if (p.geglu) {
-            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
+            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, 2>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
         } else {
-            epilogue_staged<TM, TN, false>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
+            epilogue_staged<TM, TN, false, 2>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
         }
         return;
     }
-    // narrow path (N or a leading dimension not a multiple of 8, or unaligned pointers): 8-byte accesses
-    if (p.geglu) {
-        if constexpr ((TN & 1) == 0) {
+    epilogue_narrow<TM, TN>(p, acc, mw0, nw0, lane, alpha, Mi);
+}
+
+// =====================================================================================================================
+// v3 kernel: the v2 tile engine made PERSISTENT.  Most launches of the UNet step have short K loops (K = 320 ... 1280:
+// 5-20 steps), so a one-tile-per-block grid spends as long in its prologue (row decode, first HBM round trip) and
+// epilogue as in MFMAs.  Here a block walks tiles  blockIdx, blockIdx + grid, ...  and, during the LAST K step of a
+// tile, already decodes the next tile and issues its first K tile into the LDS stage that has just become free; the
+// epilogue (staged through the other, just-consumed stage) then runs under that load.
+//   LDS: 2 stages of [A tile | B tile]; per tile the ring simply continues from whichever stage holds its K step 0.
+template <int MODE, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(const GemmArgs2 q) {
+    constexpr int NW = 4, WGN = 2;
+    constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
+    constexpr int CA = BM / 8, CB = BN / 8;
+    constexpr int AI = CA / NW, BI = (CB + NW - 1) / NW;
+    static_assert(CA % NW == 0, "A chunks must divide over the waves");
+    constexpr int STAGE = (BM + BN) * BK;  // halfs per stage
+    static_assert(NW * 16 * (16 * TN + 4) * 4 <= STAGE * 2, "output staging does not fit one operand stage");
+    const GemmArgs& p = q.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* st = reinterpret_cast<half_t*>(smem);  // stage s: A at st + s*STAGE, B at st + s*STAGE + BM*BK
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Mi = (int)p.M;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int G = (int)gridDim.x;
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, q.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? q.a2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, q.w_bytes, 0x00020000);
+
+    const int lrow = lane >> 3;
+    const unsigned lsl = (unsigned)((lane & 7) ^ lrow);
+    const int nk = (p.K + BK - 1) / BK;
+    const bool ragged = (p.K & (BK - 1)) != 0;
+
+    // it-th tile of this block: tiles [it*G, it*G + cnt) are live together; inside that range the XCD remap keeps the
+    // N-tiles of one M-tile on one XCD (shared A rows in that L2)
+    auto tile_of = [&](int it, int& tm0, int& tn0) -> bool {
+        const int base = it * G;
+        const int cnt = (ntiles - base < G) ? (ntiles - base) : G;
+        if ((int)blockIdx.x >= cnt) return false;
+        const int id = base + mv_xcd_remap(blockIdx.x, cnt);
+        const int tile_m = id / p.tiles_n;
+        tm0 = tile_m * BM;
+        tn0 = (id - tile_m * p.tiles_n) * BN;
+        return true;
+    };
+
+    // ---- loader state (of the tile whose K tiles are being issued) ----
+    int a_row[AI], a_y[AI], a_x[AI];
+    bool a_ok[AI];
+    unsigned a_off[AI], b_off[BI];
+    int kc = 0, tap = 0;
+    bool sec = false;
+    unsigned soa = 0;
+
+    auto setup_loader = [&](int m0, int n0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = mw0 + 16 * i + l15;
-                if (m >= Mi) continue;
+        for (int i = 0; i < AI; ++i) {
+            const int gm = m0 + 8 * (wave + NW * i) + lrow;
+            a_ok[i] = gm < Mi;
+            if (MODE == MV_GEMM_LINEAR) {
+                a_row[i] = gm;
+                a_y[i] = a_x[i] = 0;
+            } else if (MODE == MV_GEMM_CONV3X3) {
+                const int hwo = p.hout * p.wout;
+                const int n = gm / hwo;
+                const int rem = gm - n * hwo;
+                const int oy = rem / p.wout, ox = rem - oy * p.wout;
+                a_row[i] = n * (p.hin * p.win);
+                a_y[i] = oy * p.stride;
+                a_x[i] = ox * p.stride;
+            } else {
+                a_row[i] = gm;
+                a_y[i] = (gm / p.hw) % p.t;
+                a_x[i] = 0;
+            }
+        }
 #pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    const int nb = nw0 + 16 * j;  // packed column of the value tile
-                    if (nb >= p.N) continue;
-                    float4v v = acc[i][j], gt = acc[i][j + 1];
-                    if (p.bias) {
-                        half4v b = *reinterpret_cast<const half4v*>(p.bias + nb + 4 * g);
-                        half4v bg = *reinterpret_cast<const half4v*>(p.bias + nb + 16 + 4 * g);
-                        v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                        gt += float4v{(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+        for (int j = 0; j < BI; ++j) {
+            const int c = wave + NW * j;
+            const int n = n0 + 8 * c + lrow;  // LDS row r of the B tile holds weight row n0 + r
+            const bool ok = (c < CB) && (n < p.N);
+            b_off[j] = ok ? ((unsigned)n * (unsigned)p.K + lsl * 8u) * 2u : kOOB;
+        }
+        kc = 0;
+        tap = 0;
+    };
+    auto prepare = [&]() {
+        const bool second = (p.a2 != nullptr) && (kc >= p.c1);
+        if (kc == 0 || (second && kc == p.c1)) {
+            const unsigned ldb = (unsigned)(second ? p.lda2 : p.lda) * 2u;
+            int dy = 0, dx = 0;
+            if (MODE == MV_GEMM_CONV3X3) {
+                dy = tap / 3 - 1;
+                dx = tap - (tap / 3) * 3 - 1;
+            } else if (MODE == MV_GEMM_TCONV3) {
+                dy = tap - 1;
+            }
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                bool ok = a_ok[i];
+                int row;
+                if (MODE == MV_GEMM_LINEAR) {
+                    row = a_row[i];
+                } else if (MODE == MV_GEMM_CONV3X3) {
+                    int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                    if (p.upsample) {
+                        ok = ok && iy >= 0 && iy < 2 * p.hin && ix >= 0 && ix < 2 * p.win;
+                        iy >>= 1;
+                        ix >>= 1;
+                    } else {
+                        ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
                     }
-                    half4v o = {(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
-                                (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
-                    *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + (nb >> 1) + 4 * g) = o;
+                    row = a_row[i] + iy * p.win + ix;
+                } else {
+                    const int tt = a_y[i] + dy;
+                    ok = ok && tt >= 0 && tt < p.t;
+                    row = a_row[i] + dy * p.hw;
                 }
+                a_off[i] = ok ? (unsigned)row * ldb + lsl * 16u : kOOB;
             }
         }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = mw0 + 16 * i + l15;
-        if (m >= Mi) continue;
-        const long grp = p.rowbias ? (m / p.rows_per_group) : 0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = nw0 + 16 * j + 4 * g;
-            if (n >= p.N) continue;
-            float4v v = acc[i][j];
-            if (p.bias) {
-                half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
-                v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-            }
-            if (p.rowbias) {
-                half4v b = *reinterpret_cast<const half4v*>(p.rowbias + grp * p.ldrb + n);
-                v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-            }
-            v *= alpha;
-            if (p.act == MV_ACT_SILU) {
-                v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
-            }
-            if (p.residual) {
-                half4v r = *reinterpret_cast<const half4v*>(p.residual + (long)m * p.ldr + n);
-                v += float4v{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-            }
-            half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *reinterpret_cast<half4v*>(p.c + (long)m * p.ldc + n) = o;
+        sec = second;
+        soa = (unsigned)(second ? kc - p.c1 : kc) * 2u;
+        kc += BK;
+        if (MODE != MV_GEMM_LINEAR && kc >= p.cin) {
+            kc -= p.cin;
+            ++tap;
         }
+    };
+    auto issue = [&](int buf, int kt) {
+        const bool kcut = ragged && (kt == nk - 1) && ((int)(kt * BK + lsl * 8) >= p.K);
+        half_t* dA = st + buf * STAGE;
+        half_t* dB = dA + BM * BK;
+        const __amdgpu_buffer_rsrc_t rCur = sec ? rA2 : rA;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int c = wave + NW * i;
+            const unsigned vo = kcut ? kOOB : a_off[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rCur, (__attribute__((address_space(3))) void*)(dA + c * (8 * BK)), 16, (int)vo,
+                                                     (int)soa, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int c = wave + NW * j;
+            if ((CB % NW) != 0 && c >= CB) break;
+            const unsigned vo = kcut ? kOOB : b_off[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dB + c * (8 * BK)), 16, (int)vo,
+                                                     (int)((unsigned)kt * (BK * 2u)), 0, 0);
+        }
+    };
+
+    const int a_row0 = wm * 16 * TM + l15;
+    const int b_row0 = wn * 16 * TN + l15;
+    const int swz = l15 & 7;
+    const float alpha = p.alpha ? fabsf(*p.alpha) : 1.0f;
+
+    int lm0 = 0, ln0 = 0;
+    if (!tile_of(0, lm0, ln0)) return;  // block-uniform
+    setup_loader(lm0, ln0);
+    prepare();
+    issue(0, 0);
+    __syncthreads();
+    int b0 = 0;
+    for (int it = 0;; ++it) {
+        const int cm0 = lm0, cn0 = ln0;  // the tile being computed
+        int nm0 = 0, nn0 = 0;
+        const bool has_next = tile_of(it + 1, nm0, nn0);
+        float4v acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = (b0 + kt) & 1;
+            if (kt + 1 < nk) {
+                prepare();
+                issue(cur ^ 1, kt + 1);
+            } else if (has_next) {  // cross-tile prefetch: K step 0 of the next tile goes into the stage freed one step ago
+                lm0 = nm0;
+                ln0 = nn0;
+                setup_loader(lm0, ln0);
+                prepare();
+                issue(cur ^ 1, 0);
+            }
+            mma_tile<TM, TN>(st + cur * STAGE, st + cur * STAGE + BM * BK, acc, a_row0, b_row0, swz, g);
+            __syncthreads();  // stage `cur` fully consumed by every wave; the LDS-DMA issued above has landed
+        }
+        const int last = (b0 + nk - 1) & 1;
+        const int mw0 = cm0 + wm * 16 * TM, nw0 = cn0 + wn * 16 * TN;
+        if (q.wide) {
+            float* stg = reinterpret_cast<float*>(st + last * STAGE);  // the stage consumed last is free; the other one
+                                                                      // may already hold the next tile's first K tile
+            if (p.geglu) {
+                if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, 1>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
+            } else {
+                epilogue_staged<TM, TN, false, 1>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
+            }
+        } else {
+            epilogue_narrow<TM, TN>(p, acc, mw0, nw0, lane, alpha, Mi);
+        }
+        if (!has_next) break;
+        __syncthreads();  // every wave has left the staging rows before the next tile's K step 1 is written there
+        b0 = last ^ 1;
     }
+}
+
+int mv_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+template <int MODE, int TM, int TN>
+int launch_cfg3(const GemmArgs2& a0, hipStream_t stream) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int smem = 2 * (BM + BN) * 64 * (int)sizeof(half_t);
+    GemmArgs2 a = a0;
+    a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
+    a.g.tiles_n = (a.g.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<MODE, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            mv_set_error("mv_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return MV_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const long ntiles = (long)a.g.tiles_m * a.g.tiles_n;
+    const long resident = 2L * mv_num_cus();  // two 256-thread blocks per CU (LDS-limited)
+    dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+    hipLaunchKernelGGL((gemm3_kernel<MODE, TM, TN>), grid, dim3(256), smem, stream, a);
+    MV_CHECK_LAUNCH("mv_gemm_f16");
+    return MV_OK;
+}
+
+template <int MODE>
+int launch_mode3(const GemmArgs2& a, hipStream_t stream) {
+    const GemmArgs& g = a.g;
+    if (g.geglu) return launch_cfg3<MODE, 4, 4>(a, stream);
+    const bool n160 = (g.N % 160) == 0;
+    const long tiles_n = n160 ? g.N / 160 : (g.N + 127) / 128;
+    const long tiles_m128 = (g.M + 127) / 128;
+    const bool small = tiles_m128 * tiles_n < 512;
+    if (n160) return small ? launch_cfg3<MODE, 2, 5>(a, stream) : launch_cfg3<MODE, 4, 5>(a, stream);
+    return small ? launch_cfg3<MODE, 2, 4>(a, stream) : launch_cfg3<MODE, 4, 4>(a, stream);
 }
 
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
@@ -874,7 +1140,7 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    MV_REQUIRE(v >= 0 && v <= 11 && (v & 7) <= 3, "mv_set_gemm_variant: variant %d not in {0..3} (+8)", v);
+    MV_REQUIRE(v >= 0 && v <= 11 && (v & 7) <= 4, "mv_set_gemm_variant: variant %d not in {0..4} (+8)", v);
     g_gemm_stage = v & 7;
     g_gemm_sched = (v >> 3) & 1;
     return MV_OK;
@@ -940,6 +1206,11 @@ extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
             b.wide = (d->N % 8 == 0) && (d->ldc % 8 == 0) && al16(d->c) && (!d->bias || al16(d->bias)) &&
                      (!d->rowbias || (d->ldrb % 8 == 0 && al16(d->rowbias))) &&
                      (!d->residual || (d->ldr % 8 == 0 && al16(d->residual)));
+            if (g_gemm_stage == 4) {
+                if (d->mode == MV_GEMM_CONV3X3) return launch_mode3<MV_GEMM_CONV3X3>(b, s);
+                if (d->mode == MV_GEMM_TCONV3) return launch_mode3<MV_GEMM_TCONV3>(b, s);
+                return launch_mode3<MV_GEMM_LINEAR>(b, s);
+            }
             if (d->mode == MV_GEMM_CONV3X3) return launch_mode2<MV_GEMM_CONV3X3>(b, s, g_gemm_stage);
             if (d->mode == MV_GEMM_TCONV3) return launch_mode2<MV_GEMM_TCONV3>(b, s, g_gemm_stage);
             return launch_mode2<MV_GEMM_LINEAR>(b, s, g_gemm_stage);

@@ -93,7 +93,9 @@ class ResnetBlock2D(HipModule):
         g = self.norm1.num_groups
         h = ops.groupnorm(x, w16(self.norm1.weight), w16(self.norm1.bias), geo.n, geo.hw, eps=self.norm1.eps, silu=True,
                           x2=x2, groups=g)
-        tproj = ops.gemm(ctx.temb_act, lin_w(self.time_emb_proj), bias=lin_b(self.time_emb_proj))  # [N, Cout]
+        tproj = ctx.proj_for(self)  # [N, Cout] column slice of the batched embedding projection
+        if tproj is None:
+            tproj = ops.gemm(ctx.temb_act, lin_w(self.time_emb_proj), bias=lin_b(self.time_emb_proj))
         w1 = self.packed("conv1", lambda: ops.pack_conv_weight(self.conv1.weight.detach()))
         h = ops.conv3x3(h, w1, geo.n, geo.h, geo.w, bias=w16(self.conv1.bias), rowbias=tproj, rows_per_group=geo.hw)
         h = ops.groupnorm(h, w16(self.norm2.weight), w16(self.norm2.bias), geo.n, geo.hw, eps=self.norm2.eps, silu=True,

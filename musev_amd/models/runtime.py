@@ -52,6 +52,13 @@ class Ctx:
     skip_temporal: bool
     text_src: Optional[torch.Tensor] = None  # the caller's tensors the rows were made from (cache identity)
     clip_src: Optional[torch.Tensor] = None
+    # every ResnetBlock2D.time_emb_proj / TransformerTemporalModel.frame_emb_proj of the network applied in ONE GEMM at
+    # the top of the forward ([frames, sum of C_out]); a block takes its column slice.  (39 one-tile launches with
+    # M = 26 rows, each a serial 20-step K loop, become 2 launches that fill the chip.)
+    emb_proj: Optional[Dict[int, torch.Tensor]] = None
+
+    def proj_for(self, module) -> Optional[torch.Tensor]:
+        return None if self.emb_proj is None else self.emb_proj.get(id(module))
 
 
 def tensor_key(t: Optional[torch.Tensor]) -> tuple:

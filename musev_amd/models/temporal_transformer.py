@@ -49,7 +49,9 @@ class TransformerTemporalModel(HipModule):
             return x
         h = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.b, geo.t * geo.hw, eps=self.norm.eps,
                           silu=False, groups=self.norm.num_groups)
-        fproj = ops.gemm(ctx.femb_act, lin_w(self.frame_emb_proj), bias=lin_b(self.frame_emb_proj))  # [B*T, C]
+        fproj = ctx.proj_for(self)  # [B*T, C] column slice of the batched embedding projection
+        if fproj is None:
+            fproj = ops.gemm(ctx.femb_act, lin_w(self.frame_emb_proj), bias=lin_b(self.frame_emb_proj))
         h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowbias=fproj, rows_per_group=geo.hw)
         for blk in self.transformer_blocks:
             h = blk.hip_forward_temporal(h, geo)

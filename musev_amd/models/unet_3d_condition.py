@@ -398,7 +398,8 @@ class UNet3DConditionModel(HipModule):
                 raise NotImplementedError("vision_clip_emb must be [b, n, q]")
             clip = vision_clip_emb.to(dtype=torch.float16).reshape(-1, vision_clip_emb.shape[-1]).contiguous()
             clip_len = vision_clip_emb.shape[1]
-        ctx = Ctx(temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
+        emb_proj = self._batched_emb_proj(temb_act, femb_act)
+        ctx = Ctx(emb_proj=emb_proj, temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
                   clip=clip, clip_len=clip_len, ip_scale=float(ip_adapter_scale), skip_temporal=False,
                   text_src=encoder_hidden_states, clip_src=vision_clip_emb)
 
@@ -453,6 +454,39 @@ class UNet3DConditionModel(HipModule):
         if skip_temporal_layers is not None:
             self.set_skip_temporal_layers(not skip_temporal_layers)
         return x
+
+    def _batched_emb_proj(self, temb_act: torch.Tensor, femb_act: Optional[torch.Tensor]) -> Dict[int, torch.Tensor]:
+        """time_emb_proj of every ResnetBlock2D (diffusers ResnetBlock2D: temb = time_emb_proj(act(temb))) and
+        frame_emb_proj of every TransformerTemporalModel (temporal_transformer.py:247-251) in two GEMMs."""
+        from .layers import ResnetBlock2D, lin_b, lin_w
+        from .temporal_transformer import TransformerTemporalModel
+
+        def pack(kind, attr):
+            mods = [m for m in self.modules() if isinstance(m, kind)]
+            if not mods:
+                return None
+            w = torch.cat([lin_w(getattr(m, attr)) for m in mods], 0).contiguous()
+            b = torch.cat([lin_b(getattr(m, attr)) for m in mods], 0).contiguous()
+            offs, o = [], 0
+            for m in mods:
+                n = getattr(m, attr).weight.shape[0]
+                offs.append((id(m), o, n))
+                o += n
+            return w, b, offs
+
+        out: Dict[int, torch.Tensor] = {}
+        for name, kind, attr, src in (("tproj_all", ResnetBlock2D, "time_emb_proj", temb_act),
+                                      ("fproj_all", TransformerTemporalModel, "frame_emb_proj", femb_act)):
+            if src is None:
+                continue
+            pk = self.packed(name, lambda kind=kind, attr=attr: pack(kind, attr))
+            if pk is None:
+                continue
+            w, b, offs = pk
+            allp = ops.gemm(src, w, bias=b)
+            for mid, o, n in offs:
+                out[mid] = allp[:, o:o + n]
+        return out
 
     def _const_rows(self, rows: tuple, dev: torch.device) -> torch.Tensor:
         """small constant index tensors, uploaded once (a host->device copy per forward would break graph capture)"""

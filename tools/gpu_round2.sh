@@ -26,6 +26,7 @@ export MUSEV_GEMM_VARIANT=$BEST
 ( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $OUT/${TAG}_pytest_gpu.log
 ( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > $OUT/${TAG}_smoke.log
 ( timeout 900 python bench.py --steps 6 --warmup 2 2>&1 | tail -2 ) > $OUT/${TAG}_bench.log
+if [ "${NOPROF:-0}" = "1" ]; then tail -40 $OUT/${TAG}_gemm_ab.log; tail -3 $OUT/${TAG}_pytest_gpu.log; tail -2 $OUT/${TAG}_smoke.log; tail -1 $OUT/${TAG}_bench.log | cut -c1-1500; exit 0; fi
 cd /tmp
 ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -3 ) > $OUT/${TAG}_rocprof.log
 cd $ROOT
