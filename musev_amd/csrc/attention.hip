@@ -360,9 +360,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
     }
     AttnStage<D> st = stg;  // with the current prefetch segment's row strides folded in
 
-    auto load_seg = [&](AttnCursor& c, int seg) {
+    auto make_cur = [&](int seg) __attribute__((always_inline)) -> AttnCursor {
+        AttnCursor c;
         c.seg = seg;
         c.base = 0;
+        c.len = 0;
+        c.ldk = c.ldv = 0;
+        c.kb = c.vb = zero;
         if (seg < p.nseg) {
             c.len = ATTN_SEG_FIELD(p, seg, len);
             c.ldk = ATTN_SEG_FIELD(p, seg, ldk);
@@ -371,17 +375,15 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
             const long kvb = (long)(n / sdiv) * smul + sadd;
             c.kb = ATTN_SEG_FIELD(p, seg, k) + kvb * c.len * c.ldk + h * D;
             c.vb = ATTN_SEG_FIELD(p, seg, v) + kvb * c.len * c.ldv + h * D;
-        } else {
-            c.len = 0;
-            c.ldk = c.ldv = 0;
-            c.kb = c.vb = zero;
         }
+        return c;
     };
-    auto advance = [&](AttnCursor& c) {
+    auto next_cur = [&](AttnCursor c) __attribute__((always_inline)) -> AttnCursor {
         c.base += C::KV;
-        if (c.base >= c.len) load_seg(c, c.seg + 1);
+        if (c.base >= c.len) return make_cur(c.seg + 1);
+        return c;
     };
-    auto fold_strides = [&](const AttnCursor& c) {
+    auto fold_strides = [&](const AttnCursor& c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::PF; ++i) {
             const int r = stg.row[i] < C::KV ? stg.row[i] : 0;
@@ -389,14 +391,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
         }
     };
 
-    AttnCursor pc, cc;  // prefetch cursor (runs ahead), compute cursor
-    load_seg(pc, 0);
-    cc = pc;
+    AttnCursor pc = make_cur(0);  // prefetch cursor (runs ahead)
+    AttnCursor cc = pc;           // compute cursor
     int st_seg = 0;
     fold_strides(pc);
     // tile 0 -> registers -> buffer 0 ; tile 1 -> registers
     attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
-    advance(pc);
+    pc = next_cur(pc);
     __syncthreads();  // orders the zero fill before the first commit
     attn_commit<D>(pf, st, lds);
     bool pf_valid = pc.seg < p.nseg;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
             st_seg = pc.seg;
         }
         attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
-        advance(pc);
+        pc = next_cur(pc);
     }
     __syncthreads();
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
                 st_seg = pc.seg;
             }
             attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
-            advance(pc);
+            pc = next_cur(pc);
         }
 
         // ---- S^T = K Q^T ----
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        advance(cc);
+        cc = next_cur(cc);
         __syncthreads();  // tile t consumed by every wave; tile t+1 (committed above) visible
     }
 

@@ -96,6 +96,38 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 rep["bench"][name] = {"error": repr(ex)}
         report["variants"][str(v)] = rep
+    # ---- attention kernel variants: parity of every attention case + the reference-only self-attention shapes ----
+    from musev_amd import ops
+    report["attn"] = {}
+    for av in (1, 2):
+        assert lib.mv_set_attn_variant(av) == 0
+        rep = {"cases": {}, "bench": {}}
+        for name, fn in ALL_CASES:
+            if not name.startswith("attention"):
+                continue
+            try:
+                res = fn()
+                torch.cuda.synchronize()
+            except Exception as ex:  # noqa: BLE001
+                res = {"ok": False, "error": repr(ex)}
+            rep["cases"][name] = {"ok": bool(res.get("ok")), "max_abs_err": res.get("max_abs_err"), "error": res.get("error")}
+            print(f"attn variant {av} {'PASS' if res.get('ok') else 'FAIL'} {name} err={res.get('max_abs_err')} {res.get('error', '')}", flush=True)
+        rep["all_ok"] = all(c["ok"] for c in rep["cases"].values())
+        for (lq, d) in [(4096, 40), (1024, 80)]:
+            nb, t, heads = 26, 13, 8
+            c = heads * d
+            qkv = (torch.randn(nb * lq, 3 * c, device="cuda")).half()
+            q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+            ms = timeit(lambda: ops.attention(q, [(k, v, lq, 1, 1, 0), (k, v, lq, t, t, 0)], nb, lq, heads, d, d ** -0.5), iters=5)
+            rep["bench"][f"attn_self lq{lq} d{d}"] = {"ms": ms, "tflops": 4.0 * nb * lq * 2 * lq * c / ms / 1e9}
+            kt = torch.randn(2 * 77, 2 * c, device="cuda").half()
+            ms = timeit(lambda: ops.attention(q, [(kt[:, :c], kt[:, c:], 77, t, 1, 0)], nb, lq, heads, d, d ** -0.5), iters=5)
+            rep["bench"][f"attn_cross lq{lq} d{d}"] = {"ms": ms, "tflops": 4.0 * nb * lq * 77 * c / ms / 1e9}
+        report["attn"][str(av)] = rep
+        print(f"attn variant {av}: ok={rep['all_ok']} " + " ".join(f"{k}: {b['ms']:.3f} ms {b['tflops']:.0f} TF" for k, b in rep["bench"].items()), flush=True)
+    best_attn = 2 if report["attn"]["2"]["all_ok"] and sum(b["ms"] for b in report["attn"]["2"]["bench"].values()) <= sum(b["ms"] for b in report["attn"]["1"]["bench"].values()) else 1
+    report["best_attn"] = best_attn
+    lib.mv_set_attn_variant(best_attn)
     print(f"{'shape':44s}" + "".join(f"  v{v:>1d} TF/s   ms   " for v in variants))
     for name, _, _ in sh:
         line = f"{name:44s}"

@@ -21,8 +21,10 @@ try:
 except Exception: print(1)
 PY
 )
-echo "best variant: $BEST" | tee $OUT/${TAG}_best.log
+BESTA=$(python -c "import json; print(json.load(open('$OUT/${TAG}_gemm_ab.json')).get('best_attn', 1))" 2>/dev/null || echo 1)
+echo "best variant: gemm $BEST attn $BESTA" | tee $OUT/${TAG}_best.log
 export MUSEV_GEMM_VARIANT=$BEST
+export MUSEV_ATTN_VARIANT=$BESTA
 ( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $OUT/${TAG}_pytest_gpu.log
 ( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > $OUT/${TAG}_smoke.log
 ( timeout 900 python bench.py --steps 6 --warmup 2 2>&1 | tail -2 ) > $OUT/${TAG}_bench.log
