@@ -75,7 +75,7 @@ typedef struct mv_gemm_desc {
 
 int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
 /* tuning knob (A/B runs): 0 = v1 register-staged copies, 1 = v1 LDS-DMA, 2 = v2 buffer-descriptor LDS-DMA (default),
- * 3 = v2 + 8-wave 256x160 tiles; +8 = pinned DMA/MFMA interleave in the v2 K loop */
+ * 3 = v2 + 8-wave 256x160 tiles, 4 = persistent tile loop, 5 = 8-wave tiles on a three-stage counted-wait LDS ring */
 int mv_set_gemm_variant(int variant);
 
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
@@ -154,6 +154,9 @@ int mv_geglu_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows,
 int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
                              const void* add /* optional [rows][cout] (pose_guider_emb) */, void* y,
                              int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
+/* im2col of a 3x3 / pad-1 convolution with tiny Cin: y[pix][tap*cin + ci], zero-filled up to kpad columns (kpad % 8 == 0);
+ * conv_in then is mv_gemm_f16(LINEAR) with the weight rows zero-padded to kpad.                                          */
+int mv_im2col3x3_f16(const void* x, int32_t cin, void* y, int32_t kpad, int64_t n_img, int32_t h, int32_t w_, void* stream);
 /* y: [rows][cout] fp16, or fp32 when y_is_f32 (the UNet's noise prediction leaves the network unrounded) */
 int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
                               void* y, int32_t y_is_f32, int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);

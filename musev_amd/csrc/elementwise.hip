@@ -171,6 +171,34 @@ __global__ void conv3x3_cin_small_kernel(const half_t* x, int cin, const half_t*
     }
 }
 
+// ---- im2col for a 3x3 / pad 1 convolution with tiny Cin: y[pix][tap*cin + ci] = x[neighbour(tap)][ci], zero beyond 9*cin.
+// conv_in (4 -> 320) then runs as ONE 64-deep K step of the MFMA GEMM instead of a VALU direct convolution.
+__global__ void im2col3x3_kernel(const half_t* x, int cin, half_t* y, int kpad, long n_img, int h, int wd) {
+    const int oc = kpad >> 3;
+    const long total = n_img * h * wd * oc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % oc);
+        const long pix = i / oc;
+        const int px = (int)(pix % wd);
+        const long r = pix / wd;
+        const int py = (int)(r % h);
+        const long img = r / h;
+        half8v v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = o * 8 + j;
+            const int tap = col / cin, ci = col - tap * cin;
+            half_t e = (half_t)0.f;
+            if (tap < 9) {
+                const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+                if (iy >= 0 && iy < h && ix >= 0 && ix < wd) e = x[((img * h + iy) * wd + ix) * cin + ci];
+            }
+            v[j] = e;
+        }
+        *reinterpret_cast<half8v*>(y + pix * kpad + o * 8) = v;
+    }
+}
+
 // ---- conv3x3 with tiny Cout (conv_out: 320 -> 4): one wave per output pixel, lanes split the 9*Cin reduction ----
 template <typename OutT>
 __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x, int cin, const half_t* w,
@@ -376,6 +404,14 @@ extern "C" int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* 
     hipLaunchKernelGGL(conv3x3_cin_small_kernel, dim3((unsigned)gcin), dim3(kBlock), smem, (hipStream_t)stream,
                        (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (const half_t*)add, (half_t*)y, cout, (long)n_img, h, w_);
     MV_CHECK_LAUNCH("mv_conv3x3_cin_small_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_im2col3x3_f16(const void* x, int32_t cin, void* y, int32_t kpad, int64_t n_img, int32_t h, int32_t w_, void* stream) {
+    MV_REQUIRE(x && y && cin > 0 && kpad % 8 == 0 && kpad >= 9 * cin && n_img > 0 && h > 0 && w_ > 0, "mv_im2col3x3_f16: bad args (cin=%d kpad=%d)", cin, kpad);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(n_img * h * w_ * (kpad / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const half_t*)x, cin, (half_t*)y, kpad, (long)n_img, h, w_);
+    MV_CHECK_LAUNCH("mv_im2col3x3_f16");
     return MV_OK;
 }
 

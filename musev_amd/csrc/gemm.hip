@@ -384,7 +384,8 @@ int launch_cfg_s(const GemmArgs& a0, hipStream_t stream) {
     return MV_OK;
 }
 
-int g_gemm_stage = 2;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles
+int g_gemm_stage = 2;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles,
+                       // 4 persistent v3 kernel, 5 v2 + 8-wave tiles on a 3-stage counted-wait ring
 
 template <int MODE, int TM, int TN>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
@@ -589,8 +590,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     constexpr int AI = (CA + NW - 1) / NW, BI = (CB + NW - 1) / NW;
     const GemmArgs& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* sA = reinterpret_cast<half_t*>(smem);  // [2][BM*BK]
-    half_t* sB = sA + 2 * BM * BK;                  // [2][BN*BK]
+    constexpr int NST = (SCHED == 3) ? 3 : 2;      // LDS stages
+    half_t* sA = reinterpret_cast<half_t*>(smem);  // [NST][BM*BK]
+    half_t* sB = sA + NST * BM * BK;                // [NST][BN*BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -739,59 +741,62 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int b_row0 = wn * 16 * TN + l15;
     const int swz = l15 & 7;
 
-    prepare();
-    issue(0, 0);
-    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        const int cur = kt & 1;
+    if constexpr (SCHED == 3) {
+        // Three-stage ring with COUNTED waits: two K tiles are in flight while one is multiplied, and nothing ever drains
+        // the LDS-DMA queue inside the loop.  Per K step: this wave waits until its own pieces of tile kt have landed
+        // (s_waitcnt vmcnt(pieces of tile kt+1)), one raw s_barrier makes every wave's pieces visible and proves that all
+        // waves have finished reading the stage tile kt+2 is about to overwrite (it held tile kt-1), then the next
+        // pieces are issued and the MFMAs of tile kt run.  (__syncthreads() would add vmcnt(0) and serialise the ring.)
+        int pw = 0;  // LDS-DMA pieces this wave issues per K tile (wave-uniform)
+#pragma unroll
+        for (int d = 0; d < AI; ++d) pw += ((CA % NW) != 0 && wave + NW * d >= CA) ? 0 : 1;
+#pragma unroll
+        for (int d = 0; d < BI; ++d) pw += ((CB % NW) != 0 && wave + NW * d >= CB) ? 0 : 1;
         prepare();
-        if constexpr (SCHED == 0) {
+        issue(0, 0);
+        if (nk > 1) {
+            prepare();
+            issue(1, 1);
+        }
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                switch (pw) {  // vmcnt takes an immediate
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) {
+                prepare();
+                issue(cur == 0 ? 2 : cur - 1, kt + 2);  // (cur + 2) % 3
+            }
+            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+            cur = (cur == 2) ? 0 : cur + 1;
+        }
+    } else {
+        prepare();
+        issue(0, 0);
+        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            const int cur = kt & 1;
+            prepare();
             issue(cur ^ 1, kt + 1);
             mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
-        } else {
-            // An LDS-DMA issue costs the wave ~60+ cycles during which it cannot feed the matrix pipe.  Here ALL fragments
-            // of the current tile are read first (so no LDS read has to stay behind an LDS-DMA write the compiler
-            // cannot disambiguate), and the pieces of the next tile are threaded between the MFMAs, pinned by
-            // sched_group_barrier.
-            constexpr int NM = TM * TN, ND = AI + BI;
-            constexpr int MF = (2 * NM / (ND + 1)) > 0 ? (2 * NM / (ND + 1)) : 1;  // MFMAs between two pieces
-            const half_t* cA = sA + cur * (BM * BK);
-            const half_t* cB = sB + cur * (BN * BK);
-            half8v af[2][TM], wf[2][TN];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int slot_off = (((kk * 4 + g) ^ swz) << 3);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
-            }
-            int cnt = 0, d = 0;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
-                        ++cnt;
-                        if (cnt % MF == 0 && d < ND) issue_piece(d++, cur ^ 1, kt + 1);
-                    }
-#pragma unroll
-            for (; d < ND; ++d) issue_piece(d, cur ^ 1, kt + 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);  // all fragment reads
-#pragma unroll
-            for (int dd = 0; dd < ND; ++dd) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece
-            }
-            if constexpr (2 * NM > ND * MF) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - ND * MF, 0);
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    {
-        const int cur = (nk - 1) & 1;
-        mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+        {
+            const int cur = (nk - 1) & 1;
+            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+        }
     }
 
     // ---- epilogue ----
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         // consecutive lanes cover consecutive bytes of a row (residual loads and output stores in whole 128-byte lines).
         __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused
         float* stg = reinterpret_cast<float*>(smem);
-        static_assert(NW * 32 * (16 * TN + 4) * 4 <= 2 * (BM + BN) * BK * 2, "output staging does not fit the operand LDS");
+        static_assert(NW * 32 * (16 * TN + 4) * 4 <= NST * (BM + BN) * BK * 2, "output staging does not fit the operand LDS");
         if (p.geglu) {
             if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, 2>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
         } else {
@@ -1076,7 +1081,7 @@ int launch_mode3(const GemmArgs2& a, hipStream_t stream) {
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
-    constexpr int smem = 2 * (BM + BN) * 64 * (int)sizeof(half_t);
+    constexpr int smem = (SCHED == 3 ? 3 : 2) * (BM + BN) * 64 * (int)sizeof(half_t);
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
     GemmArgs2 a = a0;
     a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
@@ -1097,11 +1102,9 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     return MV_OK;
 }
 
-int g_gemm_sched = 0;  // tuning knob (mv_set_gemm_variant bit 3): 1 = pinned DMA / MFMA interleave in the K loop
-
 template <int MODE, int TM, int TN, int WGM, int WGN>
 int launch_cfg2(const GemmArgs2& a, hipStream_t stream) {
-    return g_gemm_sched ? launch_cfg2s<MODE, TM, TN, WGM, WGN, 1>(a, stream) : launch_cfg2s<MODE, TM, TN, WGM, WGN, 0>(a, stream);
+    return launch_cfg2s<MODE, TM, TN, WGM, WGN, 0>(a, stream);
 }
 
 // tile selection for the v2 kernel.  variant 2: the 4-wave tiles of v1; variant 3: 8-wave 256x160 tiles where the grid
@@ -1110,7 +1113,8 @@ template <int MODE>
 int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const GemmArgs& g = a.g;
     if (g.geglu) {
-        if (variant >= 3 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 512) return launch_cfg2<MODE, 4, 4, 4, 2>(a, stream);
+        if (variant == 5 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 200) return launch_cfg2s<MODE, 4, 4, 4, 2, 3>(a, stream);
+        if (variant == 3 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 512) return launch_cfg2<MODE, 4, 4, 4, 2>(a, stream);
         return launch_cfg2<MODE, 4, 4, 2, 2>(a, stream);
     }
     const bool n160 = (g.N % 160) == 0;
@@ -1118,7 +1122,9 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const long tiles_m128 = (g.M + 127) / 128;
     const bool small = tiles_m128 * tiles_n < 512;
     if (n160) {
-        if (variant >= 3 && (g.M + 255) / 256 * tiles_n >= 512) return launch_cfg2<MODE, 4, 5, 4, 2>(a, stream);
+        // variant 5: 8-wave 256x160 tiles on a three-stage counted-wait ring, wherever that grid gives every CU a block
+        if (variant == 5 && (g.M + 255) / 256 * tiles_n >= 200) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
+        if (variant == 3 && (g.M + 255) / 256 * tiles_n >= 512) return launch_cfg2<MODE, 4, 5, 4, 2>(a, stream);
         return small ? launch_cfg2<MODE, 2, 5, 2, 2>(a, stream) : launch_cfg2<MODE, 4, 5, 2, 2>(a, stream);
     }
     return small ? launch_cfg2<MODE, 2, 4, 2, 2>(a, stream) : launch_cfg2<MODE, 4, 4, 2, 2>(a, stream);
@@ -1140,9 +1146,8 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    MV_REQUIRE(v >= 0 && v <= 11 && (v & 7) <= 4, "mv_set_gemm_variant: variant %d not in {0..4} (+8)", v);
-    g_gemm_stage = v & 7;
-    g_gemm_sched = (v >> 3) & 1;
+    MV_REQUIRE(v >= 0 && v <= 5, "mv_set_gemm_variant: variant %d not in [0, 5]", v);
+    g_gemm_stage = v;
     return MV_OK;
 }
 

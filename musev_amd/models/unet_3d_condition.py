@@ -408,7 +408,11 @@ class UNet3DConditionModel(HipModule):
         if pose_guider_emb is not None:
             pose = pose_guider_emb.to(torch.float16).permute(0, 2, 3, 1).reshape(geo.rows, ch0).contiguous()
         w_in = self.packed("conv_in", lambda: ops.pack_conv_weight(self.conv_in.weight.detach()))
-        x = ops.conv3x3_cin_small(x, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose)
+        if 9 * self.conv_in.in_channels <= 64:  # latent input (4 channels): im2col + one MFMA K step
+            w_in = self.packed("conv_in64", lambda: ops.pad_cols(w_in, 64))
+            x = ops.conv3x3_cin_small_gemm(x, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose)
+        else:
+            x = ops.conv3x3_cin_small(x, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose)
         self._tap("conv_in", x, geo)
         if self.need_transformer_in:
             x = self.transformer_in.hip_forward(x, ctx, geo)

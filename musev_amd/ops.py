@@ -21,7 +21,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
 
 __all__ = [
     "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
-    "conv3x3_cin_small", "conv3x3_cout_small", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
+    "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
     "window_gather", "window_scatter_add", "cfg_ddim_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
 
@@ -310,6 +310,27 @@ def conv3x3_cin_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int
                                                _p(add_), y.data_ptr(), cout, n_img, h, w_, _stream()),
           "mv_conv3x3_cin_small_f16")
     return y
+
+
+def conv3x3_cin_small_gemm(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int,
+                           add_: Optional[torch.Tensor] = None, kpad: int = 64) -> torch.Tensor:
+    """conv_in on the matrix cores: im2col into [rows, kpad] (one 64-deep K step) + the implicit-GEMM kernel.
+    ``w`` is the packed conv weight [Cout, 9*Cin]; it is zero-padded to kpad columns here (callers cache the result
+    through ``pad_cols``)."""
+    x = _mat(x, "x")
+    cin = x.shape[1]
+    if not x.is_contiguous() or 9 * cin > kpad:
+        raise ValueError("conv3x3_cin_small_gemm: bad shapes")
+    a = torch.empty((n_img * h * w_, kpad), dtype=torch.float16, device=x.device)
+    check(_lib.load().mv_im2col3x3_f16(x.data_ptr(), cin, a.data_ptr(), kpad, n_img, h, w_, _stream()), "mv_im2col3x3_f16")
+    wp = w if w.shape[1] == kpad else pad_cols(w, kpad)
+    return gemm(a, wp, bias=bias, residual=add_)
+
+
+def pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:
+    out = torch.zeros((w.shape[0], k), dtype=w.dtype, device=w.device)
+    out[:, :w.shape[1]] = w
+    return out
 
 
 def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int,

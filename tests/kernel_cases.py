@@ -270,6 +270,10 @@ def case_conv_in_out():
     xl = x.permute(0, 2, 3, 1).reshape(n * h * w, 4).contiguous()
     got = ops.conv3x3_cin_small(xl, ops.pack_conv_weight(wt), b, n, h, w)
     r1 = _cmp("conv_in 4->320", got, ref, atol=3e-3)
+    got_g = ops.conv3x3_cin_small_gemm(xl, ops.pack_conv_weight(wt), b, n, h, w)  # im2col + MFMA path (the product path)
+    r1g = _cmp("conv_in 4->320 (im2col + gemm)", got_g, ref, atol=3e-3)
+    r1["ok"] = r1["ok"] and r1g["ok"]
+    r1["max_abs_err"] = max(r1["max_abs_err"], r1g["max_abs_err"])
     y = _rand((n, 320, h, w), 113)
     wo = _rand((4, 320, 3, 3), 114, 1.0 / math.sqrt(2880))
     bo = _rand((4,), 115)
