@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
     }
 }
 
-int g_attn_variant = 2;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
+int g_attn_variant = 1;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
 
 // ------------------------------------------------------------------------------------------------------
 struct TAttnArgs {
@@ -640,11 +640,113 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs a) {
     }
 }
 
+// ---- v2 of the temporal attention (T <= 16): the K/V rows of the block's (pixel, head) items are staged ONCE in LDS
+// with coalesced 16-byte loads (the 8 heads of a pixel are one contiguous row), and the 16 lanes of an item read them
+// back as LDS broadcasts.  tattn_kernel has every lane fetch all T key and value rows of its item from global memory
+// itself (135 16-byte loads per lane at d = 40; TA-bound at ~2.2 TB/s), this one 13.
+template <int D, int IPB>  // IPB items of 16 lanes per block
+__global__ __launch_bounds__(16 * IPB) void tattn2_kernel(const TAttnArgs a) {
+    constexpr int DCH = D / 8;
+    extern __shared__ __attribute__((aligned(16))) half_t tsm[];  // K rows [IPB][t][D], then V rows [IPB][t][D]
+    half_t* sk = tsm;
+    half_t* sv = tsm + IPB * a.t * D;
+    const int tid = threadIdx.x;
+    const long item0 = (long)blockIdx.x * IPB;
+    // ---- stage K and V: chunk index fastest, then item, then frame ----
+    const int nchunk = IPB * a.t * DCH;
+    for (int idx = tid; idx < nchunk; idx += 16 * IPB) {
+        const int ch = idx % DCH;
+        const int rest = idx / DCH;
+        const int il = rest % IPB, j = rest / IPB;
+        const long item = item0 + il;
+        u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+        if (item < a.items) {
+            const int h = (int)(item % a.heads);
+            const long bp = item / a.heads;
+            const int pix = (int)(bp % a.hw);
+            const int b = (int)(bp / a.hw);
+            const long row = ((long)b * a.t + j) * a.hw + pix;
+            kv = *reinterpret_cast<const u32x4*>(a.k + row * a.ldk + h * D + ch * 8);
+            vv = *reinterpret_cast<const u32x4*>(a.v + row * a.ldv + h * D + ch * 8);
+        }
+        *reinterpret_cast<u32x4*>(sk + (il * a.t + j) * D + ch * 8) = kv;
+        *reinterpret_cast<u32x4*>(sv + (il * a.t + j) * D + ch * 8) = vv;
+    }
+    const int il = tid >> 4, gl = tid & 15;
+    const long item = item0 + il;
+    const bool live = item < a.items;
+    const bool active = live && gl < a.t;
+    const int h = live ? (int)(item % a.heads) : 0;
+    const long bp = live ? item / a.heads : 0;
+    const int pix = (int)(bp % a.hw);
+    const int b = (int)(bp / a.hw);
+    const int tq = active ? gl : 0;
+    const long qrow = ((long)b * a.t + tq) * a.hw + pix;
+    half8v qv[DCH];
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) qv[ch] = *reinterpret_cast<const half8v*>(a.q + qrow * a.ldq + h * D + ch * 8);
+    __syncthreads();
+
+    const half_t* kb = sk + il * a.t * D;
+    const half_t* vb = sv + il * a.t * D;
+    float s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        s[j] = 0.f;
+        if (j < a.t) {  // block-uniform
+            float acc = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < DCH; ++ch) {
+                const half8v kk = *reinterpret_cast<const half8v*>(kb + j * D + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf((float)qv[ch][e], (float)kk[e], acc);
+            }
+            s[j] = acc;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < a.t) mx = fmaxf(mx, s[j] * a.scale);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float e = (j < a.t) ? __expf(s[j] * a.scale - mx) : 0.f;
+        s[j] = e;
+        l += e;
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < a.t) {
+                const half8v vv = *reinterpret_cast<const half8v*>(vb + j * D + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf(s[j], (float)vv[e], o[e]);
+            }
+        }
+        if (active) {
+            half8v w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (half_t)(o[e] * inv);
+            *reinterpret_cast<half8v*>(a.out + qrow * a.ldo + h * D + ch * 8) = w;
+        }
+    }
+}
+
+int g_tattn_variant = 2;  // 1 = tattn_kernel, 2 = tattn2_kernel where it applies (T <= 16, d in {40, 80, 160})
+
 }  // namespace
 
 extern "C" int mv_set_attn_variant(int v) {
-    MV_REQUIRE(v == 1 || v == 2, "mv_set_attn_variant: variant %d not in {1, 2}", v);
-    g_attn_variant = v;
+    // bits 0-1: spatial attention kernel (1 | 2); +4: temporal attention v1 instead of v2
+    MV_REQUIRE((v & 3) == 1 || (v & 3) == 2, "mv_set_attn_variant: variant %d", v);
+    g_attn_variant = v & 3;
+    g_tattn_variant = (v & 4) ? 1 : 2;
     return MV_OK;
 }
 
@@ -694,6 +796,14 @@ extern "C" int mv_temporal_attention_f16(const void* q, const void* k, const voi
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.b = b; a.t = t; a.hw = hw; a.heads = heads; a.d = d;
     a.scale = scale; a.items = (long)b * hw * heads;
     hipStream_t s = (hipStream_t)stream;
+    if (g_tattn_variant == 2 && t <= 16 && (d == 40 || d == 80 || d == 160)) {
+        const size_t smem = (size_t)2 * 640 * t * sizeof(half_t);  // IPB * D == 640 in every configuration (<= 40 KB)
+        if (d == 40) hipLaunchKernelGGL((tattn2_kernel<40, 16>), dim3((unsigned)((a.items + 15) / 16)), dim3(256), smem, s, a);
+        else if (d == 80) hipLaunchKernelGGL((tattn2_kernel<80, 8>), dim3((unsigned)((a.items + 7) / 8)), dim3(128), smem, s, a);
+        else hipLaunchKernelGGL((tattn2_kernel<160, 4>), dim3((unsigned)((a.items + 3) / 4)), dim3(64), smem, s, a);
+        MV_CHECK_LAUNCH("mv_temporal_attention_f16");
+        return MV_OK;
+    }
     if (t <= 16) {
         const unsigned grid = (unsigned)((a.items + 15) / 16);
         hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, a);

@@ -1122,8 +1122,13 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const long tiles_m128 = (g.M + 127) / 128;
     const bool small = tiles_m128 * tiles_n < 512;
     if (n160) {
-        // variant 5: 8-wave 256x160 tiles on a three-stage counted-wait ring, wherever that grid gives every CU a block
-        if (variant == 5 && (g.M + 255) / 256 * tiles_n >= 200) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
+        // 8-wave 256x160 tiles on a three-stage counted-wait ring.  Measured (profiles/r01e_gemm_variant_ab.log): +20 % where
+        // they form ONE round of blocks over the CUs (the M = 6656 level: 26 x 8 = 208 blocks, against 832 small
+        // 64x160 tiles), -10..-18 % on the large grids, where two independent 4-wave blocks per CU overlap better.
+        const long blocks8 = (g.M + 255) / 256 * tiles_n;
+        const long cus = mv_num_cus();
+        if (variant == 5 && blocks8 >= 200) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
+        if (variant == 2 && blocks8 * 5 >= cus * 4 && blocks8 <= cus) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
         if (variant == 3 && (g.M + 255) / 256 * tiles_n >= 512) return launch_cfg2<MODE, 4, 5, 4, 2>(a, stream);
         return small ? launch_cfg2<MODE, 2, 5, 2, 2>(a, stream) : launch_cfg2<MODE, 4, 5, 2, 2>(a, stream);
     }

@@ -16,6 +16,7 @@ Here
 Latents are kept in fp32 [C, T, HW]; the reference keeps them in the model dtype (fp16 on GPU)."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -64,7 +65,7 @@ class ParallelDenoiser:
         self.unet = unet
         # hipGraph capture of the per-window UNet forward (~1 500 kernel launches): replayed once per window and step,
         # so the host only issues the loop glue.  Falls back to eager launches when capture is unavailable.
-        self.use_graphs = use_graphs
+        self.use_graphs = use_graphs and os.environ.get("MUSEV_NO_GRAPH", "0") != "1"  # env knob for per-kernel PMC profiling
         self._graphs: Dict[tuple, "_GraphedForward"] = {}
         self.scheduler = scheduler or DDIMScheduler()
         self.context_frames, self.context_overlap = context_frames, context_overlap

@@ -409,6 +409,9 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("temporal_attention", case_temporal_attention),
     ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),
     ("temporal_attention_t20", lambda: case_temporal_attention(b=1, t=20, hw=16, d=80, seed=92)),
+    ("temporal_attention_d80_t13", lambda: case_temporal_attention(b=2, t=13, hw=33, d=80, seed=93)),
+    ("temporal_attention_d40_ragged", lambda: case_temporal_attention(b=1, t=16, hw=71, d=40, seed=94)),
+    ("temporal_attention_d160_t13", lambda: case_temporal_attention(b=2, t=13, hw=9, d=160, seed=95)),
     ("geglu", case_geglu),
     ("conv_in_out", case_conv_in_out),
     ("timestep_embedding", case_timestep_embedding),

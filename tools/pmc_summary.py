@@ -1,0 +1,37 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (gpurun_out/<tag>_pmc_<COUNTER>/...counter_collection.csv) per
+kernel family.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of a wide
+coalesced read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported (uncalibrated)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+out = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
+    agg = defaultdict(lambda: [0, 0.0])
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row.get("Kernel_Name", "")
+                fam = ("gemm" if "gemm" in name else "attn" if "attn_kernel" in name or "attn2_kernel" in name else
+                       "tattn" if "tattn" in name else "groupnorm" if "gn_" in name else "layernorm" if "layernorm" in name else "other")
+                agg[fam][0] += 1
+                agg[fam][1] += float(row.get("Counter_Value", 0.0))
+    out[counter] = {k: {"launches": v[0], "sum_kb": v[1], "avg_kb": v[1] / max(v[0], 1)} for k, v in agg.items()}
+res = {}
+for fam in out.get("FETCH_SIZE", {}):
+    f = out["FETCH_SIZE"][fam]
+    w = out.get("WRITE_SIZE", {}).get(fam, {"launches": 0, "sum_kb": 0.0, "avg_kb": 0.0})
+    n = max(f["launches"], 1)
+    res[fam] = {"launches": f["launches"], "fetch_kb_per_launch_raw": f["avg_kb"], "write_kb_per_launch": w["avg_kb"],
+                "hbm_bytes_per_launch": (2.0 * f["avg_kb"] + w["avg_kb"]) * 1024.0}
+print(json.dumps(res, indent=1))
+with open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_summary.json"), "w") as fh:
+    json.dump(res, fh, indent=1)
