@@ -118,6 +118,21 @@ def unet_flops(H, W, T, B, model="musev", n_vis=1, n_ip_tokens=4, text_tokens=77
     return 2 * tot
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per GEMM launch from the PMC counters: collected offline by tools/gpu_profile.sh (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command, gfx950 read correction x2 applied by
+    tools/pmc_summary.py) and committed as profiles/hbm_traffic.json -- a counter pass cannot run inside the timed
+    process.  None when no measurement of this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        fam = rec.get(workload, {}).get("gemm")
+        return (None, None) if fam is None else (fam["hbm_bytes_per_launch"], rec[workload].get("source"))
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def refer_shapes(h, w):
     ch, out = (320, 640, 1280, 1280), [(320, h, w)]
     hh, ww = h, w
@@ -132,14 +147,14 @@ def refer_shapes(h, w):
 def cpu_baseline(flavour: str, full_flops: float, frames: int, threads: int, state_dict, win_frames: int = 13):
     """Oracle (kind "port": plain-torch fp32 restatement of the reference) timed on the host cores on a bounded
     sample of the same workload: ONE UNet3D forward of the full window (CFG batch 2, 1 condition + 12 generated
-    frames, same weights as the GPU run) at 128x128 px (16x16 latents) instead of 512x512 -- ~2 TFLOP, 10-30 s of CPU
+    frames, same weights as the GPU run) at 256x256 px (32x32 latents) instead of 512x512 -- ~8 TFLOP, 10-30 s of CPU
     work -- extrapolated to the 512x512 forward by algorithmic FLOPs and to the 20-step denoise by x20."""
     from oracle import unet3d
     torch.set_num_threads(threads)
     cfg = unet3d.flavour_config(flavour)
     sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}  # same weights as the GPU run, fp32 on the host
     g = torch.Generator().manual_seed(0)
-    size = 128
+    size = 256
     x = torch.randn(2, 4, win_frames, size // 8, size // 8, generator=g)
     ehs = torch.randn(2, 77, 768, generator=g)
     kw = dict(sample_index=torch.arange(1, win_frames), vision_conditon_frames_sample_index=torch.tensor([0]), sample_frame_rate=8)
@@ -313,19 +328,24 @@ def main():
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
         agg = {}
-        for mode, M, N, K, geglu, e0, e1 in prof:
+        fam_bytes = 0.0
+        for mode, M, N, K, geglu, e0, e1, nbytes in prof:
             ms = e0.elapsed_time(e1)
             a = agg.setdefault(names[mode], [0.0, 0.0, 0])
             a[0] += 2.0 * M * N * K
             a[1] += ms
             a[2] += 1
+            fam_bytes += nbytes
         fam_flops = sum(a[0] for a in agg.values())
         fam_ms = sum(a[1] for a in agg.values())
         fam_n = sum(a[2] for a in agg.values())
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {
             "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3)",
-            "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None,
+            "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
+            "traffic": measured_traffic(workload)[0], "traffic_unit": "HBM bytes per launch (PMC)",
+            "traffic_source": measured_traffic(workload)[1],
+            "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
             "launches_per_step": fam_n / min(args.steps, 4),
             "avg_launch_ms": fam_ms / max(fam_n, 1),
             "algorithmic_flops_per_launch": fam_flops / max(fam_n, 1),

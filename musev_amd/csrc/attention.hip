@@ -796,7 +796,9 @@ extern "C" int mv_temporal_attention_f16(const void* q, const void* k, const voi
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.b = b; a.t = t; a.hw = hw; a.heads = heads; a.d = d;
     a.scale = scale; a.items = (long)b * hw * heads;
     hipStream_t s = (hipStream_t)stream;
-    if (g_tattn_variant == 2 && t <= 16 && (d == 40 || d == 80 || d == 160)) {
+    // v2 pays where the item count is large (level 0: 65 536 items of d = 40: 141 -> 98 us); at d = 80 / 160 its small
+    // blocks under-fill the CUs (measured 94 vs 80 us and 132 vs 44 us, profiles/r01f) and v1 stays
+    if (g_tattn_variant == 2 && t <= 16 && d == 40) {
         const size_t smem = (size_t)2 * 640 * t * sizeof(half_t);  // IPB * D == 640 in every configuration (<= 40 KB)
         if (d == 40) hipLaunchKernelGGL((tattn2_kernel<40, 16>), dim3((unsigned)((a.items + 15) / 16)), dim3(256), smem, s, a);
         else if (d == 80) hipLaunchKernelGGL((tattn2_kernel<80, 8>), dim3((unsigned)((a.items + 7) / 8)), dim3(128), smem, s, a);

@@ -45,7 +45,13 @@ def _launch_gemm(d: GemmDesc, what: str) -> None:
     e0.record()
     check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
     e1.record()
-    GEMM_PROFILE.append((int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu), e0, e1))
+    # algorithmic HBM bytes of the launch: every operand read once, the output written once
+    rows_in = int(d.M)
+    if d.mode == MV_GEMM_CONV3X3:
+        rows_in = (int(d.M) // (int(d.hout) * int(d.wout))) * int(d.hin) * int(d.win)
+    cols = int(d.N) // 2 if d.geglu else int(d.N)
+    nbytes = 2 * (rows_in * (int(d.c1) + int(d.c2)) + int(d.N) * int(d.K) + int(d.M) * cols * (2 if d.residual else 1))
+    GEMM_PROFILE.append((int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu), e0, e1, nbytes))
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
