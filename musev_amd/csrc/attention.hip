@@ -99,9 +99,13 @@ __device__ __forceinline__ void attn_commit(const u32x4 (&pf)[AttnCfg<D>::PF], c
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
+// OPT = 1 (d = 40 only, where the softmax VALU work -- not the MFMAs -- bounds the kernel): the row sums come out of
+// the P.V MFMA itself through a column of ones parked in the unused d-columns [40, 48) of the V tile, the running max
+// uses 3-input maxima, and the O rescale is skipped (exactly: alpha == 1) while no row maximum of the wave moves.
+template <int D, int OPT>
+__global__ __launch_bounds__(256, (OPT == 1 && D == 40) ? 4 : 2) void attn_kernel(const AttnArgs p) {
     using C = AttnCfg<D>;
+    constexpr bool ONES = (OPT == 1) && (C::NDT * 16 > D);
     __shared__ __attribute__((aligned(16))) half_t lds[C::LDS_HALFS];
     half_t* sK = lds;
     half_t* sV = lds + C::KV * C::KRS;
@@ -114,6 +118,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 
     // zero the K tile once: the padded contraction columns [D, DP) must read as 0 forever
     for (int i = tid; i < C::KV * C::KRS / 8; i += 256) reinterpret_cast<uint4*>(sK)[i] = uint4{0, 0, 0, 0};
+    if constexpr (ONES) {  // V[kv][D] = 1 for every key row (the commits never touch columns >= D)
+        if (tid < C::KV) sV[tid * C::VRS + D] = (half_t)1.0f;
+    }
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l15][d = 32c + 8g .. +8] ----
     half8v qf[C::QT][C::NC];
@@ -212,16 +219,38 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         half8v pfrag[C::QT][2];
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            float mx = -INFINITY;
+            float mx;
+            if constexpr (OPT == 1) {
+                float m4[4];
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+                for (int st = 0; st < 4; ++st)
+                    m4[st] = fmaxf(fmaxf(acc_s[qt][st][0], acc_s[qt][st][1]), fmaxf(acc_s[qt][st][2], acc_s[qt][st][3]));
+                mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            } else {
+                mx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[qt][st][r]);
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[qt][st][r]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx * p.scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
+            if constexpr (OPT == 1) {
+                if (__any(m_new != m_run[qt])) {  // otherwise alpha == exp2(0) == 1: skipping the rescale is bit-exact
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                    if constexpr (!ONES) l_run[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
+                    m_run[qt] = m_new;
+                }
+            } else {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
+            }
             float ps = 0.f;
 #pragma unroll
             for (int st = 0; st < 4; ++st)
@@ -229,11 +258,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     float e = __builtin_amdgcn_exp2f(fmaf(acc_s[qt][st][r], p.scale_log2e, -m_new));
                     acc_s[qt][st][r] = e;
-                    ps += e;
+                    if constexpr (!ONES) ps += e;
                 }
-            l_run[qt] = l_run[qt] * alpha + ps;
-#pragma unroll
-            for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
+            if constexpr (!ONES) l_run[qt] += ps;
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 half8v f;
@@ -270,9 +297,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     // ---- epilogue: O^T[d = 16 dt + 4 g + r][q = l15] / l ----
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if constexpr (ONES) {
+            // row D of O^T holds sum_k P[k][q] (the ones column of V): tile D / 16, lane group (D % 16) / 4, register D % 4
+            l = __shfl(acc_o[qt][D / 16][D % 4], ((D % 16) / 4) * 16 + l15, 64);
+        } else {
+            l = l_run[qt];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int qr = q0 + 16 * qt + l15;
         if (qr >= p.lq) continue;
@@ -744,7 +777,7 @@ int g_tattn_variant = 2;  // 1 = tattn_kernel, 2 = tattn2_kernel where it applie
 
 extern "C" int mv_set_attn_variant(int v) {
     // bits 0-1: spatial attention kernel (1 | 2); +4: temporal attention v1 instead of v2
-    MV_REQUIRE((v & 3) == 1 || (v & 3) == 2, "mv_set_attn_variant: variant %d", v);
+    MV_REQUIRE((v & 3) >= 1, "mv_set_attn_variant: variant %d", v);
     g_attn_variant = v & 3;
     g_tattn_variant = (v & 4) ? 1 : 2;
     return MV_OK;
@@ -777,9 +810,11 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->d == 40 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<40>, grid, dim3(256), 0, s, a);
     else if (d->d == 80 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<80>, grid, dim3(256), 0, s, a);
-    else if (d->d == 40) hipLaunchKernelGGL(attn_kernel<40>, grid, dim3(256), 0, s, a);
-    else if (d->d == 80) hipLaunchKernelGGL(attn_kernel<80>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attn_kernel<160>, grid, dim3(256), 0, s, a);
+    else if (d->d == 40 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<40, 1>), grid, dim3(256), 0, s, a);
+    else if (d->d == 80 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<80, 1>), grid, dim3(256), 0, s, a);
+    else if (d->d == 40) hipLaunchKernelGGL((attn_kernel<40, 0>), grid, dim3(256), 0, s, a);
+    else if (d->d == 80) hipLaunchKernelGGL((attn_kernel<80, 0>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<160, 0>), grid, dim3(256), 0, s, a);
     MV_CHECK_LAUNCH("mv_attention_f16");
     return MV_OK;
 }
