@@ -103,9 +103,9 @@ __device__ __forceinline__ void attn_commit(const u32x4 (&pf)[AttnCfg<D>::PF], c
 // the P.V MFMA itself through a column of ones parked in the unused d-columns [40, 48) of the V tile, the running max
 // uses 3-input maxima, and the O rescale is skipped (exactly: alpha == 1) while no row maximum of the wave moves.
 template <int D, int OPT>
-__global__ __launch_bounds__(256, (OPT == 1 && D == 40) ? 4 : 2) void attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kernel(const AttnArgs p) {
     using C = AttnCfg<D>;
-    constexpr bool ONES = (OPT == 1) && (C::NDT * 16 > D);
+    constexpr bool ONES = (OPT >= 1) && (C::NDT * 16 > D);
     __shared__ __attribute__((aligned(16))) half_t lds[C::LDS_HALFS];
     half_t* sK = lds;
     half_t* sV = lds + C::KV * C::KRS;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, (OPT == 1 && D == 40) ? 4 : 2) void attn_kerne
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
             float mx;
-            if constexpr (OPT == 1) {
+            if constexpr (OPT >= 1) {
                 float m4[4];
 #pragma unroll
                 for (int st = 0; st < 4; ++st)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, (OPT == 1 && D == 40) ? 4 : 2) void attn_kerne
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx * p.scale_log2e);
-            if constexpr (OPT == 1) {
+            if constexpr (OPT >= 1) {
                 if (__any(m_new != m_run[qt])) {  // otherwise alpha == exp2(0) == 1: skipping the rescale is bit-exact
                     const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
                     if constexpr (!ONES) l_run[qt] *= alpha;
@@ -263,13 +263,25 @@ __global__ __launch_bounds__(256, (OPT == 1 && D == 40) ? 4 : 2) void attn_kerne
             if constexpr (!ONES) l_run[qt] += ps;
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                half8v f;
+                if constexpr (OPT == 2) {
+                    // one v_cvt_pkrtz_f16_f32 per two probabilities (round toward zero); with the ones-column row sums
+                    // numerator and denominator see the SAME rounded values, so the bias cancels in O = sum(p v) / sum(p)
+                    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+                    union { fp16x2 h2[4]; half8v h8; } u;
+                    u.h2[0] = __builtin_amdgcn_cvt_pkrtz(acc_s[qt][2 * cc][0], acc_s[qt][2 * cc][1]);
+                    u.h2[1] = __builtin_amdgcn_cvt_pkrtz(acc_s[qt][2 * cc][2], acc_s[qt][2 * cc][3]);
+                    u.h2[2] = __builtin_amdgcn_cvt_pkrtz(acc_s[qt][2 * cc + 1][0], acc_s[qt][2 * cc + 1][1]);
+                    u.h2[3] = __builtin_amdgcn_cvt_pkrtz(acc_s[qt][2 * cc + 1][2], acc_s[qt][2 * cc + 1][3]);
+                    pfrag[qt][cc] = u.h8;
+                } else {
+                    half8v f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f[r] = (half_t)acc_s[qt][2 * cc][r];
-                    f[4 + r] = (half_t)acc_s[qt][2 * cc + 1][r];
+                    for (int r = 0; r < 4; ++r) {
+                        f[r] = (half_t)acc_s[qt][2 * cc][r];
+                        f[4 + r] = (half_t)acc_s[qt][2 * cc + 1][r];
+                    }
+                    pfrag[qt][cc] = f;
                 }
-                pfrag[qt][cc] = f;
             }
         }
         // ---- O^T += V^T P^T : A = V^T fragment via transpose read, B = P fragment ----
@@ -578,7 +590,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
     }
 }
 
-int g_attn_variant = 1;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
+int g_attn_pkrtz = 0;    // +8 on mv_set_attn_variant: round-toward-zero packing of P (variant 3, d = 40)
+int g_attn_variant = 3;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
 
 // ------------------------------------------------------------------------------------------------------
 struct TAttnArgs {
@@ -780,6 +793,7 @@ extern "C" int mv_set_attn_variant(int v) {
     MV_REQUIRE((v & 3) >= 1, "mv_set_attn_variant: variant %d", v);
     g_attn_variant = v & 3;
     g_tattn_variant = (v & 4) ? 1 : 2;
+    g_attn_pkrtz = (v & 8) ? 1 : 0;
     return MV_OK;
 }
 
@@ -810,6 +824,7 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->d == 40 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<40>, grid, dim3(256), 0, s, a);
     else if (d->d == 80 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<80>, grid, dim3(256), 0, s, a);
+    else if (d->d == 40 && g_attn_variant == 3 && g_attn_pkrtz) hipLaunchKernelGGL((attn_kernel<40, 2>), grid, dim3(256), 0, s, a);
     else if (d->d == 40 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<40, 1>), grid, dim3(256), 0, s, a);
     else if (d->d == 80 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<80, 1>), grid, dim3(256), 0, s, a);
     else if (d->d == 40) hipLaunchKernelGGL((attn_kernel<40, 0>), grid, dim3(256), 0, s, a);

@@ -38,6 +38,10 @@ UNET_CASES = {
     "musev_hipw": dict(flavour="musev", arch=_HIPW, b=2, t=5, h=16, w=16, n_cond=1, weight_seed=5, input_seed=16, timestep=601),
     "refnet_hipw": dict(flavour="musev_referencenet", arch=_HIPW3, b=2, t=5, h=16, w=16, n_cond=1, weight_seed=6, input_seed=17,
                         timestep=401),
+    # config-5 inputs (musev_referencenet_pose == musev_referencenet, unet_loader.py:243-268): ControlNet residuals on every
+    # skip + the mid block (unet_3d_condition.py:1146-1156,1195), PoseGuider embedding after conv_in (:1011-1016); 24x16 latents
+    "refnet_hipw_pose_controlnet": dict(flavour="musev_referencenet", arch=_HIPW3, b=2, t=4, h=24, w=16, n_cond=1, weight_seed=7,
+                                        input_seed=18, timestep=701, controlnet=True, pose=True),
 }
 
 
@@ -74,6 +78,12 @@ def case_inputs(case: dict, cfg: dict):
     if cfg["ip_adapter_cross_attn"]:
         kw["vision_clip_emb"] = torch.randn(b, 4, cfg["cross_attention_dim"], generator=g)
         kw["ip_adapter_scale"] = 0.8
+    if case.get("controlnet"):
+        shapes, mid = refer_shapes(cfg, h, w)  # the skip tensors have the ReferenceNet feature shapes
+        kw["down_block_additional_residuals"] = [0.1 * torch.randn(b * t, c, a, b_, generator=g) for c, a, b_ in shapes]
+        kw["mid_block_additional_residual"] = 0.1 * torch.randn(b * t, mid[0], mid[1], mid[2], generator=g)
+    if case.get("pose"):
+        kw["pose_guider_emb"] = 0.1 * torch.randn(b * t, cfg["block_out_channels"][0], h, w, generator=g)
     if case.get("skip_temporal_layers") is not None:
         kw["skip_temporal_layers"] = case["skip_temporal_layers"]
     return x, torch.tensor(case["timestep"]), ehs, kw
