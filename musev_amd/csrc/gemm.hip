@@ -585,12 +585,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
     constexpr int NW = WGM * WGN;
-    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, BK = 64;
-    constexpr int CA = BM / 8, CB = BN / 8;  // 8-row x 128-byte DMA chunks per tile
+    // SCHED: 0 = BK 64, two stages, __syncthreads ring; 3 = BK 64, three stages, counted waits; 4 = BK 32, four stages,
+    // counted waits (three K tiles in flight per block: 3/4 of the block's LDS is "in the air" instead of 1/2)
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, BK = (SCHED == 4) ? 32 : 64;
+    constexpr int RP = 512 / BK;             // tile rows per 1-KiB LDS-DMA piece: 8 rows of 128 B or 16 rows of 64 B
+    constexpr int CA = BM / RP, CB = BN / RP;
     constexpr int AI = (CA + NW - 1) / NW, BI = (CB + NW - 1) / NW;
     const GemmArgs& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NST = (SCHED == 3) ? 3 : 2;      // LDS stages
+    constexpr int NST = (SCHED == 4) ? 4 : (SCHED == 3) ? 3 : 2;  // LDS stages
     half_t* sA = reinterpret_cast<half_t*>(smem);  // [NST][BM*BK]
     half_t* sB = sA + NST * BM * BK;                // [NST][BN*BK]
 
@@ -611,8 +614,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? q.a2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, q.w_bytes, 0x00020000);
 
-    const int lrow = lane >> 3;                          // row inside an 8-row chunk
-    const unsigned lsl = (unsigned)((lane & 7) ^ lrow);  // logical 16-byte slot this lane fetches (source-side swizzle)
+    // LDS-DMA lane geometry (the LDS image of a piece is lane-linear, so the swizzle lives on the SOURCE address):
+    //   BK 64: lane -> row lane/8, slot lane%8, fetches logical 16-byte chunk slot ^ row
+    //   BK 32: lane -> row lane/4, slot lane%4, fetches logical chunk (slot - 2*((row/4)&1)) & 3  (reader: slot =
+    //          (g + 2*((row/4)&1)) & 3 -- conflict-free for the ds_read_b128 lane groups over 64-byte rows)
+    const int lrow = (BK == 64) ? (lane >> 3) : (lane >> 2);
+    const unsigned lsl = (BK == 64) ? (unsigned)((lane & 7) ^ lrow) : (unsigned)(((lane & 3) - 2 * ((lrow >> 2) & 1)) & 3);
 
     // ---- A rows owned by this lane: chunk c = wave + NW*i ----
     int a_row[AI];   // LINEAR/TCONV: global row; CONV: image base pixel n*hin*win
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int c = wave + NW * i;
-        const int gm = m0 + 8 * c + lrow;
+        const int gm = m0 + RP * c + lrow;
         a_ok[i] = (c < CA) && (gm < Mi);
         if (MODE == MV_GEMM_LINEAR) {
             a_row[i] = gm;
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int c = wave + NW * j;
-        const int rr = 8 * c + lrow;  // LDS row of the B tile
+        const int rr = RP * c + lrow;  // LDS row of the B tile
         const int wnt = rr / (16 * TN);
         const int within = rr - wnt * (16 * TN);
         const int jt = within >> 4, r16 = within & 15;
@@ -721,14 +728,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             const __amdgpu_buffer_rsrc_t rCur = sec ? rA2 : rA;
             const unsigned vo = kcut ? kOOB : a_off[d];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rCur, (__attribute__((address_space(3))) void*)(sA + buf * (BM * BK) + c * (8 * BK)), 16, (int)vo, (int)soa, 0, 0);
+                rCur, (__attribute__((address_space(3))) void*)(sA + buf * (BM * BK) + c * (RP * BK)), 16, (int)vo, (int)soa, 0, 0);
         } else {
             const int j = d - AI;
             const int c = wave + NW * j;
             if ((CB % NW) != 0 && c >= CB) return;
             const unsigned vo = kcut ? kOOB : b_off[j];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rW, (__attribute__((address_space(3))) void*)(sB + buf * (BN * BK) + c * (8 * BK)), 16, (int)vo,
+                rW, (__attribute__((address_space(3))) void*)(sB + buf * (BN * BK) + c * (RP * BK)), 16, (int)vo,
                 (int)((unsigned)kt * (BK * 2u)), 0, 0);
         }
     };
@@ -741,46 +748,68 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int b_row0 = wn * 16 * TN + l15;
     const int swz = l15 & 7;
 
-    if constexpr (SCHED == 3) {
-        // Three-stage ring with COUNTED waits: two K tiles are in flight while one is multiplied, and nothing ever drains
+    if constexpr (SCHED >= 3) {
+        // NST-stage ring with COUNTED waits: NST-1 K tiles are in flight while one is multiplied, and nothing ever drains
         // the LDS-DMA queue inside the loop.  Per K step: this wave waits until its own pieces of tile kt have landed
-        // (s_waitcnt vmcnt(pieces of tile kt+1)), one raw s_barrier makes every wave's pieces visible and proves that all
-        // waves have finished reading the stage tile kt+2 is about to overwrite (it held tile kt-1), then the next
-        // pieces are issued and the MFMAs of tile kt run.  (__syncthreads() would add vmcnt(0) and serialise the ring.)
+        // (s_waitcnt vmcnt(pieces of the younger tiles)), one raw s_barrier makes every wave's pieces visible and proves
+        // that all waves have finished reading the stage the next issue overwrites (it held tile kt-1), then the pieces of
+        // tile kt+NST-1 are issued and the MFMAs of tile kt run.  (__syncthreads() would add vmcnt(0) and serialise the ring.)
         int pw = 0;  // LDS-DMA pieces this wave issues per K tile (wave-uniform)
 #pragma unroll
         for (int d = 0; d < AI; ++d) pw += ((CA % NW) != 0 && wave + NW * d >= CA) ? 0 : 1;
 #pragma unroll
         for (int d = 0; d < BI; ++d) pw += ((CB % NW) != 0 && wave + NW * d >= CB) ? 0 : 1;
-        prepare();
-        issue(0, 0);
-        if (nk > 1) {
-            prepare();
-            issue(1, 1);
+#pragma unroll
+        for (int t0 = 0; t0 < NST - 1; ++t0) {
+            if (t0 < nk) {
+                prepare();
+                issue(t0, t0);
+            }
         }
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) {
-                switch (pw) {  // vmcnt takes an immediate
-                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int younger = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight
+            if (younger > NST - 2) younger = NST - 2;
+            switch (younger * pw) {  // vmcnt takes an immediate
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // over-waiting is always safe
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 2 < nk) {
+            if (kt + NST - 1 < nk) {
                 prepare();
-                issue(cur == 0 ? 2 : cur - 1, kt + 2);  // (cur + 2) % 3
+                issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);  // (cur + NST - 1) % NST: the stage tile kt-1 just left
             }
-            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
-            cur = (cur == 2) ? 0 : cur + 1;
+            if constexpr (BK == 64) {
+                mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+            } else {
+                const half_t* cA = sA + cur * (BM * BK);
+                const half_t* cB = sB + cur * (BN * BK);
+                const int slot_off = ((g + 2 * ((l15 >> 2) & 1)) & 3) << 3;
+                half8v af[TM], wf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            cur = (cur == NST - 1) ? 0 : cur + 1;
         }
     } else {
         prepare();
@@ -1081,7 +1110,7 @@ int launch_mode3(const GemmArgs2& a, hipStream_t stream) {
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
-    constexpr int smem = (SCHED == 3 ? 3 : 2) * (BM + BN) * 64 * (int)sizeof(half_t);
+    constexpr int smem = (SCHED == 4 ? 4 * 32 : SCHED == 3 ? 3 * 64 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
     GemmArgs2 a = a0;
     a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
@@ -1121,6 +1150,10 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const long tiles_n = n160 ? g.N / 160 : (g.N + 127) / 128;
     const long tiles_m128 = (g.M + 127) / 128;
     const bool small = tiles_m128 * tiles_n < 512;
+    if (variant == 6 && !g.geglu) {  // experiment: BK 32, four-stage counted ring on the 4-wave tiles
+        if (n160) return small ? launch_cfg2s<MODE, 2, 5, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 5, 2, 2, 4>(a, stream);
+        return small ? launch_cfg2s<MODE, 2, 4, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 4, 2, 2, 4>(a, stream);
+    }
     if (n160) {
         // 8-wave 256x160 tiles on a three-stage counted-wait ring.  Measured (profiles/r01e_gemm_variant_ab.log): +20 % where
         // they form ONE round of blocks over the CUs (the M = 6656 level: 26 x 8 = 208 blocks, against 832 small
@@ -1151,7 +1184,7 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    MV_REQUIRE(v >= 0 && v <= 5, "mv_set_gemm_variant: variant %d not in [0, 5]", v);
+    MV_REQUIRE(v >= 0 && v <= 6, "mv_set_gemm_variant: variant %d not in [0, 6]", v);
     g_gemm_stage = v;
     return MV_OK;
 }
