@@ -72,16 +72,22 @@ def tensor_key(t: Optional[torch.Tensor]) -> tuple:
 
 
 class SourceCache:
-    """value derived from a source tensor, recomputed when the source changes identity or is modified in place"""
+    """values derived from source tensors (K/V projections of the prompt, the image prompt, the ReferenceNet features),
+    recomputed when a source changes identity or is modified in place.  Holds a few entries so that the two CFG halves
+    (different slices of one embedding tensor) do not evict each other when they are processed separately."""
 
-    __slots__ = ("src", "key", "value")
+    __slots__ = ("entries",)
+    MAX_ENTRIES = 4
 
     def __init__(self):
-        self.src, self.key, self.value = None, None, None
+        self.entries = {}  # key -> (src, value); the strong reference to src pins the storage, so a pointer is never recycled
 
     def get(self, src: torch.Tensor, build):
         key = tensor_key(src)
-        if self.key != key or self.src is None:
-            self.value = build(src)
-            self.src, self.key = src, key  # the strong reference pins the storage, so the pointer cannot be recycled
-        return self.value
+        hit = self.entries.get(key)
+        if hit is None:
+            if len(self.entries) >= self.MAX_ENTRIES:
+                self.entries.pop(next(iter(self.entries)))  # oldest
+            hit = (src, build(src))
+            self.entries[key] = hit
+        return hit[1]

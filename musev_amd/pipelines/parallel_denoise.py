@@ -67,6 +67,8 @@ class ParallelDenoiser:
         # so the host only issues the loop glue.  Falls back to eager launches when capture is unavailable.
         self.use_graphs = use_graphs and os.environ.get("MUSEV_NO_GRAPH", "0") != "1"  # env knob for per-kernel PMC profiling
         self._graphs: Dict[tuple, "_GraphedForward"] = {}
+        self.half_streams = os.environ.get("MUSEV_HALF_STREAMS", "0") == "1"  # experiment knob
+        self._side = {}
         self.scheduler = scheduler or DDIMScheduler()
         self.context_frames, self.context_overlap = context_frames, context_overlap
         self.context_stride, self.context_schedule = context_stride, context_schedule
@@ -178,9 +180,26 @@ class ParallelDenoiser:
         ehs = embeds[hs[0]:hs[-1] + 1] if len(hs) == 2 else embeds[hs[0]:hs[0] + 1]
         kw = {k: (self._slice_half(v, list(hs), halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()}
 
+        def one(inp, nb, e, k):
+            return self.unet.forward_rows(inp, nb, tw, h, w, t_dev, e, sample_index=sub_idx,
+                                          vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **k)
+
         def eager(inp):
-            return self.unet.forward_rows(inp, len(hs), tw, h, w, t_dev, ehs, sample_index=sub_idx,
-                                          vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **kw)
+            if not (self.half_streams and len(hs) == 2 and inp.is_cuda):
+                return one(inp, len(hs), ehs, kw)
+            # The CFG halves only meet in the loop glue: run them as two batch-1 forwards on two HIP streams, so the
+            # prologue / epilogue / tail phases of one half's kernels overlap the other half's MFMA phases.
+            rows = inp.shape[0] // 2
+            main = torch.cuda.current_stream()
+            side = self._side_stream(inp.device)
+            kws = [{k: (self._slice_half(v, [i], halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()} for i in hs]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1])
+            e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0])
+            main.wait_stream(side)
+            e1.record_stream(main)
+            return torch.cat([e0, e1], dim=0)
 
         if not (self.use_graphs and x.is_cuda and hasattr(torch.cuda, "CUDAGraph")):
             return eager(x)
@@ -191,10 +210,20 @@ class ParallelDenoiser:
         if gf is None:
             if len(self._graphs) >= 8:  # stale captures (other prompts / sizes) would pin their activation pools
                 self._graphs.clear()
+            if self.half_streams and len(hs) == 2:
+                # fill the shared packed-weight caches on ONE stream before two streams start using them
+                one(x, len(hs), ehs, kw)
+                torch.cuda.synchronize()
             gf = _GraphedForward(eager, x)
             self._graphs[key] = gf
             return gf.first_result
         return gf(x)
+
+    def _side_stream(self, dev):
+        key = str(dev)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
 
     @staticmethod
     def _slice_half(v, hs: List[int], halves: int):
