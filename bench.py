@@ -319,7 +319,8 @@ def main():
     if not args.no_roofline:
         # instrumented repeat of the same K steps: HIP events around every implicit-GEMM launch on the launch stream
         ops.GEMM_PROFILE = []
-        den.use_graphs = False  # per-launch events need eager launches (the timed region above replays hipGraphs)
+        den.use_graphs = False   # per-launch events need eager launches (the timed region above replays hipGraphs)
+        den.half_streams = False  # ... issued back to back on ONE stream, so that a launch's duration is its own
         sync_all()
         t0 = time.perf_counter()
         run_steps(min(args.steps, 4))
