@@ -1150,6 +1150,10 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const long tiles_n = n160 ? g.N / 160 : (g.N + 127) / 128;
     const long tiles_m128 = (g.M + 127) / 128;
     const bool small = tiles_m128 * tiles_n < 512;
+    if (variant == 7 && !g.geglu && (g.N % 320) == 0 && (g.M + 255) / 256 * (g.N / 320) >= 200) {
+        // experiment: 256x320 block tile, 8 waves as 2(M) x 4(N), wave tile 128x80 -- twice the flops per LDS-DMA byte
+        return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
+    }
     if (variant == 6 && !g.geglu) {  // experiment: BK 32, four-stage counted ring on the 4-wave tiles
         if (n160) return small ? launch_cfg2s<MODE, 2, 5, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 5, 2, 2, 4>(a, stream);
         return small ? launch_cfg2s<MODE, 2, 4, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 4, 2, 2, 4>(a, stream);
@@ -1184,7 +1188,7 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    MV_REQUIRE(v >= 0 && v <= 6, "mv_set_gemm_variant: variant %d not in [0, 6]", v);
+    MV_REQUIRE(v >= 0 && v <= 7, "mv_set_gemm_variant: variant %d not in [0, 7]", v);
     g_gemm_stage = v;
     return MV_OK;
 }
