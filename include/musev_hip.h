@@ -75,7 +75,8 @@ typedef struct mv_gemm_desc {
 
 int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
 /* tuning knob (A/B runs): 0 = v1 register-staged copies, 1 = v1 LDS-DMA, 2 = v2 buffer-descriptor LDS-DMA (default),
- * 3 = v2 + 8-wave 256x160 tiles, 4 = persistent tile loop, 5 = 8-wave tiles on a three-stage counted-wait LDS ring */
+ * 3 = v2 + 8-wave 256x160 tiles, 4 = persistent tile loop, 5 = 8-wave tiles on a three-stage counted-wait LDS ring,
+ * 6 = BK-32 four-stage ring, 7 = 256x320 tiles wherever they fit, 8 = 2 + 256x256 tiles for the GEGLU GEMM */
 int mv_set_gemm_variant(int variant);
 
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------

@@ -385,7 +385,8 @@ int launch_cfg_s(const GemmArgs& a0, hipStream_t stream) {
 }
 
 int g_gemm_stage = 2;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles,
-                       // 4 persistent v3 kernel, 5 v2 + 8-wave tiles on a 3-stage counted-wait ring
+                       // 4 persistent v3 kernel, 5 v2 + 8-wave tiles on a 3-stage counted-wait ring, 6 BK-32 4-stage ring,
+                       // 7 256x320 tiles wherever they fit, 8 = 2 + 256x256 tiles for the GEGLU GEMM
 
 template <int MODE, int TM, int TN>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
@@ -1142,6 +1143,8 @@ template <int MODE>
 int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const GemmArgs& g = a.g;
     if (g.geglu) {
+        // 256x256 tile (8 waves as 2 x 4, wave tile 128x64): variant 8 experiment / candidate default for the big grids
+        if (variant == 8 && (g.N % 256) == 0 && (g.M + 255) / 256 * (g.N / 256) >= 200) return launch_cfg2s<MODE, 8, 4, 2, 4, 0>(a, stream);
         if (variant == 5 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 200) return launch_cfg2s<MODE, 4, 4, 4, 2, 3>(a, stream);
         if (variant == 3 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 512) return launch_cfg2<MODE, 4, 4, 4, 2>(a, stream);
         return launch_cfg2<MODE, 4, 4, 2, 2>(a, stream);
@@ -1150,10 +1153,13 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const long tiles_n = n160 ? g.N / 160 : (g.N + 127) / 128;
     const long tiles_m128 = (g.M + 127) / 128;
     const bool small = tiles_m128 * tiles_n < 512;
-    if (variant == 7 && !g.geglu && (g.N % 320) == 0 && (g.M + 255) / 256 * (g.N / 320) >= 200) {
-        // experiment: 256x320 block tile, 8 waves as 2(M) x 4(N), wave tile 128x80 -- twice the flops per LDS-DMA byte
-        return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
-    }
+    // 256x320 block tile, 8 waves as 2(M) x 4(N), wave tile 128x80: twice the flops per LDS-DMA byte of the 128x160 tile and
+    // 0.33 instead of 0.45 fragment reads per MFMA.  One block per CU, so it needs a K loop long enough to amortise its
+    // un-overlapped prologue / epilogue: measured (profiles/r01l_gemm_variant_ab.log) +10..+20 % on the conv / temporal-conv
+    // / K >= 640 linear shapes of levels 0-1, -20 % on the N = 320, K = 320 projections.
+    const bool big320 = !g.geglu && (g.N % 320) == 0 && (g.M + 255) / 256 * (g.N / 320) >= 200;
+    if (variant == 7 && big320) return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
+    if ((variant == 2 || variant == 8) && big320 && (g.K >= 640 || g.N >= 960)) return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
     if (variant == 6 && !g.geglu) {  // experiment: BK 32, four-stage counted ring on the 4-wave tiles
         if (n160) return small ? launch_cfg2s<MODE, 2, 5, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 5, 2, 2, 4>(a, stream);
         return small ? launch_cfg2s<MODE, 2, 4, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 4, 2, 2, 4>(a, stream);
@@ -1165,7 +1171,7 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
         const long blocks8 = (g.M + 255) / 256 * tiles_n;
         const long cus = mv_num_cus();
         if (variant == 5 && blocks8 >= 200) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
-        if (variant == 2 && blocks8 * 5 >= cus * 4 && blocks8 <= cus) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
+        if ((variant == 2 || variant == 8) && blocks8 * 5 >= cus * 4 && blocks8 <= cus) return launch_cfg2s<MODE, 4, 5, 4, 2, 3>(a, stream);
         if (variant == 3 && (g.M + 255) / 256 * tiles_n >= 512) return launch_cfg2<MODE, 4, 5, 4, 2>(a, stream);
         return small ? launch_cfg2<MODE, 2, 5, 2, 2>(a, stream) : launch_cfg2<MODE, 4, 5, 2, 2>(a, stream);
     }
@@ -1188,7 +1194,7 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int mv_set_gemm_variant(int v) {
-    MV_REQUIRE(v >= 0 && v <= 7, "mv_set_gemm_variant: variant %d not in [0, 7]", v);
+    MV_REQUIRE(v >= 0 && v <= 8, "mv_set_gemm_variant: variant %d not in [0, 8]", v);
     g_gemm_stage = v;
     return MV_OK;
 }
