@@ -1143,8 +1143,10 @@ template <int MODE>
 int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const GemmArgs& g = a.g;
     if (g.geglu) {
-        // 256x256 tile (8 waves as 2 x 4, wave tile 128x64): variant 8 experiment / candidate default for the big grids
-        if (variant == 8 && (g.N % 256) == 0 && (g.M + 255) / 256 * (g.N / 256) >= 200) return launch_cfg2s<MODE, 8, 4, 2, 4, 0>(a, stream);
+        // 256x256 tile (8 waves as 2 x 4, wave tile 128x64) where it still gives every CU a block: +5..+14 % on the FF1
+        // projections (profiles/r01m_gemm_variant_ab.log); variant 9 = the 128x128 tile everywhere (the A/B baseline)
+        if ((variant == 2 || variant == 8) && (g.N % 256) == 0 && (g.M + 255) / 256 * (g.N / 256) >= 200)
+            return launch_cfg2s<MODE, 8, 4, 2, 4, 0>(a, stream);
         if (variant == 5 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 200) return launch_cfg2s<MODE, 4, 4, 4, 2, 3>(a, stream);
         if (variant == 3 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 512) return launch_cfg2<MODE, 4, 4, 4, 2>(a, stream);
         return launch_cfg2<MODE, 4, 4, 2, 2>(a, stream);

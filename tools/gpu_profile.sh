@@ -17,7 +17,7 @@ fi
 cd /tmp
 # per-kernel durations are profiled on ONE stream (MUSEV_HALF_STREAMS=0), like bench.py's own instrumented roofline pass
 ( MUSEV_HALF_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -3 ) > $OUT/${TAG}_rocprof.log
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do
   ( MUSEV_NO_GRAPH=1 MUSEV_HALF_STREAMS=0 timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -3 ) > $OUT/${TAG}_pmc_$c.log
 done
 cd $ROOT
