@@ -1144,8 +1144,8 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const GemmArgs& g = a.g;
     if (g.geglu) {
         // 256x256 tile (8 waves as 2 x 4, wave tile 128x64) where it still gives every CU a block: +5..+14 % on the FF1
-        // projections (profiles/r01m_gemm_variant_ab.log); variant 9 = the 128x128 tile everywhere (the A/B baseline)
-        if ((variant == 2 || variant == 8) && (g.N % 256) == 0 && (g.M + 255) / 256 * (g.N / 256) >= 200)
+        // projections (profiles/r01m_gemm_variant_ab.log); opt-in (variant 8), see the note on the 256x320 tile below
+        if (variant == 8 && (g.N % 256) == 0 && (g.M + 255) / 256 * (g.N / 256) >= 200)
             return launch_cfg2s<MODE, 8, 4, 2, 4, 0>(a, stream);
         if (variant == 5 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 200) return launch_cfg2s<MODE, 4, 4, 4, 2, 3>(a, stream);
         if (variant == 3 && (g.M + 255) / 256 * ((g.N + 127) / 128) >= 512) return launch_cfg2<MODE, 4, 4, 4, 2>(a, stream);
@@ -1161,7 +1161,10 @@ int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     // / K >= 640 linear shapes of levels 0-1, -20 % on the N = 320, K = 320 projections.
     const bool big320 = !g.geglu && (g.N % 320) == 0 && (g.M + 255) / 256 * (g.N / 320) >= 200;
     if (variant == 7 && big320) return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
-    if ((variant == 2 || variant == 8) && big320 && (g.K >= 640 || g.N >= 960)) return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
+    // NOT in the default variant yet: parity and the micro-benchmarks are green (r01l / r01m), but the only whole-model run
+    // with these tiles (bench.py under hipGraph replay + two streams, r01n) did not finish inside the GPU budget that was
+    // left, so variant 2 stays exactly what r01k verified and variant 8 = 2 + these tiles (MUSEV_GEMM_VARIANT=8).
+    if (variant == 8 && big320 && (g.K >= 640 || g.N >= 960)) return launch_cfg2s<MODE, 8, 5, 2, 4, 0>(a, stream);
     if (variant == 6 && !g.geglu) {  // experiment: BK 32, four-stage counted ring on the 4-wave tiles
         if (n160) return small ? launch_cfg2s<MODE, 2, 5, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 5, 2, 2, 4>(a, stream);
         return small ? launch_cfg2s<MODE, 2, 4, 2, 2, 4>(a, stream) : launch_cfg2s<MODE, 4, 4, 2, 2, 4>(a, stream);
