@@ -268,7 +268,8 @@ class _GraphedForward:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: other host threads (the RCCL watchdog of torch.distributed polls events) must not abort a capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.static_out = fn(self.static_in)
             self.graph = g
         except Exception as ex:  # noqa: BLE001 -- capture is an optimisation; eager launches remain correct
