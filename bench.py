@@ -164,18 +164,15 @@ def cpu_baseline(flavour: str, full_flops: float, frames: int, threads: int, sta
         kw["mid_block_refer_emb"] = torch.randn(1, mid[0], 1, mid[1], mid[2], generator=g).repeat(2, 1, 1, 1, 1)
         kw["vision_clip_emb"] = torch.randn(2, 4, 768, generator=g)
         kw["ip_adapter_scale"] = 1.0
-    # torch's intra-op pool scales badly past a few dozen threads on these small fp32 ops: time the sample at a few
-    # thread counts (bounded by the cores present) and report the fastest, with the thread count it used
-    dt, best = None, threads
-    for th in sorted({min(threads, 16), min(threads, 64), threads}):
-        torch.set_num_threads(th)
-        t0 = time.time()
-        with torch.no_grad():
-            unet3d.unet3d_forward(sd, cfg, x, torch.tensor(951), ehs, **kw)
-        d = time.time() - t0
-        if dt is None or d < dt:
-            dt, best = d, th
-    threads = best
+    # torch's intra-op pool scales badly past a few dozen threads on these small fp32 ops (measured on the 256-core host of
+    # the GPU box: 16 threads 14.7 s, 64 and 256 threads several times slower and wildly variable -- one run spent minutes
+    # there), so the sample runs ONCE at min(cores, 16) threads; `cores` in the JSON is that thread count
+    threads = min(threads, 16)
+    torch.set_num_threads(threads)
+    t0 = time.time()
+    with torch.no_grad():
+        unet3d.unet3d_forward(sd, cfg, x, torch.tensor(951), ehs, **kw)
+    dt = time.time() - t0
     sample_flops = unet_flops(size, size, win_frames, 2, "musev" if flavour == "musev" else "musev_referencenet")
     t_full = dt * full_flops / sample_flops
     return {
@@ -359,13 +356,21 @@ def main():
                            "frac_of_mfma_peak": per_rank_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
         }
 
-    cpu = None
+    cpu, cpu_timed_out = None, False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the baseline is a report, never a reason to lose the GPU number: it runs under a watchdog (a host with a
+        # misbehaving thread pool once spent minutes in it) and any failure is recorded instead of raised
+        import concurrent.futures
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        fut = pool.submit(cpu_baseline, flavour, unet_flops(args.size, args.size, win + n_cond, 2, flavour, n_vis=n_cond), T,
+                          os.cpu_count() or 1, unet.state_dict())
         try:
-            cpu = cpu_baseline(flavour, unet_flops(args.size, args.size, win + n_cond, 2, flavour, n_vis=n_cond), T,
-                               threads=os.cpu_count() or 1, state_dict=unet.state_dict())
-        except Exception as ex:  # noqa: BLE001 -- the baseline is a report, never a reason to lose the GPU number
+            cpu = fut.result(timeout=180)
+        except concurrent.futures.TimeoutError:
+            cpu, cpu_timed_out = {"error": "cpu_baseline sample exceeded its 180 s watchdog"}, True
+        except Exception as ex:  # noqa: BLE001
             cpu = {"error": repr(ex)}
+        pool.shutdown(wait=False)
 
     if rank == 0:
         line = {
@@ -384,6 +389,9 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if cpu_timed_out:
+        sys.stdout.flush()
+        os._exit(0)  # the abandoned baseline thread would otherwise keep the process alive
 
 
 if __name__ == "__main__":
