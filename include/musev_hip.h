@@ -201,6 +201,13 @@ int mv_window_scatter_add(const void* eps_win, int32_t eps_is_f32, const int32_t
 int mv_cfg_ddim_step(float* latents, const float* eps_acc, const float* counter, int32_t c, int32_t t_total,
                      int32_t hw, int32_t halves, float guidance, float alpha_t, float alpha_prev, void* stream);
 
+/* mv_cfg_affine_step: eps = acc / counter; CFG; x <- cx * x + ce * eps (in place).  Euler-discrete with s_churn = 0:
+ *   cx = 1, ce = sigma_{i+1} - sigma_i.
+ * replaces: pipeline_controlnet.py:2079,2101-2117 + musev/schedulers/scheduling_euler_discrete.py:110-167
+ *   (pred_original_sample = x - sigma*eps; derivative = (x - x0)/sigma = eps; prev = x + derivative*(sigma_next - sigma)). */
+int mv_cfg_affine_step(float* latents, const float* eps_acc, const float* counter, int32_t c, int32_t t_total, int32_t hw,
+                       int32_t halves, float guidance, float cx, float ce, void* stream);
+
 /* ---- weight packing -------------------------------------------------------------------------------------
  * conv weight [O][I][kh][kw] (torch layout, fp16 or fp32) -> [O][kh][kw][I] fp16;  Conv3d [O][I][3][1][1] -> [O][3][I]
  * replaces: nothing in the reference (torch consumes its native layout); lets real checkpoints (state_dict keys

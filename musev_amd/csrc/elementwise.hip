@@ -303,6 +303,22 @@ __global__ void cfg_ddim_step_kernel(float* latents, const float* eps_acc, const
     }
 }
 
+// generic one-step scheduler update after CFG: x <- cx * x + ce * eps   (Euler-discrete: cx = 1, ce = sigma_next - sigma)
+__global__ void cfg_affine_step_kernel(float* latents, const float* eps_acc, const float* counter, int c, int t_total, int hw,
+                                       int halves, float guidance, float cx, float ce) {
+    const long n = (long)c * t_total * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tf = (int)((i / hw) % t_total);
+        const float inv = 1.0f / counter[tf];
+        float eps = eps_acc[i] * inv;
+        if (halves == 2) {
+            const float et = eps_acc[n + i] * inv;
+            eps = eps + guidance * (et - eps);
+        }
+        latents[i] = cx * latents[i] + ce * eps;
+    }
+}
+
 // conv weight repack: [O][I][taps] -> [O][taps][I] fp16
 template <typename SrcT>
 __global__ void pack_conv_weight_kernel(const SrcT* w, half_t* out, int o, int ic, int taps) {
@@ -465,6 +481,16 @@ extern "C" int mv_cfg_ddim_step(float* latents, const float* eps_acc, const floa
                        eps_acc, counter, c, t_total, hw, halves, guidance, sqrtf(alpha_t), sqrtf(1.f - alpha_t), sqrtf(alpha_prev),
                        sqrtf(1.f - alpha_prev));
     MV_CHECK_LAUNCH("mv_cfg_ddim_step");
+    return MV_OK;
+}
+
+extern "C" int mv_cfg_affine_step(float* latents, const float* eps_acc, const float* counter, int32_t c, int32_t t_total,
+                                  int32_t hw, int32_t halves, float guidance, float cx, float ce, void* stream) {
+    MV_REQUIRE(latents && eps_acc && counter && (halves == 1 || halves == 2) && c > 0 && t_total > 0 && hw > 0,
+               "mv_cfg_affine_step: bad args");
+    hipLaunchKernelGGL(cfg_affine_step_kernel, dim3(grid_for((long)c * t_total * hw)), dim3(kBlock), 0, (hipStream_t)stream, latents,
+                       eps_acc, counter, c, t_total, hw, halves, guidance, cx, ce);
+    MV_CHECK_LAUNCH("mv_cfg_affine_step");
     return MV_OK;
 }
 

@@ -22,7 +22,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
 __all__ = [
     "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
     "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
-    "window_gather", "window_scatter_add", "cfg_ddim_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
+    "window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
 
 
@@ -422,6 +422,14 @@ def cfg_ddim_step(latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.T
     halves, c, t_total, hw = eps_acc.shape
     check(_lib.load().mv_cfg_ddim_step(latents.data_ptr(), eps_acc.data_ptr(), counter.data_ptr(), c, t_total, hw, halves,
                                        float(guidance), float(alpha_t), float(alpha_prev), _stream()), "mv_cfg_ddim_step")
+
+
+def cfg_affine_step(latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.Tensor, guidance: float, cx: float,
+                    ce: float) -> None:
+    """latents <- cx * latents + ce * CFG(eps_acc / counter), in place (Euler-discrete: cx = 1, ce = sigma_next - sigma)."""
+    halves, c, t_total, hw = eps_acc.shape
+    check(_lib.load().mv_cfg_affine_step(latents.data_ptr(), eps_acc.data_ptr(), counter.data_ptr(), c, t_total, hw, halves,
+                                         float(guidance), float(cx), float(ce), _stream()), "mv_cfg_affine_step")
 
 
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:

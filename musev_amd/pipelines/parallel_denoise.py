@@ -23,7 +23,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .. import ops
-from ..schedulers.scheduling_ddim import DDIMScheduler
+from ..schedulers.scheduling_ddim import DDIMScheduler  # default; EulerDiscreteScheduler offers the same loop interface
 from .context import prepare_global_context
 
 
@@ -115,7 +115,7 @@ class ParallelDenoiser:
 
         sched = self.scheduler
         sched.set_timesteps(num_inference_steps)
-        timesteps = [int(t) for t in sched.timesteps.tolist()]
+        timesteps = [float(t) for t in sched.timesteps.tolist()]  # integral for DDIM, fractional for Euler ("linspace")
         wins = self.windows(T, num_inference_steps)
         win_len = len(wins[0])
         if any(len(wd) != win_len for wd in wins):
@@ -150,9 +150,13 @@ class ParallelDenoiser:
                 break
             eps_acc.zero_()
             t_dev.fill_(float(t))
+            # scheduler.scale_model_input (:1911): identity for DDIM, 1/sqrt(sigma^2+1) for Euler; the vision-condition
+            # latents are concatenated AFTER the scaling in the reference (:1922-1946) and stay unscaled
+            in_scale = sched.input_scale(step)
+            lat_in = lat if in_scale == 1.0 else lat * in_scale
             slot = 0
             for wi, hs in my_groups:
-                x = ops.window_gather(lat, cond, idx_dev[wi], n_cond, len(hs))  # scale_model_input is the identity (DDIM)
+                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs))
                 eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx, vis_idx, motion_speed, unet_kwargs)
                 if world == 1:
                     for k, hf in enumerate(hs):
@@ -166,8 +170,7 @@ class ParallelDenoiser:
                 for r in range(world):  # fixed accumulation order on every rank -> bit-identical replicas
                     for k, u in enumerate(shards[r]):
                         ops.window_scatter_add(recv[r * max_units + k], idx_dev[u.window], 0, 1, u.half, eps_acc, counter, False)
-            a_t, a_prev = sched.alphas_for(t)
-            ops.cfg_ddim_step(lat, eps_acc, counter, float(guidance_scale), a_t, a_prev)
+            sched.loop_update(lat, eps_acc, counter, float(guidance_scale), step, t)
             if callback is not None:
                 callback(step, t, lat)
 

@@ -115,12 +115,57 @@ class DDIMOracle:
         return a_prev ** 0.5 * x0 + direction                       # :262-264
 
 
+class EulerOracle:
+    """musev/schedulers/scheduling_euler_discrete.py:47-167 (the step override) on diffusers' EulerDiscreteScheduler base
+    (un-vendored; set_timesteps / sigmas / scale_model_input / init_noise_sigma restated from upstream v0.24 -- unpinned).
+    s_churn = 0 as the reference pipeline calls it: gamma = 0, the drawn noise never enters the sample."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, timestep_spacing="linspace", steps_offset=0):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.train_sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        self.num_train_timesteps, self.timestep_spacing, self.steps_offset = num_train_timesteps, timestep_spacing, steps_offset
+        self.sigmas = None
+        self.timesteps = None
+
+    def set_timesteps(self, n: int):
+        N = self.num_train_timesteps
+        if self.timestep_spacing == "linspace":
+            ts = np.linspace(0, N - 1, n, dtype=np.float32)[::-1].copy()
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, n) * (N // n)).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        else:
+            ts = (np.arange(N, 0, -N / n)).round().copy().astype(np.float32) - 1
+        sig = np.interp(ts, np.arange(0, len(self.train_sigmas)), self.train_sigmas)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+
+    @property
+    def init_noise_sigma(self):
+        m = float(self.sigmas.max())
+        return m if self.timestep_spacing in ("linspace", "trailing") else (m ** 2 + 1) ** 0.5
+
+    def scale_model_input(self, sample: Tensor, i: int) -> Tensor:
+        sigma = self.sigmas[i]
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output: Tensor, i: int, sample: Tensor) -> Tensor:
+        """scheduling_euler_discrete.py:110-167 with gamma = 0, epsilon prediction."""
+        sigma = self.sigmas[i]
+        sigma_hat = sigma * (0.0 + 1)                       # :133
+        pred_original_sample = sample - sigma_hat * model_output   # :146-147
+        derivative = (sample - pred_original_sample) / sigma_hat   # :158
+        dt = self.sigmas[i + 1] - sigma_hat                        # :160
+        return sample + derivative * dt                            # :162
+
+
 # ---- the loop --------------------------------------------------------------------------------------------
 def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds: Tensor, *, num_inference_steps: int,
                  guidance_scale: float, condition_latents: Optional[Tensor] = None, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
                  context_batch_size: int = 1, motion_speed: float = 8.0, unet_kwargs: Optional[dict] = None,
-                 record: Optional[list] = None, max_steps: Optional[int] = None) -> Tensor:
+                 record: Optional[list] = None, max_steps: Optional[int] = None, scheduler: str = "ddim",
+                 scheduler_kwargs: Optional[dict] = None) -> Tensor:
     """pipeline_controlnet.py:1832-2156.  ``max_steps`` (test helper, not in the reference): stop after the first
     max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
@@ -128,7 +173,8 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
     Returns the final latents with the condition frames re-inserted in front (:2149-2156)."""
     do_cfg = guidance_scale > 1.0
     unet_kwargs = unet_kwargs or {}
-    sched = DDIMOracle()
+    euler = scheduler == "euler"
+    sched = EulerOracle(**(scheduler_kwargs or {})) if euler else DDIMOracle()
     sched.set_timesteps(num_inference_steps)
     n_cond = 0 if condition_latents is None else condition_latents.shape[2]
     vis_idx = torch.arange(n_cond, dtype=torch.long) if n_cond else None      # vision_condition_latent_index
@@ -145,7 +191,8 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
         for context in global_context:
             latents_c = torch.cat([latents[:, :, c] for c in context])                       # :1902
             x = latents_c.repeat(2 if do_cfg else 1, 1, 1, 1, 1)                              # :1908-1910
-            # scale_model_input is the identity for DDIM (:1911)
+            if euler:
+                x = sched.scale_model_input(x, i)                                             # :1911 (identity for DDIM)
             sub_idx = None
             if latent_index is not None:
                 win = len(context[0])
@@ -169,7 +216,7 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
             noise_pred = u + gscales[i] * (tx - u)                                            # :2101-2105
         if record is not None:
             record.append(noise_pred.clone())
-        latents = sched.step(noise_pred, int(t), latents)                                     # :2112-2117
+        latents = sched.step(noise_pred, i if euler else int(t), latents)                     # :2112-2117
     if condition_latents is not None:
         out = torch.zeros((latents.shape[0], latents.shape[1], n_cond + T, *latents.shape[3:]), dtype=latents.dtype)
         out.index_copy_(2, vis_idx, condition_latents)

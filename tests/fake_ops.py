@@ -32,6 +32,12 @@ def cfg_ddim_step(latents, eps_acc, counter, guidance, a_t, a_prev):
     latents.copy_(math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * e)
 
 
+def cfg_affine_step(latents, eps_acc, counter, guidance, cx, ce):
+    eps = eps_acc / counter[None, None, :, None]
+    e = eps[0] + guidance * (eps[1] - eps[0]) if eps.shape[0] == 2 else eps[0]
+    latents.copy_(cx * latents + ce * e)
+
+
 class FakeUNet:
     """eps = tanh(0.5 x) * (1 + 0.1 * mean(text)) + 0.01 * (timestep / 1000) + 0.05 * frame_position -- depends on the
     input frames, the CFG half's prompt, the timestep and the window-local frame position, like the real network."""

@@ -13,6 +13,7 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
                                 the oracle's seeded state dict, loaded with strict=True -> the key/shape inventory of
                                 oracle.unet3d.param_shapes is checked against the reference constructor as well.
   * reference_ddim.npz          musev/schedulers/scheduling_ddim.py DDIMScheduler.step (eta = 0, epsilon)
+  * reference_euler.npz         musev/schedulers/scheduling_euler_discrete.py EulerDiscreteScheduler.step (s_churn = 0)
   * reference_datautil.npz      musev/data/data_util.py index helpers used by the loop
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
@@ -104,6 +105,40 @@ def gen_ddim():
     print("ddim:", s.timesteps.tolist()[:3], "...")
 
 
+def gen_euler():
+    """musev/schedulers/scheduling_euler_discrete.py (the reference's step override; base class = refshim restatement of
+    upstream diffusers): 20-step schedules in the three spacings, four consecutive steps each, both noise types (the drawn
+    noise must not enter the sample at s_churn = 0)."""
+    import types
+    import musev
+    pkg = types.ModuleType("musev.schedulers")
+    pkg.__path__ = [os.path.join(os.path.dirname(musev.__file__), "schedulers")]
+    sys.modules["musev.schedulers"] = pkg
+    from musev.schedulers.scheduling_euler_discrete import EulerDiscreteScheduler
+    outs = {}
+    for spacing, offset in (("linspace", 0), ("leading", 1), ("trailing", 0)):
+        s = EulerDiscreteScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                   timestep_spacing=spacing, steps_offset=offset)
+        s.set_timesteps(20)
+        g = torch.Generator().manual_seed(79)
+        x = torch.randn(1, 4, 6, 8, 8, generator=g) * float(s.init_noise_sigma)
+        outs[f"{spacing}_timesteps"] = s.timesteps.numpy()
+        outs[f"{spacing}_sigmas"] = s.sigmas.numpy()
+        outs[f"{spacing}_init_noise_sigma"] = np.float32(float(s.init_noise_sigma))
+        outs[f"{spacing}_x0"] = x.numpy()
+        for i in range(4):
+            t = s.timesteps[i]
+            xin = s.scale_model_input(x, t)
+            outs[f"{spacing}_scaled{i}"] = xin.numpy()
+            eps = torch.randn(1, 4, 6, 8, 8, generator=g)
+            outs[f"{spacing}_eps{i}"] = eps.numpy()
+            x = s.step(eps, t, x, generator=torch.Generator().manual_seed(5 + i),
+                       noise_type="video_fusion" if i % 2 else "random").prev_sample
+            outs[f"{spacing}_x{i + 1}"] = x.numpy()
+    np.savez_compressed(os.path.join(HERE, "reference_euler.npz"), **outs)
+    print("euler: spacings linspace/leading/trailing, sigma_max", float(outs["linspace_sigmas"].max()))
+
+
 def gen_datautil():
     from musev.data import data_util as du
     g = torch.Generator().manual_seed(88)
@@ -123,5 +158,6 @@ def gen_datautil():
 if __name__ == "__main__":
     gen_context()
     gen_ddim()
+    gen_euler()
     gen_datautil()
     gen_unet()

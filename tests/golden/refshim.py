@@ -446,6 +446,89 @@ class DiffusersDDIMScheduler(SchedulerMixin, ConfigMixin):
         self.timesteps = torch.from_numpy(ts).to(device)
 
 
+@dataclass
+class EulerDiscreteSchedulerOutput(BaseOutput):
+    prev_sample: torch.FloatTensor = None
+    pred_original_sample: Optional[torch.FloatTensor] = None
+
+
+class DiffusersEulerDiscreteScheduler(SchedulerMixin, ConfigMixin):
+    """upstream diffusers v0.24 EulerDiscreteScheduler, the parts the reference's subclass relies on (constructor
+    tables, set_timesteps with linear interpolation, scale_model_input, init_noise_sigma, step-index bookkeeping)"""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                 prediction_type="epsilon", interpolation_type="linear", use_karras_sigmas=False, timestep_spacing="linspace",
+                 steps_offset=0):
+        if beta_schedule == "linear":
+            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(beta_schedule)
+        self.register_to_config(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                beta_schedule=beta_schedule, prediction_type=prediction_type, interpolation_type=interpolation_type,
+                                use_karras_sigmas=use_karras_sigmas, timestep_spacing=timestep_spacing, steps_offset=steps_offset)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sigmas = np.concatenate([sigmas[::-1], [0.0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sigmas)
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=float)[::-1].copy())
+        self.is_scale_input_called = False
+        self.use_karras_sigmas = use_karras_sigmas
+        self._step_index = None
+
+    @property
+    def init_noise_sigma(self):
+        max_sigma = max(self.sigmas) if isinstance(self.sigmas, list) else self.sigmas.max()
+        if self.config.timestep_spacing in ["linspace", "trailing"]:
+            return max_sigma
+        return (max_sigma ** 2 + 1) ** 0.5
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def _init_step_index(self, timestep):
+        if isinstance(timestep, torch.Tensor):
+            timestep = timestep.to(self.timesteps.device)
+        index_candidates = (self.timesteps == timestep).nonzero()
+        step_index = index_candidates[1] if len(index_candidates) > 1 else index_candidates[0]
+        self._step_index = step_index.item()
+
+    def scale_model_input(self, sample, timestep):
+        if self.step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self.step_index]
+        sample = sample / ((sigma ** 2 + 1) ** 0.5)
+        self.is_scale_input_called = True
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        n_train = self.config.num_train_timesteps
+        if self.config.timestep_spacing == "linspace":
+            timesteps = np.linspace(0, n_train - 1, num_inference_steps, dtype=np.float32)[::-1].copy()
+        elif self.config.timestep_spacing == "leading":
+            step_ratio = n_train // self.num_inference_steps
+            timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32)
+            timesteps += self.config.steps_offset
+        elif self.config.timestep_spacing == "trailing":
+            step_ratio = n_train / self.num_inference_steps
+            timesteps = (np.arange(n_train, 0, -step_ratio)).round().copy().astype(np.float32)
+            timesteps -= 1
+        else:
+            raise ValueError(self.config.timestep_spacing)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)
+        sigmas = np.concatenate([sigmas, [0.0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sigmas).to(device=device)
+        self.timesteps = torch.from_numpy(timesteps).to(device=device)
+        self._step_index = None
+
+
 def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)
 
@@ -530,6 +613,9 @@ def install(reference_root: str = "/root/reference") -> None:
     sdm = _mod("diffusers.schedulers.scheduling_ddim")
     sdm.DDIMScheduler, sdm.DDIMSchedulerOutput = DiffusersDDIMScheduler, DDIMSchedulerOutput
     sdm.betas_for_alpha_bar = sdm.rescale_zero_terminal_snr = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    sem = _mod("diffusers.schedulers.scheduling_euler_discrete")
+    sem.EulerDiscreteScheduler, sem.EulerDiscreteSchedulerOutput = DiffusersEulerDiscreteScheduler, EulerDiscreteSchedulerOutput
+    _mod("diffusers.utils.torch_utils").randn_tensor = randn_tensor
     xf = _mod("xformers")
     xo = _mod("xformers.ops")
     xo.memory_efficient_attention = memory_efficient_attention

@@ -369,7 +369,13 @@ def case_window_loop():
     x0 = (lat - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
     ref_lat = math.sqrt(a_p) * x0 + math.sqrt(1 - a_p) * eps
     r4 = _cmp("cfg_ddim_step", lat2, ref_lat, atol=1e-5, rtol=1e-5)
-    parts = (r1, r2, r3, r4)
+    # Euler-discrete step (scheduling_euler_discrete.py:146-162 with gamma = 0): x + (sigma_next - sigma) * eps
+    lat3 = lat.clone() * 14.6
+    sig, sig_next = 14.6146, 11.8927
+    ops.cfg_affine_step(lat3, acc, cnt2, gs, 1.0, sig_next - sig)
+    ref3 = lat * 14.6 + (sig_next - sig) * eps
+    r5 = _cmp("cfg_affine_step", lat3, ref3, atol=1e-4, rtol=1e-5)
+    parts = (r1, r2, r3, r4, r5)
     return {"name": "window loop glue", "ok": all(p["ok"] for p in parts), "max_abs_err": max(p["max_abs_err"] for p in parts),
             "parts": {p["name"]: p["ok"] for p in parts}}
 

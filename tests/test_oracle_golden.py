@@ -103,3 +103,38 @@ def test_datautil_semantics():
     assert np.array_equal(cat.numpy(), g["cat"])
     assert np.array_equal(cat.index_select(2, torch.arange(1, 6)).numpy(), g["sel"])
     assert np.array_equal(unet3d.align_repeat(torch.arange(6.0).reshape(2, 3), 8, dim=0).numpy(), g["rep"])
+
+
+def test_euler_matches_reference():
+    """oracle.pipeline.EulerOracle and the host tables of musev_amd.schedulers.EulerDiscreteScheduler against the reference's
+    own EulerDiscreteScheduler (step override musev/schedulers/scheduling_euler_discrete.py:47-167 executed on the refshim
+    restatement of the diffusers base): timesteps, sigmas, init_noise_sigma, scale_model_input and four steps per spacing."""
+    import os
+
+    import numpy as np
+    from oracle import pipeline as opipe
+    from musev_amd.schedulers import EulerDiscreteScheduler
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_euler.npz"))
+    for spacing, offset in (("linspace", 0), ("leading", 1), ("trailing", 0)):
+        o = opipe.EulerOracle(timestep_spacing=spacing, steps_offset=offset)
+        o.set_timesteps(20)
+        h = EulerDiscreteScheduler(timestep_spacing=spacing, steps_offset=offset)
+        h.set_timesteps(20)
+        for sched in (o, h):
+            assert np.array_equal(sched.timesteps.numpy(), gold[f"{spacing}_timesteps"])
+            assert np.array_equal(sched.sigmas.numpy(), gold[f"{spacing}_sigmas"])
+            assert abs(float(sched.init_noise_sigma) - float(gold[f"{spacing}_init_noise_sigma"])) < 1e-6
+        x = torch.from_numpy(gold[f"{spacing}_x0"])
+        for i in range(4):
+            want_in = torch.from_numpy(gold[f"{spacing}_scaled{i}"])
+            assert torch.allclose(o.scale_model_input(x, i), want_in, rtol=1e-6, atol=1e-6)
+            assert torch.allclose(x * h.input_scale(i), want_in, rtol=1e-6, atol=1e-6)
+            assert torch.allclose(h.scale_model_input(x, h.timesteps[i]), want_in, rtol=1e-6, atol=1e-6)
+            eps = torch.from_numpy(gold[f"{spacing}_eps{i}"])
+            x = o.step(eps, i, x)
+            want = torch.from_numpy(gold[f"{spacing}_x{i + 1}"])
+            assert torch.allclose(x, want, rtol=1e-5, atol=1e-5), (spacing, i, (x - want).abs().max())
+            # the affine form the fused kernel evaluates: x + (sigma_next - sigma) * eps
+            prev = torch.from_numpy(gold[f"{spacing}_x{i}"] if i else gold[f"{spacing}_x0"])
+            affine = prev + (float(h.sigmas[i + 1]) - float(h.sigmas[i])) * eps
+            assert torch.allclose(affine, want, rtol=1e-5, atol=2e-5), (spacing, i, (affine - want).abs().max())

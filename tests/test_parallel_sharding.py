@@ -32,14 +32,14 @@ def test_shard_units_invariants():
 
 def _patch(monkeypatch_like):
     from musev_amd import ops
-    for name in ("window_gather", "window_scatter_add", "cfg_ddim_step"):
+    for name in ("window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step"):
         monkeypatch_like(ops, name, getattr(fake_ops, name))
 
 
-def _run_loop(group=None):
+def _run_loop(group=None, scheduler=None):
     from musev_amd import ops
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
-    saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "cfg_ddim_step")}
+    saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step")}
     try:
         _patch(setattr)
         ParallelDenoiser._device_check = False
@@ -47,7 +47,7 @@ def _run_loop(group=None):
         lat = torch.randn(1, 4, 20, 4, 4, generator=g)
         cond = torch.randn(1, 4, 1, 4, 4, generator=g)
         prompt = torch.randn(2, 7, 16, generator=g)
-        den = ParallelDenoiser(fake_ops.FakeUNet(), context_frames=8, context_overlap=2)
+        den = ParallelDenoiser(fake_ops.FakeUNet(), scheduler=scheduler, context_frames=8, context_overlap=2)
         return den(lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond, group=group), (lat, cond, prompt)
     finally:
         ParallelDenoiser._device_check = True
@@ -80,3 +80,17 @@ def test_two_rank_gloo_matches_single_process_and_oracle():
     want = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
                               context_frames=8, context_overlap=2, motion_speed=8.0)
     assert (single - want).abs().max().item() < 5e-3  # fp16 window inputs / predictions vs the fp32 oracle loop
+
+
+def test_euler_loop_matches_oracle_loop():
+    """the loop with the Euler-discrete scheduler (scale_model_input on the gathered latents, fused affine step) against
+    the oracle loop restating pipeline_controlnet.py:1846-2147 + scheduling_euler_discrete.py, kernel test doubles on CPU"""
+    from musev_amd.schedulers import EulerDiscreteScheduler
+    from oracle import pipeline as opipe
+    got, (lat, cond, prompt) = _run_loop(None, scheduler=EulerDiscreteScheduler())
+    fake = fake_ops.FakeUNet()
+    want = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
+                              context_frames=8, context_overlap=2, motion_speed=8.0, scheduler="euler")
+    assert got.shape == want.shape
+    # Euler latents live in sigma-scaled space (sigma_max = 14.6): compare relative to that scale
+    assert (got - want).abs().max().item() < 5e-3 * 14.6
