@@ -1,0 +1,209 @@
+"""ReferenceNet2D on HIP kernels: reference musev/models/referencenet.py:640-1143 in the configuration
+``load_referencenet_by_name("musev_referencenet")`` builds (referencenet_loader.py:111-119: ``need_block_embs=True,
+need_self_attn_block_embs=False``) -- the SD-1.5 UNet2D encoder (conv_in, CrossAttnDownBlock2D x3, DownBlock2D,
+UNetMidBlock2DCrossAttn; no up path is constructed) returning the 12 down-path residuals and the mid-block output as
+``b c t h w`` feature maps: the ``down_block_refer_embs`` / ``mid_block_refer_emb`` inputs of UNet3DConditionModel.
+
+It is a composition of the modules of the UNet3D spatial path (ResnetBlock2D, Transformer2DModel with plain
+self-attention, Downsample2D), i.e. of kernels already parity-tested on the GPU; parameters live under the diffusers
+UNet2DConditionModel state-dict keys, so ``<checkpoint>/referencenet/diffusion_pytorch_model.*`` loads as in the reference.
+
+STATUS: oracle (oracle/referencenet.py) pinned against the reference's own ReferenceNet2D on CPU; this HIP module was
+written after the round's GPU budget was spent -- its GPU parity test (tests/test_referencenet_gpu.py) carries the marker
+``gpu_pending`` and has not run on a GPU yet."""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from .. import ops
+from .layers import Downsample2D, HipModule, ResnetBlock2D, TimestepEmbedding, w16
+from .runtime import Ctx, Geo
+from .transformer_2d import Transformer2DModel
+
+
+class _DownBlock2D(nn.Module):
+    """CrossAttnDownBlock2D / DownBlock2D (musev/models/unet_2d_blocks.py:812-925, 1006-1075): [resnet (, attention)] x L
+    (+ Downsample2D); every stage's output is a residual sample"""
+
+    def __init__(self, cin: int, cout: int, temb: int, layers: int, heads: int, cross_dim: int, cross_attn: bool,
+                 add_downsample: bool, eps: float, groups: int):
+        super().__init__()
+        self.has_cross_attention = cross_attn
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, eps=eps, groups=groups)
+                                      for i in range(layers)])
+        if cross_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(heads, cout // heads, in_channels=cout, num_layers=1,
+                                                                cross_attention_dim=cross_dim, norm_num_groups=groups)
+                                             for _ in range(layers)])
+            for a in self.attentions:
+                a.reference_only = False  # plain self-attention (no vision-condition frame in a 2-D network)
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_downsample else None
+
+    def hip_forward(self, x, ctx: Ctx, geo: Geo):
+        outs = []
+        for i, res in enumerate(self.resnets):
+            x = res.hip_forward(x, None, ctx, geo)
+            if self.has_cross_attention:
+                x = self.attentions[i].hip_forward(x, ctx, geo)
+            outs.append((x, geo))
+        if self.downsamplers is not None:
+            x = self.downsamplers[0].hip_forward(x, geo)
+            geo = geo.down()
+            outs.append((x, geo))
+        return x, geo, outs
+
+
+class _MidBlock2DCrossAttn(nn.Module):
+    """UNetMidBlock2DCrossAttn (unet_2d_blocks.py:646-760): resnet, attention, resnet"""
+
+    def __init__(self, c: int, temb: int, heads: int, cross_dim: int, eps: float, groups: int):
+        super().__init__()
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, c // heads, in_channels=c, num_layers=1,
+                                                            cross_attention_dim=cross_dim, norm_num_groups=groups)])
+        self.attentions[0].reference_only = False
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, eps=eps, groups=groups) for _ in range(2)])
+
+    def hip_forward(self, x, ctx: Ctx, geo: Geo):
+        x = self.resnets[0].hip_forward(x, None, ctx, geo)
+        x = self.attentions[0].hip_forward(x, ctx, geo)
+        return self.resnets[1].hip_forward(x, None, ctx, geo)
+
+
+class ReferenceNet2D(HipModule):
+    def __init__(self, in_channels: int = 4, block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280),
+                 down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                                      "DownBlock2D"),
+                 layers_per_block: int = 2, attention_head_dim: int = 8, cross_attention_dim: int = 768,
+                 norm_num_groups: int = 32, norm_eps: float = 1e-5, need_self_attn_block_embs: bool = False,
+                 need_block_embs: bool = True, **_unused):
+        super().__init__()
+        if need_self_attn_block_embs or not need_block_embs:
+            raise NotImplementedError("only the block-embedding mode of the shipped musev_referencenet flavour "
+                                      "(need_block_embs=True, need_self_attn_block_embs=False; referencenet_loader.py:111-119)")
+        if len(down_block_types) != len(block_out_channels):
+            raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
+        for bt in down_block_types:
+            if bt not in ("CrossAttnDownBlock2D", "DownBlock2D"):
+                raise ValueError(f"{bt} does not exist.")
+        ch = tuple(block_out_channels)
+        temb = ch[0] * 4
+        self.config = SimpleNamespace(in_channels=in_channels, block_out_channels=ch, down_block_types=tuple(down_block_types),
+                                      layers_per_block=layers_per_block, attention_head_dim=attention_head_dim,
+                                      cross_attention_dim=cross_attention_dim, norm_num_groups=norm_num_groups, norm_eps=norm_eps)
+        self.block_out_channels = ch
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb)
+        blocks, cin = [], ch[0]
+        for i, bt in enumerate(down_block_types):
+            blocks.append(_DownBlock2D(cin, ch[i], temb, layers_per_block, attention_head_dim, cross_attention_dim,
+                                       bt == "CrossAttnDownBlock2D", i != len(ch) - 1, norm_eps, norm_num_groups))
+            cin = ch[i]
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _MidBlock2DCrossAttn(ch[-1], temb, attention_head_dim, cross_attention_dim, norm_eps, norm_num_groups)
+        self.need_block_embs, self.need_self_attn_block_embs = True, False
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, num_frames: Optional[int] = None,
+                return_ndim: int = 5, **_unused):
+        """sample [(b t), c, h, w] (VAE latents of the reference images), encoder_hidden_states [(b t), L, D]
+        -> (down_block_refer_embs: 12 tensors, mid_block_refer_emb, None), each [b, c, t, h, w] (return_ndim 5,
+        referencenet.py:1018-1033) or [(b t), c, h, w] (4)."""
+        if not sample.is_cuda:
+            raise RuntimeError("musev_amd.ReferenceNet2D runs only on an MI355X (HIP) device; there is no CPU path")
+        if sample.ndim != 4:
+            raise ValueError(f"sample must be (b t) c h w, got ndim={sample.ndim}")
+        if return_ndim not in (4, 5):
+            raise ValueError(f"reshape_emb only support 4, 5 but given {return_ndim}")
+        n, _, h, w = sample.shape
+        t = num_frames if num_frames is not None else 1
+        if n % t != 0:
+            raise ValueError("sample batch is not a multiple of num_frames")
+        if encoder_hidden_states.ndim != 3 or encoder_hidden_states.shape[0] != n:
+            raise ValueError("encoder_hidden_states must be [(b t), L, D]")
+        dev = sample.device
+        geo = Geo(n, 1, h, w)  # every reference image is an independent "frame": b = (b t), t = 1
+        ch0 = self.block_out_channels[0]
+        tt = timestep.to(device=dev, dtype=torch.float32).reshape(-1) if torch.is_tensor(timestep) else \
+            torch.tensor([float(timestep)], dtype=torch.float32, device=dev)
+        tt = tt.expand(n).contiguous()
+        emb = self.time_embedding.hip_forward(ops.timestep_embedding(tt, ch0), final_silu=False)
+        text = encoder_hidden_states.to(dtype=torch.float16).reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
+        ctx = Ctx(temb_act=ops.silu(emb), femb_act=None, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=None,
+                  clip=None, clip_len=0, ip_scale=0.0, skip_temporal=True, text_src=encoder_hidden_states, clip_src=None)
+        x = sample.permute(0, 2, 3, 1).reshape(n * h * w, sample.shape[1]).to(torch.float16).contiguous()  # channels-last rows
+        w_in = self.packed("conv_in64", lambda: ops.pad_cols(ops.pack_conv_weight(self.conv_in.weight.detach()), 64))
+        x = ops.conv3x3_cin_small_gemm(x, w_in, w16(self.conv_in.bias), n, h, w)
+        res: List[Tuple[torch.Tensor, Geo]] = [(x, geo)]
+        for blk in self.down_blocks:
+            x, geo, outs = blk.hip_forward(x, ctx, geo)
+            res.extend(outs)
+        x = self.mid_block.hip_forward(x, ctx, geo)
+
+        def shape(rows: torch.Tensor, g: Geo) -> torch.Tensor:
+            # rows are ((b t), y, x) x C; as [b, t, ...] the layout kernel returns b c t h w directly
+            out = ops.bthwc_to_bcthw(rows, n // t, t, g.h, g.w, dtype=torch.float16)
+            return out if return_ndim == 5 else out.permute(0, 2, 1, 3, 4).reshape(n, -1, g.h, g.w)
+
+        return [shape(r, g) for r, g in res], shape(x, geo), None
+
+
+def load_referencenet(sd_referencenet_model: Union[str, nn.Module, dict, None], sd_model=None,
+                      need_self_attn_block_embs: bool = False, need_block_embs: bool = True, dtype: torch.dtype = torch.float16,
+                      cross_attention_dim: int = 768, subfolder: str = "unet", strict: bool = True, **config_overrides) -> nn.Module:
+    """reference musev/models/referencenet_loader.py:33-83"""
+    kwargs = dict(cross_attention_dim=cross_attention_dim, need_self_attn_block_embs=need_self_attn_block_embs,
+                  need_block_embs=need_block_embs)
+    state = None
+    if isinstance(sd_referencenet_model, str):
+        d = os.path.join(sd_referencenet_model, subfolder)
+        d = d if os.path.isdir(d) else sd_referencenet_model
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = json.load(f)
+        for k in ("in_channels", "block_out_channels", "down_block_types", "layers_per_block", "attention_head_dim",
+                  "norm_num_groups", "norm_eps"):
+            if k in cfg:
+                kwargs[k] = tuple(cfg[k]) if isinstance(cfg[k], list) else cfg[k]
+        from .unet_loader import _read_state
+        state = _read_state(d)
+    elif isinstance(sd_referencenet_model, nn.Module):
+        state = sd_referencenet_model.state_dict()
+    elif isinstance(sd_referencenet_model, dict):
+        state = sd_referencenet_model
+    kwargs.update(config_overrides)
+    net = ReferenceNet2D(**kwargs)
+    if state is not None:
+        # a full SD UNet2D checkpoint also carries up_blocks / conv_norm_out / conv_out, which this encoder does not own
+        own = {k: v for k, v in state.items() if not k.startswith(("up_blocks.", "conv_norm_out.", "conv_out."))}
+        missing, unexpected = net.load_state_dict(own, strict=False)
+        if strict:
+            assert len(unexpected) == 0, f"unexpected keys: {unexpected[:8]}"
+            assert len(missing) == 0, f"missing keys: {missing[:8]}"
+    if sd_model is not None:
+        t2i = sd_model.state_dict() if isinstance(sd_model, nn.Module) else sd_model
+        own = {k: v for k, v in t2i.items() if not k.startswith(("up_blocks.", "conv_norm_out.", "conv_out."))}
+        _, unexpected = net.load_state_dict(own, strict=False)
+        assert len(unexpected) == 0, f"unexpected keys: {unexpected[:8]}"
+    return net.to(dtype=dtype).eval()
+
+
+def load_referencenet_by_name(model_name: str, sd_referencenet_model: Union[str, nn.Module, dict, None] = None, sd_model=None,
+                              cross_attention_dim: int = 768, dtype: torch.dtype = torch.float16, **config_overrides) -> nn.Module:
+    """reference musev/models/referencenet_loader.py:86-124"""
+    if model_name != "musev_referencenet":
+        raise ValueError(f"unsupport model_name={model_name}, only support musev_referencenet")
+    return load_referencenet(sd_referencenet_model, sd_model=sd_model, cross_attention_dim=cross_attention_dim, dtype=dtype,
+                             need_self_attn_block_embs=False, need_block_embs=True, subfolder="referencenet", **config_overrides)

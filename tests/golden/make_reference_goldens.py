@@ -15,6 +15,7 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
   * reference_ddim.npz          musev/schedulers/scheduling_ddim.py DDIMScheduler.step (eta = 0, epsilon)
   * reference_euler.npz         musev/schedulers/scheduling_euler_discrete.py EulerDiscreteScheduler.step (s_churn = 0)
   * reference_datautil.npz      musev/data/data_util.py index helpers used by the loop
+  * reference_referencenet_*.npz musev/models/referencenet.py ReferenceNet2D.forward (block-embedding mode): 12 + 1 feature maps
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
 from __future__ import annotations
@@ -155,9 +156,37 @@ def gen_datautil():
     print("datautil: adain identity =", bool(torch.equal(adain_in, adain_out)))
 
 
+def gen_referencenet():
+    """musev/models/referencenet.py ReferenceNet2D.forward (need_block_embs=True, need_self_attn_block_embs=False) with the
+    oracle's seeded weights loaded strict=True: pins the key / shape inventory and the 12 + 1 feature maps."""
+    from musev.models.referencenet import ReferenceNet2D
+    from golden_cases import REFNET_CASES, refnet_case_inputs
+    from oracle import referencenet as oref
+    for name, case in REFNET_CASES.items():
+        cfg = oref.referencenet_config(**case["arch"])
+        sd = oref.init_state_dict(cfg, case["weight_seed"])
+        kw = dict(block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg["layers_per_block"],
+                  down_block_types=tuple(cfg["down_block_types"]), cross_attention_dim=cfg["cross_attention_dim"],
+                  attention_head_dim=cfg["attention_head_dim"], need_block_embs=True, need_self_attn_block_embs=False)
+        if "up_block_types" not in case["arch"] and len(cfg["block_out_channels"]) != 4:
+            n_up = len(cfg["block_out_channels"])
+            kw["up_block_types"] = ("UpBlock2D",) + ("CrossAttnUpBlock2D",) * (n_up - 1)
+        net = ReferenceNet2D(**kw).eval()
+        net.load_state_dict(sd, strict=True)
+        x, t, ehs = refnet_case_inputs(case, cfg)
+        with torch.no_grad():
+            down, mid, sa = net(x, t, encoder_hidden_states=ehs, num_frames=case["t"], return_ndim=5)
+        assert sa is None
+        out = {f"down{i}": d.numpy().astype(np.float32) for i, d in enumerate(down)}
+        out["mid"] = mid.numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, f"reference_referencenet_{name}.npz"), **out)
+        print("referencenet", name, len(down), [tuple(d.shape) for d in down[:2]], tuple(mid.shape), "absmax", float(mid.abs().max()))
+
+
 if __name__ == "__main__":
     gen_context()
     gen_ddim()
     gen_euler()
     gen_datautil()
+    gen_referencenet()
     gen_unet()

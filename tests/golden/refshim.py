@@ -627,5 +627,65 @@ def install(reference_root: str = "/root/reference") -> None:
     acc = _mod("accelerate")
     _mod("accelerate.utils").set_module_tensor_to_device = None
     _mod("accelerate.utils.versions").is_torch_version = lambda op, v: True
+    _install_referencenet_extras()
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
+
+
+def _install_referencenet_extras() -> None:
+    """names that musev/models/referencenet.py and musev/models/unet_2d_blocks.py import from diffusers.  Everything the
+    SD-1.5 ReferenceNet configuration does not instantiate is an empty placeholder class."""
+    def stub(name):
+        return type(name, (nn.Module,), {})
+
+    ap = _mod("diffusers.models.attention_processor")
+    for n in ("AttnAddedKVProcessor", "AttnAddedKVProcessor2_0", "AttnProcessor", "AttentionProcessor"):
+        if not hasattr(ap, n):
+            setattr(ap, n, type(n, (), {}))
+    for n in ("ADDED_KV_ATTENTION_PROCESSORS", "CROSS_ATTENTION_PROCESSORS"):
+        if not hasattr(ap, n):
+            setattr(ap, n, ())
+    _mod("diffusers.models.dual_transformer_2d").DualTransformer2DModel = stub("DualTransformer2DModel")
+    _mod("diffusers.models.normalization").AdaGroupNorm = stub("AdaGroupNorm")
+    rs = _mod("diffusers.models.resnet")
+    for n in ("FirDownsample2D", "FirUpsample2D", "KDownsample2D", "KUpsample2D"):
+        if not hasattr(rs, n):
+            setattr(rs, n, stub(n))
+    u2 = _mod("diffusers.models.unet_2d_blocks")
+    for n in ("AttnDownBlock2D AttnDownEncoderBlock2D AttnSkipDownBlock2D AttnSkipUpBlock2D AttnUpBlock2D AttnUpDecoderBlock2D "
+              "DownEncoderBlock2D KCrossAttnDownBlock2D KCrossAttnUpBlock2D KDownBlock2D KUpBlock2D ResnetDownsampleBlock2D "
+              "ResnetUpsampleBlock2D SimpleCrossAttnDownBlock2D SimpleCrossAttnUpBlock2D SkipDownBlock2D SkipUpBlock2D "
+              "UpDecoderBlock2D").split():
+        setattr(u2, n, stub(n))
+    tu = _mod("diffusers.utils.torch_utils")
+    tu.apply_freeu = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    if not hasattr(tu, "maybe_allow_in_graph"):
+        tu.maybe_allow_in_graph = lambda c: c
+    uc = _mod("diffusers.models.unet_2d_condition")
+
+    @dataclass
+    class UNet2DConditionOutput(BaseOutput):
+        sample: torch.FloatTensor = None
+
+    uc.UNet2DConditionModel = type("UNet2DConditionModel", (ModelMixin, ConfigMixin), {})
+    uc.UNet2DConditionOutput = UNet2DConditionOutput
+    ut = _mod("diffusers.utils")
+    _mod("diffusers.utils.deprecation_utils").deprecate = lambda *a, **k: None
+    pu = _mod("diffusers.utils.peft_utils")
+    pu.scale_lora_layers = pu.unscale_lora_layers = lambda *a, **k: None
+    for n, v in (("deprecate", lambda *a, **k: None), ("scale_lora_layers", lambda *a, **k: None),
+                 ("unscale_lora_layers", lambda *a, **k: None), ("USE_PEFT_BACKEND", False), ("BaseOutput", BaseOutput)):
+        if not hasattr(ut, n):
+            setattr(ut, n, v)
+    mu = _mod("diffusers.models.modeling_utils")
+    if not hasattr(mu, "load_state_dict"):
+        mu.load_state_dict = lambda *a, **k: None
+    em = _mod("diffusers.models.embeddings")
+    for n in ("GaussianFourierProjection ImageHintTimeEmbedding ImageProjection ImageTimeEmbedding PositionNet "
+              "TextImageProjection TextImageTimeEmbedding TextTimeEmbedding").split():
+        if not hasattr(em, n):
+            setattr(em, n, stub(n))
+    act = _mod("diffusers.models.activations")
+    if not hasattr(act, "get_activation"):
+        act.get_activation = lambda name: {"silu": nn.SiLU(), "swish": nn.SiLU(), "mish": nn.Mish(), "gelu": nn.GELU(),
+                                           "relu": nn.ReLU()}[name]

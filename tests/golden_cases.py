@@ -87,3 +87,23 @@ def case_inputs(case: dict, cfg: dict):
     if case.get("skip_temporal_layers") is not None:
         kw["skip_temporal_layers"] = case["skip_temporal_layers"]
     return x, torch.tensor(case["timestep"]), ehs, kw
+
+
+# ---- ReferenceNet2D: the configuration of load_referencenet_by_name("musev_referencenet") ---------------
+REFNET_CASES = {
+    "narrow": dict(arch=dict(block_out_channels=(64, 128, 256, 256)), b=2, t=1, h=16, w=16, weight_seed=21, input_seed=31, timestep=0),
+    "narrow_2ref": dict(arch=dict(block_out_channels=(64, 128, 256, 256)), b=1, t=2, h=16, w=24, weight_seed=22, input_seed=32,
+                        timestep=0),
+    # widths the HIP attention kernels support (head dims 40 / 80 / 80); 3 levels, 1 layer per block
+    "hipw": dict(arch=dict(block_out_channels=(320, 640, 640), layers_per_block=1,
+                           down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D")),
+                 b=2, t=1, h=16, w=16, weight_seed=23, input_seed=33, timestep=0),
+}
+
+
+def refnet_case_inputs(case: dict, cfg: dict):
+    g = torch.Generator().manual_seed(case["input_seed"])
+    n = case["b"] * case["t"]
+    x = torch.randn(n, cfg["in_channels"], case["h"], case["w"], generator=g)
+    ehs = torch.randn(n, 4, cfg["cross_attention_dim"], generator=g)  # the pipeline feeds the IP-Adapter image tokens (4 per image)
+    return x, torch.tensor(case["timestep"]), ehs

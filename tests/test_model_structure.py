@@ -67,3 +67,30 @@ def test_bench_flop_counter_known_answers():
     assert abs(bench.unet_flops(512, 512, 12, 2, "musev", n_vis=0) / 1e12 - 30.55) < 0.01
     assert abs(bench.unet_flops(512, 512, 13, 2, "musev_referencenet") / 1e12 - 41.34) < 0.01
     assert abs(bench.unet_flops(256, 256, 4, 2, "musev", n_vis=0) / 1e12 - 2.38) < 0.01
+
+
+def test_referencenet_state_dict_and_surface():
+    """musev_amd.models.referencenet.ReferenceNet2D owns exactly the parameters of the reference's ReferenceNet2D in block-
+    embedding mode (oracle.referencenet.param_shapes is loaded strict=True into the reference constructor by
+    tests/golden/make_reference_goldens.py), under the diffusers UNet2D key names; an SD checkpoint's decoder keys are
+    ignored by the loader; the module refuses CPU tensors and the modes the shipped flavour does not use."""
+    from oracle import referencenet as oref
+    from musev_amd.models.referencenet import ReferenceNet2D, load_referencenet_by_name
+    cfg = oref.referencenet_config(**NARROW)
+    want = oref.param_shapes(cfg)
+    sd = oref.init_state_dict(cfg, 2)
+    full = dict(sd)
+    full["up_blocks.0.resnets.0.conv1.weight"] = torch.zeros(1)  # decoder weights of a full SD UNet2D checkpoint
+    full["conv_out.weight"] = torch.zeros(1)
+    m = load_referencenet_by_name("musev_referencenet", full, dtype=torch.float32, **NARROW)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert set(got) == set(want)
+    assert all(got[k] == tuple(want[k]) for k in want)
+    assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    assert m.need_block_embs and not m.need_self_attn_block_embs and m.dtype == torch.float32
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(2, 4, 8, 8), 0, torch.zeros(2, 4, 768), num_frames=1)
+    with pytest.raises(NotImplementedError):
+        ReferenceNet2D(need_self_attn_block_embs=True)
+    with pytest.raises(ValueError, match="unsupport model_name"):
+        load_referencenet_by_name("musev")

@@ -138,3 +138,27 @@ def test_euler_matches_reference():
             prev = torch.from_numpy(gold[f"{spacing}_x{i}"] if i else gold[f"{spacing}_x0"])
             affine = prev + (float(h.sigmas[i + 1]) - float(h.sigmas[i])) * eps
             assert torch.allclose(affine, want, rtol=1e-5, atol=2e-5), (spacing, i, (affine - want).abs().max())
+
+
+@pytest.mark.parametrize("name", ["narrow", "narrow_2ref", "hipw"])
+def test_oracle_referencenet_matches_reference(name):
+    """oracle.referencenet.referencenet_forward against the 12 + 1 feature maps recorded from the reference's own
+    ReferenceNet2D (musev/models/referencenet.py:640-1143, block-embedding mode) on the same seeded weights and inputs."""
+    import os
+
+    import numpy as np
+    from golden_cases import REFNET_CASES, refnet_case_inputs
+    from oracle import referencenet as oref
+    case = REFNET_CASES[name]
+    cfg = oref.referencenet_config(**case["arch"])
+    sd = oref.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs = refnet_case_inputs(case, cfg)
+    with torch.no_grad():
+        down, mid = oref.referencenet_forward(sd, cfg, x, t, ehs, num_frames=case["t"])
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_referencenet_{name}.npz"))
+    assert len(down) == sum(1 for k in gold.files if k.startswith("down"))
+    for i, d in enumerate(down):
+        want = torch.from_numpy(gold[f"down{i}"])
+        assert d.shape == want.shape
+        assert torch.allclose(d, want, rtol=1e-4, atol=2e-4), (name, i, (d - want).abs().max())
+    assert torch.allclose(mid, torch.from_numpy(gold["mid"]), rtol=1e-4, atol=2e-4)
