@@ -369,15 +369,30 @@ def case_window_loop():
     x0 = (lat - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
     ref_lat = math.sqrt(a_p) * x0 + math.sqrt(1 - a_p) * eps
     r4 = _cmp("cfg_ddim_step", lat2, ref_lat, atol=1e-5, rtol=1e-5)
-    # Euler-discrete step (scheduling_euler_discrete.py:146-162 with gamma = 0): x + (sigma_next - sigma) * eps
-    lat3 = lat.clone() * 14.6
-    sig, sig_next = 14.6146, 11.8927
-    ops.cfg_affine_step(lat3, acc, cnt2, gs, 1.0, sig_next - sig)
-    ref3 = lat * 14.6 + (sig_next - sig) * eps
-    r5 = _cmp("cfg_affine_step", lat3, ref3, atol=1e-4, rtol=1e-5)
-    parts = (r1, r2, r3, r4, r5)
+    parts = (r1, r2, r3, r4)
     return {"name": "window loop glue", "ok": all(p["ok"] for p in parts), "max_abs_err": max(p["max_abs_err"] for p in parts),
             "parts": {p["name"]: p["ok"] for p in parts}}
+
+
+def case_cfg_affine_step():
+    """mv_cfg_affine_step against the Euler-discrete step (scheduling_euler_discrete.py:146-162 with gamma = 0):
+    x + (sigma_next - sigma) * CFG(acc / counter)."""
+    from musev_amd import ops
+    c, t_total, hw = 4, 20, 48
+    g = torch.Generator().manual_seed(140)
+    lat = (14.6 * torch.randn((c, t_total, hw), generator=g)).to(DEV)
+    acc = torch.randn((2, c, t_total, hw), generator=g).to(DEV)
+    cnt = torch.tensor([1.0, 2.0] * (t_total // 2), device=DEV)
+    gs, sig, sig_next = 3.5, 14.6146, 11.8927
+    got = lat.clone()
+    ops.cfg_affine_step(got, acc, cnt, gs, 1.0, sig_next - sig)
+    eps = acc / cnt[None, None, :, None]
+    eps = eps[0] + gs * (eps[1] - eps[0])
+    r1 = _cmp("cfg_affine_step euler", got, lat + (sig_next - sig) * eps, atol=1e-4, rtol=1e-5)
+    got1 = lat.clone()
+    ops.cfg_affine_step(got1, acc[:1].contiguous(), cnt, 1.0, 0.5, -2.0)  # one half (no CFG), general cx / ce
+    r2 = _cmp("cfg_affine_step single half", got1, 0.5 * lat - 2.0 * (acc[0] / cnt[None, :, None]), atol=1e-4, rtol=1e-5)
+    return {"name": "cfg_affine_step", "ok": r1["ok"] and r2["ok"], "max_abs_err": max(r1["max_abs_err"], r2["max_abs_err"])}
 
 
 ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
