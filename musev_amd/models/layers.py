@@ -27,6 +27,10 @@ def bump_pack_epoch() -> None:
 class HipModule(nn.Module):
     """nn.Module with a cache of packed (kernel-layout, fp16) weights."""
 
+    # the top-level forwards refuse non-HIP tensors (there is no CPU path); the CPU test suite switches this off on an
+    # instance only together with tests/emu_ops.py, to exercise the host-side wiring against the oracle
+    _device_check = True
+
     def _cache(self) -> Dict[str, object]:
         if getattr(self, "_pk_epoch", -1) != _PACK_EPOCH[0]:
             object.__setattr__(self, "_pk", {})

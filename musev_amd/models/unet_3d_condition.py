@@ -310,7 +310,7 @@ class UNet3DConditionModel(HipModule):
         do_classifier_free_guidance: bool = False,
         pose_guider_emb: torch.Tensor = None,
     ) -> Union[UNet3DConditionOutput, Tuple]:
-        if not sample.is_cuda:
+        if self._device_check and not sample.is_cuda:
             raise RuntimeError("musev_amd.UNet3DConditionModel runs only on an MI355X (HIP) device; there is no CPU path")
         if sample.ndim != 5:
             raise ValueError(f"sample must be b c t h w, got ndim={sample.ndim}")

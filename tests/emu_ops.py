@@ -1,0 +1,351 @@
+"""CPU emulation of the tensor-level C-ABI wrappers (musev_amd.ops) in plain torch: fp16 operands, fp32 arithmetic, fp16
+results -- the storage contract of the kernels in include/musev_hip.h.  TEST INFRASTRUCTURE ONLY: it lets the CPU suite
+drive the *host side* of the product (module wiring, weight packing, segment descriptors, geometry, conditioning rows,
+the denoise loop) end to end against the oracle when no GPU is present.  The product never imports this module, and
+nothing here is timed or shipped; on a GPU box the same module code runs on libmusev_hip.so.
+
+tests/test_emulated_wiring.py first checks every function here against the very torch reference expressions that the
+GPU kernels are verified against (tests/kernel_cases.py run with DEV = "cpu"), so "emulation == references" on the CPU
+and "kernels == references" on the MI355X describe the same contract."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from fake_ops import cfg_affine_step, cfg_ddim_step, window_gather, window_scatter_add  # noqa: F401  (loop glue)
+
+MV_ACT_NONE, MV_ACT_SILU = 0, 1
+
+# The argument contract of the real entry points (musev_amd/ops.py::_mat/_vec and the MV_REQUIRE lines of csrc/*.hip) is
+# enforced here too, so a module that hands a kernel a non-contiguous view, a misaligned column slice or an unsupported
+# width fails on the CPU exactly where it would fail on the GPU.  STRICT_WIDTHS covers the constraints the 1/5-width
+# golden cases cannot meet (head dim in {40, 80, 160}; conv sources in multiples of 64 channels).
+STRICT_WIDTHS = True
+
+
+class ContractError(ValueError):
+    pass
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ContractError(msg)
+
+
+def _mat(t, name, ld_mult=8):
+    _req(t.dim() == 2 and t.stride(1) == 1, f"{name}: 2-D with unit inner stride expected, got {tuple(t.shape)} / {t.stride()}")
+    _req(t.dtype == torch.float16, f"{name}: fp16 expected, got {t.dtype}")
+    _req(t.stride(0) % ld_mult == 0 or t.shape[0] == 1, f"{name}: leading dimension {t.stride(0)} % {ld_mult}")
+    _req(t.storage_offset() % 8 == 0, f"{name}: view starts at element {t.storage_offset()} (16-byte alignment)")
+    return t
+
+
+def _vec(t, name, n=None):
+    if t is None:
+        return None
+    _req(t.dtype == torch.float16 and t.is_contiguous(), f"{name}: contiguous fp16 expected")
+    _req(n is None or t.numel() == n, f"{name}: expected {n} elements, got {t.numel()}")
+    return t
+
+
+def _check_epilogue(M, N, cols, bias, rowbias, rows_per_group, residual, alpha):
+    _vec(bias, "bias", N)
+    if rowbias is not None:
+        _mat(rowbias, "rowbias", 4)
+        _req(rows_per_group > 0 and rowbias.shape[0] * rows_per_group >= M and rowbias.shape[1] == N, "rowbias: coverage")
+    if residual is not None:
+        _mat(residual, "residual", 4)
+        _req(tuple(residual.shape) == (M, cols), "residual: shape mismatch")
+    if alpha is not None:
+        _req(alpha.dtype == torch.float32 and alpha.numel() == 1, "alpha: fp32 scalar tensor expected")
+
+
+def _check_out(out, M, cols, ld_mult=4):
+    if out is not None:
+        _mat(out, "out", ld_mult)
+        _req(tuple(out.shape) == (M, cols), f"out: expected {(M, cols)}, got {tuple(out.shape)}")
+
+
+def _store(val: torch.Tensor, out: Optional[torch.Tensor], dtype=torch.float16) -> torch.Tensor:
+    val = val.to(dtype)
+    if out is None:
+        return val.contiguous()
+    out.copy_(val)
+    return out
+
+
+def _epilogue(acc, *, bias, rowbias, rows_per_group, residual, alpha, act, geglu):
+    M = acc.shape[0]
+    if bias is not None:
+        acc = acc + bias.float()
+    if rowbias is not None:
+        acc = acc + rowbias.float()[torch.arange(M) // int(rows_per_group)]
+    if alpha is not None:
+        acc = acc * alpha.float().abs().reshape(())
+    if act == MV_ACT_SILU:
+        acc = F.silu(acc)
+    if geglu:  # rows of the packed weight come in blocks of [16 value | 16 gate] (ops.pack_geglu)
+        blk = acc.reshape(M, -1, 2, 16)
+        acc = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, -1)
+    if residual is not None:
+        acc = acc + residual.float()
+    return acc
+
+
+def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=None, act=MV_ACT_NONE,
+         geglu=False, out=None):
+    _mat(a, "a")
+    _mat(w, "w")
+    _req(w.is_contiguous(), "w must be contiguous [N, K]")
+    M, (N, K) = a.shape[0], w.shape
+    if a2 is not None:
+        _mat(a2, "a2")
+        _req(a2.shape[0] == M, "a2: row count mismatch")
+        _req(a.shape[1] % 64 == 0, "two-source input needs c1 % 64 == 0")
+    x = a if a2 is None else torch.cat([a, a2], dim=1)
+    _req(x.shape[1] == K, "gemm: K mismatch")
+    _req(N % 4 == 0 and K % 8 == 0 and a.shape[1] % 8 == 0 and (a2 is None or a2.shape[1] % 8 == 0), "gemm: N % 4, K % 8, c % 8")
+    if geglu:
+        _req(N % 32 == 0 and rowbias is None and residual is None and alpha is None and act == MV_ACT_NONE, "geglu epilogue: bare only")
+    cols = N // 2 if geglu else N
+    _check_epilogue(M, N, cols, bias, rowbias, rows_per_group, residual, alpha)
+    _check_out(out, M, cols)
+    acc = x.float() @ w.float().t()
+    return _store(_epilogue(acc, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual,
+                            alpha=alpha, act=act, geglu=geglu), out)
+
+
+def pack_conv_weight(w):
+    o, i = w.shape[0], w.shape[1]
+    return w.reshape(o, i, -1).permute(0, 2, 1).reshape(o, -1).to(torch.float16).contiguous()  # tap-major, channel-minor
+
+
+def _unpack(w, cin, kshape):
+    o = w.shape[0]
+    taps = w.shape[1] // cin
+    return w.float().reshape(o, taps, cin).permute(0, 2, 1).reshape(o, cin, *kshape)
+
+
+def _images(x, n_img, h, w_):
+    return x.float().reshape(n_img, h, w_, -1).permute(0, 3, 1, 2)
+
+
+def _rows(y):
+    return y.permute(0, 2, 3, 1).reshape(-1, y.shape[1])
+
+
+def conv3x3(x, w, n_img, h, w_, *, x2=None, stride=1, upsample=False, bias=None, rowbias=None, rows_per_group=0,
+            residual=None, out=None):
+    _mat(x, "x")
+    _mat(w, "w")
+    _req(x.shape[0] == n_img * h * w_, "conv3x3: x rows != n_img*h*w")
+    if x2 is not None:
+        _mat(x2, "x2")
+        _req(x2.shape[0] == x.shape[0], "conv3x3: x2 rows")
+    xs = x if x2 is None else torch.cat([x, x2], dim=1)
+    _req(w.shape[1] == 9 * xs.shape[1], "conv3x3: weight K != 9*(C1+C2)")
+    _req(stride in (1, 2) and not (upsample and stride != 1), "conv3x3: stride / upsample")
+    if STRICT_WIDTHS:
+        _req(xs.shape[1] % 64 == 0 and (x2 is None or x.shape[1] % 64 == 0), "conv modes need cin % 64 == 0")
+    ho, wo = (2 * h, 2 * w_) if upsample else ((h + 2 - 3) // stride + 1, (w_ + 2 - 3) // stride + 1)
+    _check_epilogue(n_img * ho * wo, w.shape[0], w.shape[0], bias, rowbias, rows_per_group, residual, None)
+    _check_out(out, n_img * ho * wo, w.shape[0])
+    img = _images(xs, n_img, h, w_)
+    if upsample:
+        img = F.interpolate(img, scale_factor=2.0, mode="nearest")
+    y = _rows(F.conv2d(img, _unpack(w, xs.shape[1], (3, 3)), None, stride=stride, padding=1))
+    return _store(_epilogue(y, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual, alpha=None,
+                            act=MV_ACT_NONE, geglu=False), out)
+
+
+def tconv3(x, w, b, t, hw, *, bias=None, residual=None, alpha=None, out=None):
+    _mat(x, "x")
+    _mat(w, "w")
+    c = x.shape[1]
+    _req(x.shape[0] == b * t * hw and w.shape[1] == 3 * c, "tconv3: geometry")
+    if STRICT_WIDTHS:
+        _req(c % 64 == 0, "conv modes need cin % 64 == 0")
+    _check_epilogue(x.shape[0], w.shape[0], w.shape[0], bias, None, 0, residual, alpha)
+    _check_out(out, x.shape[0], w.shape[0])
+    vol = x.float().reshape(b, t, hw, 1, c).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(vol, _unpack(w, c, (3, 1, 1)), None, padding=(1, 0, 0))
+    y = y.permute(0, 2, 3, 4, 1).reshape(b * t * hw, -1)
+    return _store(_epilogue(y, bias=bias, rowbias=None, rows_per_group=0, residual=residual, alpha=alpha,
+                            act=MV_ACT_NONE, geglu=False), out)
+
+
+def groupnorm(x, gamma, beta, n_items, rows, *, eps, silu, x2=None, groups=32, out=None):
+    _mat(x, "x")
+    _req(x.shape[0] == n_items * rows, "groupnorm: x rows != n_items*rows")
+    if x2 is not None:
+        _mat(x2, "x2")
+        _req(x2.shape[0] == x.shape[0] and x2.shape[1] % 8 == 0, "groupnorm: x2")
+    xs = x if x2 is None else torch.cat([x, x2], dim=1)
+    c = xs.shape[1]
+    _req(x.shape[1] % 8 == 0 and c % groups == 0 and c <= 8192, "groupnorm: channels")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _check_out(out, n_items * rows, c, 8)
+    y = F.group_norm(xs.float().reshape(n_items, rows, c).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)
+    if silu:
+        y = F.silu(y)
+    return _store(y.permute(0, 2, 1).reshape(n_items * rows, c), out)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _mat(x, "x")
+    _req(x.shape[1] % 8 == 0 and x.shape[1] <= 1536, "layernorm: C % 8 == 0 and C <= 1536")
+    _vec(gamma, "gamma", x.shape[1])
+    _vec(beta, "beta", x.shape[1])
+    _check_out(out, x.shape[0], x.shape[1], 8)
+    return _store(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps), out)
+
+
+def attention(q, segs, nb, lq, heads, d, scale, *, out=None, accumulate=False, out_scale=1.0):
+    c = heads * d
+    _mat(q, "q")
+    _req(tuple(q.shape) == (nb * lq, c) and 1 <= len(segs) <= 4, "attention: q shape / segment count")
+    _req(nb <= 65535 and nb > 0 and lq > 0, "attention: grid")
+    if STRICT_WIDTHS:
+        _req(d in (40, 80, 160), f"attention: head dim {d} not in (40, 80, 160)")
+    _check_out(out, nb * lq, c)
+    _req(not accumulate or out is not None, "attention: accumulate needs out")
+    ks, vs = [], []
+    for k, v, ln, div, mul, add_ in segs:
+        _mat(k, "k")
+        _mat(v, "v")
+        _req(ln > 0 and div > 0 and k.shape[1] == c and v.shape[1] == c, "attention: bad segment")
+        kvb = [(n // div) * mul + add_ for n in range(nb)]
+        _req(k.shape[0] >= (max(kvb) + 1) * ln and v.shape[0] >= (max(kvb) + 1) * ln, "attention: segment does not cover its key batches")
+        nkb = k.shape[0] // ln
+        ks.append(k.float()[: nkb * ln].reshape(nkb, ln, c)[kvb])
+        vs.append(v.float()[: nkb * ln].reshape(nkb, ln, c)[kvb])
+    kk, vv = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
+    qh = q.float().reshape(nb, lq, heads, d).transpose(1, 2)
+    kh = kk.reshape(nb, -1, heads, d).transpose(1, 2)
+    vh = vv.reshape(nb, -1, heads, d).transpose(1, 2)
+    o = (torch.softmax((qh @ kh.transpose(-1, -2)) * scale, dim=-1) @ vh).transpose(1, 2).reshape(nb * lq, c)
+    if accumulate:
+        o = out.float() + out_scale * o
+    return _store(o, out)
+
+
+def temporal_attention(q, k, v, b, t, hw, heads, d, scale, out=None):
+    c = heads * d
+    for name, m in (("q", q), ("k", k), ("v", v)):
+        _mat(m, name)
+        _req(tuple(m.shape) == (b * t * hw, c), f"temporal_attention: {name} shape")
+    _req(1 <= t <= 32 and d % 8 == 0, "temporal_attention: T in [1, 32], d % 8")
+    _check_out(out, b * t * hw, c, 8)
+
+    def seq(x):  # rows (b, t, p) -> [(b p), heads, t, d]
+        return x.float().reshape(b, t, hw, heads, d).permute(0, 2, 3, 1, 4).reshape(b * hw, heads, t, d)
+    o = torch.softmax((seq(q) @ seq(k).transpose(-1, -2)) * scale, dim=-1) @ seq(v)
+    o = o.reshape(b, hw, heads, t, d).permute(0, 3, 1, 2, 4).reshape(b * t * hw, c)
+    return _store(o, out)
+
+
+def geglu(x, out=None):
+    _mat(x, "x")
+    half = x.shape[1] // 2
+    _req(half % 8 == 0, "geglu: half_cols % 8")
+    _check_out(out, x.shape[0], half, 8)
+    return _store(x.float()[:, :half] * F.gelu(x.float()[:, half:]), out)
+
+
+def silu(x):
+    _req(x.is_contiguous() and x.dtype == torch.float16 and x.numel() % 8 == 0 and x.numel() > 0, "silu: contiguous fp16, n % 8")
+    return F.silu(x.float()).to(torch.float16)
+
+
+def add(a, b):
+    _req(a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == torch.float16
+         and a.numel() % 8 == 0, "add: contiguous fp16 tensors of equal shape, n % 8")
+    return (a.float() + b.float()).to(torch.float16)
+
+
+def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None):
+    cin = x.shape[1]
+    _req(x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[0] == n_img * h * w_, "conv_in: x")
+    _req(w.dtype == torch.float16 and w.is_contiguous() and w.shape[1] >= 9 * cin and w.shape[0] % 8 == 0 and cin <= 16, "conv_in: w")
+    _vec(bias, "bias", w.shape[0])
+    if add_ is not None:
+        _req(add_.dtype == torch.float16 and add_.is_contiguous() and tuple(add_.shape) == (x.shape[0], w.shape[0]), "conv_in: add")
+    y = _rows(F.conv2d(_images(x, n_img, h, w_), _unpack(w[:, : 9 * cin], cin, (3, 3)), None, padding=1))
+    if bias is not None:
+        y = y + bias.float()
+    if add_ is not None:
+        y = y + add_.float()
+    return y.to(torch.float16)
+
+
+def conv3x3_cin_small_gemm(x, w, bias, n_img, h, w_, add_=None, kpad=64):
+    _req(9 * x.shape[1] <= kpad and kpad % 8 == 0 and w.shape[1] in (9 * x.shape[1], kpad), "conv3x3_cin_small_gemm: bad shapes")
+    return conv3x3_cin_small(x, w, bias, n_img, h, w_, add_)
+
+
+def pad_cols(w, k):
+    out = torch.zeros((w.shape[0], k), dtype=w.dtype)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+def conv3x3_cout_small(x, w, bias, n_img, h, w_, out_dtype=torch.float16):
+    _mat(x, "x")
+    _mat(w, "w")
+    _req(x.is_contiguous() and w.shape[1] == 9 * x.shape[1] and x.shape[1] % 8 == 0 and w.shape[0] <= 8, "conv_out: shapes")
+    _req(x.shape[0] == n_img * h * w_ and out_dtype in (torch.float16, torch.float32), "conv_out: rows / dtype")
+    _vec(bias, "bias", w.shape[0])
+    y = _rows(F.conv2d(_images(x, n_img, h, w_), _unpack(w, x.shape[1], (3, 3)), None, padding=1))
+    if bias is not None:
+        y = y + bias.float()
+    return y.to(out_dtype).contiguous()
+
+
+def timestep_embedding(t, dim):
+    half = dim // 2
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t.float().reshape(-1, 1) * freq[None]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1).to(torch.float16)  # flip_sin_to_cos, freq_shift 0
+
+
+def zero_rows(x, row_idx):
+    _mat(x, "x", 1)
+    _req(row_idx.numel() > 0 and int(row_idx.max()) < x.shape[0], "zero_rows: index range")
+    x[row_idx.long()] = 0
+
+
+def bcthw_to_bthwc(x):
+    return x.float().permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).to(torch.float16).contiguous()
+
+
+def bthwc_to_bcthw(x, b, t, h, w, dtype=torch.float16):
+    _req(x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.float16, torch.float32) and x.shape[0] == b * t * h * w,
+         "bthwc_to_bcthw: contiguous 2-D fp16|fp32 rows of b*t*h*w expected")
+    return x.reshape(b, t, h, w, -1).permute(0, 4, 1, 2, 3).to(dtype).contiguous()
+
+
+def pack_geglu(w, bias):
+    half = w.shape[0] // 2
+    idx = torch.arange(half).view(-1, 16)
+    perm = torch.cat([idx, idx + half], dim=1).reshape(-1)
+    return w.index_select(0, perm).contiguous(), (bias.index_select(0, perm).contiguous() if bias is not None else None)
+
+
+EMULATED = ["gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
+            "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "timestep_embedding", "zero_rows",
+            "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step",
+            "pack_conv_weight", "pack_geglu"]
+
+
+def install(monkeypatch) -> None:
+    """route musev_amd.ops.<name> to the emulation for the duration of one test (pytest's monkeypatch restores it)"""
+    import sys
+
+    from musev_amd import ops
+    me = sys.modules[__name__]
+    for name in EMULATED:
+        monkeypatch.setattr(ops, name, getattr(me, name))

@@ -1,0 +1,195 @@
+"""CPU checks of the product's HOST SIDE with the kernels emulated (tests/emu_ops.py): the HIP-backed modules -- weight
+packing, QKV fusion, segment descriptors, geometry, conditioning rows, skip bookkeeping, the denoise loop -- run end to
+end against the oracle and against the outputs recorded from the reference's own source, with no GPU.
+
+What this does and does not prove: the kernels themselves are NOT exercised here (that is `-m gpu`, through the C ABI
+on an MI355X).  The emulation is first tied to the same torch reference expressions the kernels are verified against
+(test_emulation_matches_kernel_references), so a wiring error in a module shows up here on the CPU, and a kernel error
+shows up in tests/test_kernels_gpu.py on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from golden_cases import REFNET_CASES, UNET_CASES, case_config, case_inputs, refnet_case_inputs
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-2  # the north-star bound; fp16 storage between emulated ops gives the same error level as the kernels (~3e-3)
+
+
+@pytest.fixture
+def emulated(monkeypatch):
+    emu_ops.install(monkeypatch)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    return monkeypatch
+
+
+def _widths(emulated, arch):
+    """full argument contract (head dims 40/80/160, 64-channel conv sources) for the widths the kernels serve; the
+    layout / alignment contract only for the 1/5-width cases"""
+    emulated.setattr(emu_ops, "STRICT_WIDTHS", arch["block_out_channels"][0] % 320 == 0)
+
+
+def _cpu(model):
+    model._device_check = False  # instance attribute: the class default (refuse non-HIP tensors) stays
+    return model
+
+
+# ---- 1. the emulation against the reference expressions of tests/kernel_cases.py ----------------------------------------
+def test_emulation_matches_kernel_references(emulated):
+    import kernel_cases as kc
+    emulated.setattr(kc, "DEV", "cpu")
+    emulated.setattr(emu_ops, "STRICT_WIDTHS", False)  # small shapes: the arithmetic is what is compared here
+    cases = [
+        lambda: kc.case_gemm(M=200, N=320, K=640), lambda: kc.case_gemm(M=130, N=160, K=448, two_src=True),
+        lambda: kc.case_gemm(M=64, N=64, K=64, epilogue=False), kc.case_gemm_silu, lambda: kc.case_gemm_geglu(M=77, C=64),
+        lambda: kc.case_conv3x3(n=2, h=8, w=12, c1=32, cout=64),
+        lambda: kc.case_conv3x3(n=2, h=8, w=12, c1=32, c2=16, cout=64),
+        lambda: kc.case_conv3x3(n=2, h=8, w=12, c1=32, cout=64, stride=2),
+        lambda: kc.case_conv3x3(n=2, h=7, w=9, c1=32, cout=64, stride=2),
+        lambda: kc.case_conv3x3(n=2, h=8, w=12, c1=32, cout=64, upsample=True),
+        lambda: kc.case_tconv3(b=2, t=5, hw=12, c=64),
+        lambda: kc.case_groupnorm(n=3, rows=50, c1=64), lambda: kc.case_groupnorm(n=2, rows=50, c1=64, c2=32, silu=False),
+        lambda: kc.case_layernorm(rows=99, c=64),
+        lambda: kc.case_attention_self(d=40, b=2, t=3, lq=20, cond_idx=1), lambda: kc.case_attention_cross(d=80, nb=6, t=3, lq=13),
+        lambda: kc.case_temporal_attention(b=2, t=5, hw=7, d=40), kc.case_geglu, kc.case_conv_in_out, kc.case_timestep_embedding,
+        kc.case_layout_and_misc, kc.case_window_loop, kc.case_cfg_affine_step,
+    ]
+    for fn in cases:
+        res = fn()
+        assert res["ok"], res
+
+
+# ---- 2. UNet3DConditionModel wiring: vs the reference's recorded outputs and vs the oracle -------------------------------
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_unet_wiring_matches_reference_golden(name, emulated):
+    """every golden case, including the 1/5-width ones whose head dims (8/16/32) the HIP attention kernels do not
+    serve -- the module wiring is width-independent"""
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    case = UNET_CASES[name]
+    _widths(emulated, case["arch"])
+    cfg = case_config(case)
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs, kw = case_inputs(case, cfg)
+    want = torch.from_numpy(np.load(os.path.join(GOLDEN, f"reference_unet_{name}.npz"))["out"])
+    model = _cpu(load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]))
+    got = model(x, t, encoder_hidden_states=ehs, return_dict=False, **kw)[0]
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL, f"{name}: |delta|max = {err}"
+    # second call: cached K/V projections / packed weights must give the same result
+    again = model(x, t, encoder_hidden_states=ehs, return_dict=False, **kw)[0]
+    assert torch.equal(got, again)
+
+
+def test_unet_rejects_cpu_tensors_by_default():
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    case = UNET_CASES["musev_narrow_2d"]
+    cfg = case_config(case)
+    model = load_unet_by_name("musev", sd_unet_model=unet3d.init_state_dict(cfg, 3), dtype=torch.float16, **case["arch"])
+    x, t, ehs, kw = case_inputs(case, cfg)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(x, t, encoder_hidden_states=ehs, **kw)
+
+
+# ---- 3. ReferenceNet2D wiring and the ReferenceNet -> UNet hand-over ------------------------------------------------------
+@pytest.mark.parametrize("name", list(REFNET_CASES))
+def test_referencenet_wiring_matches_reference_golden(name, emulated):
+    from oracle import referencenet as oref
+    from musev_amd.models.referencenet import load_referencenet_by_name
+    case = REFNET_CASES[name]
+    _widths(emulated, case["arch"])
+    cfg = oref.referencenet_config(**case["arch"])
+    sd = oref.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs = refnet_case_inputs(case, cfg)
+    net = _cpu(load_referencenet_by_name("musev_referencenet", sd, **case["arch"]))
+    down, mid, sa = net(x, t, encoder_hidden_states=ehs, num_frames=case["t"], return_ndim=5)
+    assert sa is None
+    gold = np.load(os.path.join(GOLDEN, f"reference_referencenet_{name}.npz"))
+    n_down = len([k for k in gold.files if k.startswith("down")])
+    assert len(down) == n_down
+    for i, d in enumerate(down):
+        want = torch.from_numpy(gold[f"down{i}"])
+        assert d.shape == want.shape, (i, d.shape, want.shape)
+        err = (d.float() - want).abs().max().item()
+        assert err < TOL, f"{name} down{i}: {err}"
+    assert (mid.float() - torch.from_numpy(gold["mid"])).abs().max().item() < TOL
+    # return_ndim = 4: the same features as (b t) c h w (referencenet.py:1018-1033)
+    down4, mid4, _ = net(x, t, encoder_hidden_states=ehs, num_frames=case["t"], return_ndim=4)
+    b = x.shape[0] // case["t"]
+    for d5, d4 in zip(list(down) + [mid], list(down4) + [mid4]):
+        assert torch.equal(d5.permute(0, 2, 1, 3, 4).reshape(b * case["t"], *d4.shape[1:]), d4)
+
+
+def test_referencenet_features_feed_the_unet(emulated):
+    """ReferenceNet2D -> UNet3DConditionModel(down_block_refer_embs=, mid_block_refer_emb=) on the module side against the
+    same chain in the oracle (pipeline_controlnet.py:867-964 -> :2045-2067)."""
+    from oracle import referencenet as oref
+    from oracle import unet3d
+    from musev_amd.models.referencenet import load_referencenet_by_name
+    from musev_amd.models.unet_loader import load_unet_by_name
+    case = UNET_CASES["refnet_narrow"]
+    _widths(emulated, case["arch"])
+    cfg = case_config(case)
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs, kw = case_inputs(case, cfg)
+    rcfg = oref.referencenet_config(block_out_channels=cfg["block_out_channels"])
+    rsd = oref.init_state_dict(rcfg, 21)
+    g = torch.Generator().manual_seed(77)
+    ref_img = torch.randn(1, 4, case["h"], case["w"], generator=g)  # one reference image, shared by both CFG halves
+    rtext = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g)
+    with torch.no_grad():
+        odown, omid = oref.referencenet_forward(rsd, rcfg, ref_img, torch.tensor(0), rtext, num_frames=1)
+    okw = dict(kw, down_block_refer_embs=[d.repeat(case["b"], 1, 1, 1, 1) for d in odown],
+               mid_block_refer_emb=omid.repeat(case["b"], 1, 1, 1, 1))
+    want = unet3d.unet3d_forward(sd, cfg, x, t, ehs, **okw)
+
+    net = _cpu(load_referencenet_by_name("musev_referencenet", rsd, block_out_channels=cfg["block_out_channels"]))
+    down, mid, _ = net(ref_img, torch.tensor(0), encoder_hidden_states=rtext, num_frames=1, return_ndim=5)
+    hkw = dict(kw, down_block_refer_embs=[d.repeat(case["b"], 1, 1, 1, 1) for d in down],
+               mid_block_refer_emb=mid.repeat(case["b"], 1, 1, 1, 1))
+    model = _cpu(load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]))
+    got = model(x, t, encoder_hidden_states=ehs, return_dict=False, **hkw)[0]
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL, f"|delta|max = {err}"
+
+
+# ---- 4. the denoise loop over the real module (not the closed-form fake UNet of test_parallel_sharding.py) -----------------
+@pytest.mark.parametrize("scheduler", ["ddim", "euler"])
+def test_denoise_loop_over_the_module(scheduler, emulated):
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    arch = UNET_CASES["musev_narrow"]["arch"]
+    _widths(emulated, arch)
+    cfg = unet3d.flavour_config("musev", **arch)
+    sd = unet3d.init_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(0)
+    T, win, ov, h, w = 8, 6, 2, 8, 8
+    latents = torch.randn(1, 4, T, h, w, generator=g)
+    sched = None
+    if scheduler == "euler":
+        from musev_amd.schedulers import EulerDiscreteScheduler
+        sched = EulerDiscreteScheduler()
+        sched.set_timesteps(20)
+        latents = latents * sched.init_noise_sigma
+    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    kw = dict(num_inference_steps=20, max_steps=2, guidance_scale=3.5, condition_latents=cond, motion_speed=8.0)
+    want = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt,
+                              context_frames=win, context_overlap=ov, scheduler=scheduler, **kw)
+    unet = _cpu(load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **arch))
+    den = ParallelDenoiser(unet, scheduler=sched, context_frames=win, context_overlap=ov)
+    den._device_check = False
+    got = den(latents, prompt, **kw)
+    assert got.shape == want.shape
+    # Euler works on sigma-scaled latents (init_noise_sigma ~ 14.6): the bound scales with the latent magnitude
+    scale = max(1.0, float(want.abs().max()) / 4.0)
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL * scale, f"|delta latent|max = {err} (scale {scale})"
+    assert torch.equal(got[:, :, 0].float(), want[:, :, 0])

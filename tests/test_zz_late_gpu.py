@@ -1,7 +1,12 @@
 """-m gpu, LAST in collection order on purpose: GPU checks written after round 1's GPU budget was spent (the Euler-discrete
-loop, its fused step kernel, the full-size batch-independence property).  They exercise code whose CPU-side logic is tested
-(tests/test_oracle_golden.py, tests/test_parallel_sharding.py) but which had not run on a GPU when they were written; keeping
-them at the end means a surprise here cannot hide the results of the tests above under `pytest -x`."""
+loop, its fused step kernel, the full-size batch-independence property, ReferenceNet2D on HIP kernels).  They exercise code
+whose host side is tested on the CPU against the oracle and the reference's recorded outputs with the kernels emulated
+(tests/test_emulated_wiring.py, tests/test_oracle_golden.py, tests/test_parallel_sharding.py) but which had not run on a GPU
+when they were written; keeping them at the end means a surprise here cannot hide the results of the tests above under
+`pytest -x`."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -83,3 +88,30 @@ def test_full_size_batch_independence():
         err = (one - both[i:i + 1]).abs().max().item()
         assert err < 5e-3, f"CFG half {i}: batch-1 vs batch-2 forward differ by {err}"
     assert (both[0] - both[1]).abs().max().item() > 1e-3, "the halves see different prompts and must differ"
+
+
+def test_referencenet_matches_reference_golden_and_oracle():
+    """ReferenceNet2D on HIP kernels against the oracle and against the feature maps recorded from the
+    reference's own ReferenceNet2D (tests/golden/reference_referencenet_hipw.npz)."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from golden_cases import REFNET_CASES, refnet_case_inputs
+    from oracle import referencenet as oref
+    from musev_amd.models.referencenet import load_referencenet_by_name
+    case = REFNET_CASES["hipw"]
+    cfg = oref.referencenet_config(**case["arch"])
+    sd = oref.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs = refnet_case_inputs(case, cfg)
+    net = load_referencenet_by_name("musev_referencenet", sd, **case["arch"]).to("cuda")
+    down, mid, sa = net(x.to("cuda"), t.to("cuda"), encoder_hidden_states=ehs.to("cuda"), num_frames=case["t"], return_ndim=5)
+    torch.cuda.synchronize()
+    assert sa is None
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_referencenet_hipw.npz"))
+    with torch.no_grad():
+        odown, omid = oref.referencenet_forward(sd, cfg, x, t, ehs, num_frames=case["t"])
+    assert len(down) == len(odown)
+    for i, d in enumerate(down):
+        want = torch.from_numpy(gold[f"down{i}"])
+        assert d.shape == want.shape
+        assert (d.float().cpu() - want).abs().max().item() < 1e-2, f"down{i} vs reference"
+        assert (d.float().cpu() - odown[i]).abs().max().item() < 1e-2, f"down{i} vs oracle"
+    assert (mid.float().cpu() - torch.from_numpy(gold["mid"])).abs().max().item() < 1e-2

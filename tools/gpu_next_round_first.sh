@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # First GPU call of the next round (about 6 GPU-minutes): validates what round 1 could not.
-#   1. pytest -m gpu_pending            (ReferenceNet2D on HIP kernels vs oracle + reference golden)
+#   1. pytest tests/test_zz_late_gpu.py (checks written after round 1's GPU budget was spent: Euler loop, ReferenceNet2D, ...)
 #   2. tools/gpu_bigtile_diag.sh        (why bench.py with MUSEV_GEMM_VARIANT=8 -- 256x320 / 256x256 tiles -- stalled in r01n)
 #   3. bench.py with the big tiles if (2) is clean: expected -3..-4 ms per step
 set -u
@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-( timeout 300 python -m pytest tests -m gpu_pending -x -q 2>&1 | tail -8 ) > $OUT/${TAG}_pytest_pending.log
+( timeout 300 python -m pytest tests/test_zz_late_gpu.py -m gpu -q 2>&1 | tail -8 ) > $OUT/${TAG}_pytest_pending.log
 cat $OUT/${TAG}_pytest_pending.log
 bash tools/gpu_bigtile_diag.sh $TAG
 ( MUSEV_GEMM_VARIANT=8 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200 ) > $OUT/${TAG}_bench_v8.log
