@@ -840,10 +840,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused
         float* stg = reinterpret_cast<float*>(smem);
         static_assert(NW * 32 * (16 * TN + 4) * 4 <= NST * (BM + BN) * BK * 2, "output staging does not fit the operand LDS");
+        // 16-row tiles staged per pass: the 128-row wave tiles of the 256-row blocks sit at the 256-register cap, where the
+        // residual prefetch of a 32-row pass (20 registers) spilled an accumulator to scratch; 16-row passes keep it in registers
+        constexpr int EIT = (TM >= 8) ? 1 : 2;
         if (p.geglu) {
-            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, 2>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
+            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, EIT>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
         } else {
-            epilogue_staged<TM, TN, false, 2>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
+            epilogue_staged<TM, TN, false, EIT>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
         }
         return;
     }
