@@ -79,6 +79,14 @@ int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
  * 6 = BK-32 four-stage ring, 7 = 256x320 tiles wherever they fit, 8 = 2 + 256x256 tiles for the GEGLU GEMM */
 int mv_set_gemm_variant(int variant);
 
+/* workgroup -> output-tile order of the implicit-GEMM kernel: logical ids (contiguous per XCD) walk groups of `group`
+ * m-tiles m-fastest when the grid is more than `group` n-tiles wide, so that the ~64 blocks resident on one XCD cover
+ * ~8 x 8 tiles (what its L2 must fetch per window) instead of 1-3 m-tiles x the whole weight matrix.  Default 8;
+ * 0 = plain m-major (A/B knob).  Results are independent of the order. */
+int mv_set_gemm_tile_group(int group);
+/* host-side evaluation of that map (launches nothing): tile_m[b], tile_n[b] of workgroup b, for b < tiles_m*tiles_n */
+int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int32_t* tile_n);
+
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
  * replaces: torch.nn.GroupNorm(32, C)(+SiLU) in ResnetBlock2D.norm1/norm2, Transformer2DModel.norm
  *   (musev/models/transformer_2d.py:260), TransformerTemporalModel.norm (temporal_transformer.py:117,239),

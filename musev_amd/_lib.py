@@ -61,6 +61,8 @@ SIGNATURES = {
     "mv_last_error": (C.c_char_p, []),
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "mv_set_gemm_variant": (_i32, [_i32]),
+    "mv_set_gemm_tile_group": (_i32, [_i32]),
+    "mv_gemm_tile_order": (_i32, [_i32, _i32, _i32, _vp, _vp]),
     "mv_groupnorm_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
                                 _vp, _i32, _vp, _vp]),
     "mv_groupnorm_partial_floats": (_i64, [_i64, _i32, _i32]),
@@ -110,6 +112,9 @@ def load() -> C.CDLL:
     variant = os.environ.get("MUSEV_GEMM_VARIANT")  # tuning knob for A/B runs (see mv_set_gemm_variant)
     if variant is not None:
         lib.mv_set_gemm_variant(int(variant))
+    group = os.environ.get("MUSEV_GEMM_TILE_GROUP")  # 0 = plain m-major tile order (see mv_set_gemm_tile_group)
+    if group is not None:
+        lib.mv_set_gemm_tile_group(int(group))
     variant = os.environ.get("MUSEV_ATTN_VARIANT")
     if variant is not None:
         lib.mv_set_attn_variant(int(variant))

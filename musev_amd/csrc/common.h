@@ -68,10 +68,36 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // XCD-aware bijective remap of a linear workgroup id: blocks that the dispatcher places on the same XCD
 // (observed: id % 8) get a contiguous range of logical ids, so neighbouring tiles share that XCD's L2.
-__device__ __forceinline__ int mv_xcd_remap(int bid, int nwg) {
+__host__ __device__ __forceinline__ int mv_xcd_remap(int bid, int nwg) {
     const int nx = 8;
     int xcd = bid % nx, k = bid / nx;
     int q = nwg / nx, r = nwg % nx;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
+}
+
+// Logical id -> output tile.  An XCD runs a sliding window of ~64 consecutive logical ids (32 CUs x 2 resident blocks);
+// what its 4 MB L2 has to fetch for that window is (distinct m-tiles) x BM x K + (distinct n-tiles) x BN x K halfs.  With
+// plain m-major order and a wide N (the GEGLU projections: 20 / 40 / 80 n-tiles; fused QKV: 24) a window is 1-3 m-tiles x
+// ALL n-tiles, i.e. every window streams most of the weight matrix again.  Groups of MV_TILE_GROUP m-tiles walked m-fastest
+// make the window ~8 x 8 tiles instead (group = MV_TILE_GROUP; 0 / 1 = plain m-major, the A/B knob) (the fetch per window drops from (1 + tiles_n) to 16 tile-slabs).  For tiles_n <= 8 the
+// m-major window already is 8 m-tiles (or more) x tiles_n, and the order is left exactly as it was.  Any order is a
+// bijection onto the tile grid, each tile is still reduced over K in the same order by one block: results do not change.
+#define MV_TILE_GROUP 8
+__host__ __device__ __forceinline__ void mv_tile_order(int id, int tiles_m, int tiles_n, int group, int* tile_m, int* tile_n) {
+    if (group <= 1 || tiles_n <= group) {
+        const int tm = id / tiles_n;
+        *tile_m = tm;
+        *tile_n = id - tm * tiles_n;
+        return;
+    }
+    const int per_group = group * tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * group;
+    const int rest = tiles_m - first_m;
+    const int gsz = rest < group ? rest : group;  // the last group may be shorter
+    const int r = id - grp * per_group;
+    const int tn = r / gsz;
+    *tile_m = first_m + (r - tn * gsz);
+    *tile_n = tn;
 }

@@ -38,6 +38,7 @@ struct GemmArgs {
     int t, hw;
     int rows_per_group, act, geglu;
     int tiles_m, tiles_n;
+    int tile_group;  // mv_tile_order group size (0: m-major)
 };
 
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[4];  // 64 zero bytes: target of predicated-off loads
@@ -384,6 +385,7 @@ int launch_cfg_s(const GemmArgs& a0, hipStream_t stream) {
     return MV_OK;
 }
 
+int g_gemm_tile_group = MV_TILE_GROUP;  // mv_tile_order group size of the v2 kernel (mv_set_gemm_tile_group; 0 = m-major)
 int g_gemm_stage = 2;  // tuning knob (mv_set_gemm_variant): 0 register staging, 1 LDS-DMA, 2 v2 kernel, 3 v2 + 8-wave tiles,
                        // 4 persistent v3 kernel, 5 v2 + 8-wave tiles on a 3-stage counted-wait ring, 6 BK-32 4-stage ring,
                        // 7 256x320 tiles wherever they fit, 8 = 2 + 256x256 tiles for the GEGLU GEMM
@@ -606,7 +608,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = mv_xcd_remap(blockIdx.x, nwg);
-    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    mv_tile_order(id, p.tiles_m, p.tiles_n, p.tile_group, &tile_m, &tile_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int Mi = (int)p.M;
@@ -1119,6 +1122,7 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     GemmArgs2 a = a0;
     a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
     a.g.tiles_n = (a.g.N + BN - 1) / BN;
+    a.g.tile_group = g_gemm_tile_group;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED>),
@@ -1204,6 +1208,27 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 extern "C" int mv_set_gemm_variant(int v) {
     MV_REQUIRE(v >= 0 && v <= 8, "mv_set_gemm_variant: variant %d not in [0, 8]", v);
     g_gemm_stage = v;
+    return MV_OK;
+}
+
+extern "C" int mv_set_gemm_tile_group(int group) {
+    MV_REQUIRE(group >= 0 && group <= 64, "mv_set_gemm_tile_group: group %d not in [0, 64]", group);
+    g_gemm_tile_group = group;
+    return MV_OK;
+}
+
+// host-side evaluation of the workgroup -> tile map the v2 kernel uses (the same inline functions): introspection for
+// tests and for reasoning about L2 locality; launches nothing
+extern "C" int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int32_t* tile_n) {
+    MV_REQUIRE(tiles_m > 0 && tiles_n > 0 && (long)tiles_m * tiles_n < (1L << 31) && tile_m && tile_n && group >= 0,
+               "mv_gemm_tile_order: bad args");
+    const int nwg = tiles_m * tiles_n;
+    for (int b = 0; b < nwg; ++b) {
+        int tm, tn;
+        mv_tile_order(mv_xcd_remap(b, nwg), tiles_m, tiles_n, group, &tm, &tn);
+        tile_m[b] = tm;
+        tile_n[b] = tn;
+    }
     return MV_OK;
 }
 

@@ -58,3 +58,56 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.MuseVHipError):
         _lib.load()
+
+
+# ---- workgroup -> tile order of the implicit-GEMM kernel (host evaluation of the kernel's own inline map) -----------------
+def _tile_order(tiles_m, tiles_n, group):
+    import numpy as np
+    from musev_amd import _lib
+    lib = _lib.load()
+    n = tiles_m * tiles_n
+    tm = np.full(n, -1, dtype=np.int32)
+    tn = np.full(n, -1, dtype=np.int32)
+    assert lib.mv_gemm_tile_order(tiles_m, tiles_n, group, tm.ctypes.data, tn.ctypes.data) == 0
+    return tm, tn
+
+
+# (tiles_m, tiles_n) of every GEMM shape class of config 2 (M = 106496 / 26624 / 6656 / 1664 rows over 128- and 256-row
+# tiles; N = 320 ... 10240 over 160- / 128- / 256- / 320-wide tiles) plus ragged and degenerate grids
+_GRIDS = [(832, 2), (832, 6), (832, 20), (416, 10), (208, 4), (208, 12), (208, 40), (104, 20), (52, 8), (52, 24), (52, 80),
+          (26, 40), (13, 8), (13, 80), (7, 9), (1, 1), (1, 37), (37, 1), (9, 9), (8, 9), (17, 64), (3, 100)]
+
+
+@pytest.mark.parametrize("group", [0, 8, 5])
+def test_tile_order_is_a_bijection(group):
+    """every output tile is produced by exactly one workgroup, for any grid and group size (so results cannot depend on
+    the order); group 0 and grids at most `group` n-tiles wide keep the plain m-major order"""
+    import numpy as np
+    for tiles_m, tiles_n in _GRIDS:
+        tm, tn = _tile_order(tiles_m, tiles_n, group)
+        assert tm.min() == 0 and tm.max() == tiles_m - 1 and tn.min() == 0 and tn.max() == tiles_n - 1
+        flat = tm.astype(np.int64) * tiles_n + tn
+        assert len(np.unique(flat)) == tiles_m * tiles_n, (tiles_m, tiles_n, group)
+        if group <= 1 or tiles_n <= group:
+            tm0, tn0 = _tile_order(tiles_m, tiles_n, 0)
+            assert (tm == tm0).all() and (tn == tn0).all()
+
+
+def test_tile_order_window_locality():
+    """what an XCD's L2 must fetch for the ~64 workgroups resident on it: (distinct m-tiles + distinct n-tiles) of 64
+    consecutive workgroups of ONE XCD (workgroup ids = xcd mod 8).  Wide grids: ~16 tile-slabs grouped vs ~(1 + 64)
+    m-major."""
+    import numpy as np
+    for tiles_m, tiles_n in [(52, 80), (208, 40), (832, 20), (52, 24)]:
+        worst, mean = {}, {}
+        for group in (0, 8):
+            tm, tn = _tile_order(tiles_m, tiles_n, group)
+            costs = []
+            for xcd in range(8):
+                ids = np.arange(xcd, tiles_m * tiles_n, 8)
+                for s in range(0, len(ids) - 63, 16):
+                    w = ids[s:s + 64]
+                    costs.append(len(np.unique(tm[w])) + len(np.unique(tn[w])))
+            worst[group], mean[group] = max(costs), float(np.mean(costs))
+        assert worst[8] <= 32, (tiles_m, tiles_n, worst)        # 8 x 8 window = 16, up to ~2x across a group boundary
+        assert worst[8] <= worst[0] and mean[8] < 0.9 * mean[0], (tiles_m, tiles_n, worst, mean)

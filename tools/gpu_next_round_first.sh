@@ -14,3 +14,7 @@ cat $OUT/${TAG}_pytest_pending.log
 bash tools/gpu_bigtile_diag.sh $TAG
 ( MUSEV_GEMM_VARIANT=8 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200 ) > $OUT/${TAG}_bench_v8.log
 cat $OUT/${TAG}_bench_v8.log
+# 4. tile order A/B (written after round 1's GPU budget): default (groups of 8 m-tiles on wide grids) vs plain m-major
+( MUSEV_GEMM_TILE_GROUP=0 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200 ) > $OUT/${TAG}_bench_mmajor.log
+( timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200 ) > $OUT/${TAG}_bench_grouped.log
+cat $OUT/${TAG}_bench_mmajor.log $OUT/${TAG}_bench_grouped.log
