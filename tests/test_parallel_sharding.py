@@ -63,7 +63,9 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process_and_oracle():
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_gloo_matches_single_process_and_oracle(world):
+    """world 2: 8 units -> 4 + 4; world 3: 3 + 3 + 2 (the last rank's unused exchange slot must not be accumulated)"""
     single, (lat, cond, prompt) = _run_loop(None)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -71,8 +73,9 @@ def test_two_rank_gloo_matches_single_process_and_oracle():
     s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    assert torch.equal(ret[0], ret[1]), "replicated latents diverged between ranks"
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(1, world):
+        assert torch.equal(ret[0], ret[r]), "replicated latents diverged between ranks"
     # the 2-rank run exchanges fp16 predictions exactly like the 1-rank run consumes them -> identical results
     assert torch.equal(ret[0], single)
     from oracle import pipeline as opipe
