@@ -221,11 +221,19 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
         for (int qt = 0; qt < C::QT; ++qt) {
             float mx;
             if constexpr (OPT >= 1) {
-                float m4[4];
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    m4[st] = fmaxf(fmaxf(acc_s[qt][st][0], acc_s[qt][st][1]), fmaxf(acc_s[qt][st][2], acc_s[qt][st][3]));
-                mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+                // 16 scores -> 1 in a tree of 3-input maxima.  Written as fmaxf(fmaxf(a, b), c) throughout: that shape
+                // selects v_max3_f32 on the raw MFMA results, whereas a 2-input fmaxf of two accumulator registers is
+                // preceded by a canonicalising v_max_f32 x, x per operand (10 VALU ops instead of ~25; the maximum
+                // itself is exact in any association, so the result does not change)
+                const float4v &s0 = acc_s[qt][0], &s1 = acc_s[qt][1], &s2 = acc_s[qt][2], &s3 = acc_s[qt][3];
+                const float t0 = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
+                const float t1 = fmaxf(fmaxf(s0[3], s1[0]), s1[1]);
+                const float t2 = fmaxf(fmaxf(s1[2], s1[3]), s2[0]);
+                const float t3 = fmaxf(fmaxf(s2[1], s2[2]), s2[3]);
+                const float t4 = fmaxf(fmaxf(s3[0], s3[1]), s3[2]);
+                const float u0 = fmaxf(fmaxf(t0, t1), t2);
+                const float u1 = fmaxf(fmaxf(t3, t4), s3[3]);
+                mx = fmaxf(u0, u1);
             } else {
                 mx = -INFINITY;
 #pragma unroll
