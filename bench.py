@@ -382,6 +382,11 @@ def main():
                                    f"window {win} overlap 4 -> {n_windows} window(s) x 2 CFG halves = {n_windows * 2} units over {world} GPU(s), "
                                    f"{DENOISE_STEPS} DDIM steps, guidance 3.5",
                        "frames": T, "windows": n_windows, "units_per_gpu_max": max(len(s) for s in shards),
+                       # every window forward denoises 12 frames; with overlap 4 the closed-loop schedule needs N windows for
+                       # 8N unique frames (N >= 2), so at fixed per-GPU work (one window per GPU) the unique-frame rate of a
+                       # PERFECTLY parallel run is 8N/12 of N x the single-window rate -- the algorithm's overlap, not a loss
+                       "window_frames_per_s": n_windows * win / (DENOISE_STEPS * ms_per_step / 1e3),
+                       "ideal_value_vs_n1": (T / 12.0) if workload == "weak" else None,
                        "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
                        "output_finite": finite},
             "roofline": roofline, "cpu_baseline": cpu,
