@@ -24,6 +24,7 @@ import torch
 
 from .. import ops
 from ..schedulers.scheduling_ddim import DDIMScheduler  # default; EulerDiscreteScheduler offers the same loop interface
+from ..utils.timesteps_util import generate_parameters_with_timesteps
 from .context import prepare_global_context
 
 
@@ -87,10 +88,13 @@ class ParallelDenoiser:
     def __call__(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, *, num_inference_steps: int = 20,
                  guidance_scale: float = 7.5, condition_latents: Optional[torch.Tensor] = None, motion_speed: float = 8.0,
                  unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
-                 reinsert_condition: bool = True, max_steps: Optional[int] = None) -> torch.Tensor:
+                 reinsert_condition: bool = True, max_steps: Optional[int] = None, guidance_scale_end: Optional[float] = None,
+                 guidance_scale_method: str = "linear") -> torch.Tensor:
         """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
         [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
         ``group``: torch.distributed process group to shard the units over (None = this process alone).
+        ``guidance_scale_end`` / ``guidance_scale_method``: per-step guidance schedule from guidance_scale to
+        guidance_scale_end ("linear", "two_stage", "three_stage", "fix_two_stage"; reference :1718-1723, :2103).
         ``max_steps``: run only the first max_steps steps of the num_inference_steps-long schedule (smoke / bench helper).
         Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
         if latents.ndim != 5 or latents.shape[0] != 1:
@@ -116,6 +120,8 @@ class ParallelDenoiser:
         sched = self.scheduler
         sched.set_timesteps(num_inference_steps)
         timesteps = [float(t) for t in sched.timesteps.tolist()]  # integral for DDIM, fractional for Euler ("linspace")
+        guidance = [float(g) for g in generate_parameters_with_timesteps(start=guidance_scale, stop=guidance_scale_end,
+                                                                        num=len(timesteps), method=guidance_scale_method)]
         wins = self.windows(T, num_inference_steps)
         win_len = len(wins[0])
         if any(len(wd) != win_len for wd in wins):
@@ -170,7 +176,7 @@ class ParallelDenoiser:
                 for r in range(world):  # fixed accumulation order on every rank -> bit-identical replicas
                     for k, u in enumerate(shards[r]):
                         ops.window_scatter_add(recv[r * max_units + k], idx_dev[u.window], 0, 1, u.half, eps_acc, counter, False)
-            sched.loop_update(lat, eps_acc, counter, float(guidance_scale), step, t)
+            sched.loop_update(lat, eps_acc, counter, guidance[step], step, t)
             if callback is not None:
                 callback(step, t, lat)
 

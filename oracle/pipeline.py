@@ -159,13 +159,44 @@ class EulerOracle:
         return sample + derivative * dt                            # :162
 
 
+# ---- loop utilities: guidance-scale schedule and initial noise ---------------------------------------------------------
+def guidance_schedule(start, num: int, stop=None, method: str = "linear", n_fix_start: int = 3) -> List[float]:
+    """musev/utils/timesteps_util.py:5-61 restated (the pipeline calls it with start = guidance_scale,
+    stop = guidance_scale_end, num = len(timesteps): pipeline_controlnet.py:1718-1723)."""
+    if stop is None or start == stop:                                   # :12-13
+        return [start] * num
+    if method == "linear":                                              # :30-38
+        return [float(v) for v in np.linspace(start, stop, num)]
+    if method == "two_stage":                                           # :41-45
+        return [start] * (num // 2) + [stop] * (num - num // 2)
+    if method == "three_stage":                                         # :55-61 (integer midpoint)
+        k = num // 3
+        return [start] * k + [(start + stop) // 2] * k + [stop] * (num - 2 * k)
+    if method == "fix_two_stage":                                       # :48-52
+        return [start] * n_fix_start + [stop] * (num - n_fix_start)
+    raise ValueError(method)                                            # :23-26
+
+
+def fusion_noise(shape, generator, w_ind_noise: float = 0.5, initial_common_noise: Optional[Tensor] = None) -> Tensor:
+    """musev/utils/noise_util.py:31-83 (fp32, CPU): the common [b, c, 1, h, w] noise is drawn first, then the individual
+    [b, c, t, h, w] noise; a list of generators draws item by item (:69-82)."""
+    if isinstance(generator, list):
+        return torch.cat([fusion_noise((1, *shape[1:]), g, w_ind_noise, initial_common_noise) for g in generator], dim=0)
+    b, c, t, h, w = shape
+    common = initial_common_noise if initial_common_noise is not None else torch.randn((b, c, 1, h, w), generator=generator)
+    ind = torch.randn(tuple(shape), generator=generator)
+    s = torch.tensor(w_ind_noise)
+    return torch.sqrt(1 - s) * common + torch.sqrt(s) * ind               # :67-68
+
+
 # ---- the loop --------------------------------------------------------------------------------------------
 def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds: Tensor, *, num_inference_steps: int,
                  guidance_scale: float, condition_latents: Optional[Tensor] = None, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
                  context_batch_size: int = 1, motion_speed: float = 8.0, unet_kwargs: Optional[dict] = None,
                  record: Optional[list] = None, max_steps: Optional[int] = None, scheduler: str = "ddim",
-                 scheduler_kwargs: Optional[dict] = None) -> Tensor:
+                 scheduler_kwargs: Optional[dict] = None, guidance_scale_end: Optional[float] = None,
+                 guidance_scale_method: str = "linear") -> Tensor:
     """pipeline_controlnet.py:1832-2156.  ``max_steps`` (test helper, not in the reference): stop after the first
     max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
@@ -180,7 +211,7 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
     vis_idx = torch.arange(n_cond, dtype=torch.long) if n_cond else None      # vision_condition_latent_index
     T = latents.shape[2]
     latent_index = torch.arange(n_cond, n_cond + T, dtype=torch.long) if n_cond else None
-    gscales = [guidance_scale] * num_inference_steps                            # timesteps_util.py:12-13
+    gscales = guidance_schedule(guidance_scale, num_inference_steps, guidance_scale_end, guidance_scale_method)  # :1718-1723
     global_context = prepare_global_context(context_schedule, num_inference_steps, T, context_frames, context_stride,
                                             context_overlap, context_batch_size)
     for i, t in enumerate(sched.timesteps):

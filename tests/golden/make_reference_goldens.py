@@ -16,6 +16,8 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
   * reference_euler.npz         musev/schedulers/scheduling_euler_discrete.py EulerDiscreteScheduler.step (s_churn = 0)
   * reference_datautil.npz      musev/data/data_util.py index helpers used by the loop
   * reference_referencenet_*.npz musev/models/referencenet.py ReferenceNet2D.forward (block-embedding mode): 12 + 1 feature maps
+  * reference_loop_utils.json / .npz  musev/utils/timesteps_util.py generate_parameters_with_timesteps (guidance schedule) and
+                                musev/utils/noise_util.py random_noise / video_fusion_noise (initial latents)
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
 from __future__ import annotations
@@ -183,7 +185,39 @@ def gen_referencenet():
         print("referencenet", name, len(down), [tuple(d.shape) for d in down[:2]], tuple(mid.shape), "absmax", float(mid.abs().max()))
 
 
+# the argument table is shared with tests/test_oracle_golden.py through golden_cases.py
+def gen_loop_utils():
+    from golden_cases import GUIDANCE_CASES, NOISE_CASES
+    from musev.utils import noise_util as rn
+    from musev.utils import timesteps_util as rt
+    table = []
+    for kw in GUIDANCE_CASES:
+        try:
+            out = [float(v) for v in rt.generate_parameters_with_timesteps(**kw)]
+        except ValueError as ex:
+            out = {"raises": "ValueError"}
+        table.append({"args": kw, "out": out})
+    with open(os.path.join(HERE, "reference_loop_utils.json"), "w") as fjs:
+        json.dump(table, fjs, indent=0)
+    arrays = {}
+    for name, c in NOISE_CASES.items():
+        shape = tuple(c["shape"])
+        gen = [torch.Generator().manual_seed(sd) for sd in c["seeds"]] if c.get("per_item") else torch.Generator().manual_seed(c["seeds"][0])
+        if c["kind"] == "random":
+            out = rn.random_noise(shape=shape, dtype=torch.float32, device="cpu", generator=gen)
+        else:
+            common = None
+            if c.get("common_seed") is not None:
+                common = torch.randn(shape[0], shape[1], 1, shape[3], shape[4], generator=torch.Generator().manual_seed(c["common_seed"]))
+            out = rn.video_fusion_noise(shape=shape, dtype=torch.float32, device="cpu", generator=gen, w_ind_noise=c["w"],
+                                        initial_common_noise=common)
+        arrays[name] = out.numpy()
+    np.savez_compressed(os.path.join(HERE, "reference_loop_utils.npz"), **arrays)
+    print("loop utils:", len(table), "guidance cases,", len(arrays), "noise cases")
+
+
 if __name__ == "__main__":
+    gen_loop_utils()
     gen_context()
     gen_ddim()
     gen_euler()

@@ -530,6 +530,12 @@ class DiffusersEulerDiscreteScheduler(SchedulerMixin, ConfigMixin):
 
 
 def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    """diffusers.utils.torch_utils.randn_tensor (upstream v0.24): a list of generators draws one batch item each"""
+    if isinstance(generator, list) and len(generator) == 1:
+        generator = generator[0]
+    if isinstance(generator, list):
+        item = (1,) + tuple(shape)[1:]
+        return torch.cat([torch.randn(item, generator=g, device=device, dtype=dtype) for g in generator], dim=0)
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)
 
 

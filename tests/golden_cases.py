@@ -107,3 +107,22 @@ def refnet_case_inputs(case: dict, cfg: dict):
     x = torch.randn(n, cfg["in_channels"], case["h"], case["w"], generator=g)
     ehs = torch.randn(n, 4, cfg["cross_attention_dim"], generator=g)  # the pipeline feeds the IP-Adapter image tokens (4 per image)
     return x, torch.tensor(case["timestep"]), ehs
+
+
+
+# ---- loop utilities: guidance-scale schedule and initial-noise construction ------------------------------
+GUIDANCE_CASES = [
+    dict(start=7.5, num=20), dict(start=7.5, num=20, stop=7.5), dict(start=7.5, num=20, stop=3.0),
+    dict(start=7.5, num=7, stop=3.0, method="linear"), dict(start=8, num=20, stop=2, method="two_stage"),
+    dict(start=8, num=7, stop=3, method="two_stage"), dict(start=8, num=20, stop=3, method="three_stage"),
+    dict(start=7.5, num=10, stop=3.0, method="three_stage"), dict(start=8, num=20, stop=2, method="fix_two_stage"),
+    dict(start=8, num=20, stop=2, method="fix_two_stage", n_fix_start=5), dict(start=8, num=4, stop=2, method="cosine"),
+]
+NOISE_CASES = {
+    "random": dict(kind="random", shape=(2, 4, 5, 6, 6), seeds=[11]),
+    "random_per_item": dict(kind="random", shape=(2, 4, 5, 6, 6), seeds=[12, 13], per_item=True),
+    "fusion": dict(kind="fusion", shape=(1, 4, 12, 8, 8), seeds=[14], w=0.5),
+    "fusion_w02_b2": dict(kind="fusion", shape=(2, 4, 6, 8, 8), seeds=[15], w=0.2),
+    "fusion_per_item": dict(kind="fusion", shape=(2, 4, 6, 8, 8), seeds=[16, 17], w=0.5, per_item=True),
+    "fusion_given_common": dict(kind="fusion", shape=(1, 4, 6, 8, 8), seeds=[18], w=0.7, common_seed=19),
+}

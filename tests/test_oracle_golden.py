@@ -162,3 +162,63 @@ def test_oracle_referencenet_matches_reference(name):
         assert d.shape == want.shape
         assert torch.allclose(d, want, rtol=1e-4, atol=2e-4), (name, i, (d - want).abs().max())
     assert torch.allclose(mid, torch.from_numpy(gold["mid"]), rtol=1e-4, atol=2e-4)
+
+
+# ---- loop utilities: guidance schedule + initial noise, oracle AND product host code vs the reference ----
+def test_guidance_schedule_matches_reference():
+    """musev/utils/timesteps_util.py executed by tests/golden/make_reference_goldens.py -> reference_loop_utils.json"""
+    from oracle.pipeline import guidance_schedule
+    from musev_amd.utils.timesteps_util import generate_parameters_with_timesteps
+    table = json.load(open(os.path.join(GOLD, "reference_loop_utils.json")))
+    assert len(table) >= 10
+    for row in table:
+        kw = row["args"]
+        if isinstance(row["out"], dict):  # the reference raises ValueError for an unknown method
+            with pytest.raises(ValueError):
+                guidance_schedule(kw["start"], kw["num"], kw.get("stop"), kw.get("method", "linear"), kw.get("n_fix_start", 3))
+            with pytest.raises(ValueError):
+                generate_parameters_with_timesteps(**kw)
+            continue
+        got_o = guidance_schedule(kw["start"], kw["num"], kw.get("stop"), kw.get("method", "linear"), kw.get("n_fix_start", 3))
+        got_p = generate_parameters_with_timesteps(**kw)
+        assert [float(v) for v in got_o] == row["out"], kw
+        assert [float(v) for v in got_p] == row["out"], kw
+
+
+def test_initial_noise_matches_reference():
+    """musev/utils/noise_util.py random_noise / video_fusion_noise on seeded generators: the same draws in the same order
+    (bit-exact), for the oracle restatement and for the product's musev_amd.utils.noise_util"""
+    from golden_cases import NOISE_CASES
+    from oracle.pipeline import fusion_noise
+    from musev_amd.utils import noise_util as pn
+    gold = np.load(os.path.join(GOLD, "reference_loop_utils.npz"))
+    for name, c in NOISE_CASES.items():
+        shape = tuple(c["shape"])
+
+        def gens():
+            return [torch.Generator().manual_seed(sd) for sd in c["seeds"]] if c.get("per_item") else torch.Generator().manual_seed(c["seeds"][0])
+
+        want = torch.from_numpy(gold[name])
+        if c["kind"] == "random":
+            got = pn.random_noise(shape=shape, dtype=torch.float32, device="cpu", generator=gens())
+            assert torch.equal(got, want), name
+            continue
+        common = None
+        if c.get("common_seed") is not None:
+            common = torch.randn(shape[0], shape[1], 1, shape[3], shape[4], generator=torch.Generator().manual_seed(c["common_seed"]))
+        got = pn.video_fusion_noise(shape=shape, dtype=torch.float32, device="cpu", generator=gens(), w_ind_noise=c["w"],
+                                    initial_common_noise=common)
+        assert torch.equal(got, want), name
+        assert torch.equal(fusion_noise(shape, gens(), c["w"], common), want), name
+        # the text2video branch of prepare_latents: the same noise times init_noise_sigma
+        lat = pn.prepare_noise_latents(shape, dtype=torch.float32, device="cpu", generator=gens(), noise_type="video_fusion",
+                                       w_ind_noise=c["w"], initial_common_latent=common, init_noise_sigma=14.6146)
+        assert torch.equal(lat, want * 14.6146), name
+    with pytest.raises(ValueError):
+        pn.video_fusion_noise(shape=(2, 4, 3, 2, 2), dtype=torch.float32, device="cpu", generator=[torch.Generator()])
+    # image-based video noise (pipeline_controlnet.py:325-344): sqrt(w) * mean_t(cond) + sqrt(1 - w) * noise
+    noise = torch.randn(1, 4, 5, 3, 3, generator=torch.Generator().manual_seed(1))
+    cond = torch.randn(1, 4, 2, 3, 3, generator=torch.Generator().manual_seed(2))
+    mixed = pn.img_based_video_noise(noise, cond, img_weight=1e-3)
+    ref = 1e-3 ** 0.5 * cond.mean(dim=2, keepdim=True).repeat(1, 1, 5, 1, 1) + (1 - 1e-3) ** 0.5 * noise
+    assert torch.equal(mixed, ref)

@@ -36,7 +36,7 @@ def _patch(monkeypatch_like):
         monkeypatch_like(ops, name, getattr(fake_ops, name))
 
 
-def _run_loop(group=None, scheduler=None):
+def _run_loop(group=None, scheduler=None, **loop_kw):
     from musev_amd import ops
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
     saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step")}
@@ -48,7 +48,7 @@ def _run_loop(group=None, scheduler=None):
         cond = torch.randn(1, 4, 1, 4, 4, generator=g)
         prompt = torch.randn(2, 7, 16, generator=g)
         den = ParallelDenoiser(fake_ops.FakeUNet(), scheduler=scheduler, context_frames=8, context_overlap=2)
-        return den(lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond, group=group), (lat, cond, prompt)
+        return den(lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond, group=group, **loop_kw), (lat, cond, prompt)
     finally:
         ParallelDenoiser._device_check = True
         for n, f in saved.items():
@@ -97,3 +97,18 @@ def test_euler_loop_matches_oracle_loop():
     assert got.shape == want.shape
     # Euler latents live in sigma-scaled space (sigma_max = 14.6): compare relative to that scale
     assert (got - want).abs().max().item() < 5e-3 * 14.6
+
+
+@pytest.mark.parametrize("method", ["linear", "two_stage", "fix_two_stage"])
+def test_guidance_schedule_in_the_loop(method):
+    """guidance_scale -> guidance_scale_end over the steps (pipeline_controlnet.py:1718-1723, consumed at :2103)"""
+    from oracle import pipeline as opipe
+    got, (lat, cond, prompt) = _run_loop(None, guidance_scale_end=1.5, guidance_scale_method=method)
+    fake = fake_ops.FakeUNet()
+    want = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
+                              context_frames=8, context_overlap=2, motion_speed=8.0, guidance_scale_end=1.5,
+                              guidance_scale_method=method)
+    const = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
+                               context_frames=8, context_overlap=2, motion_speed=8.0)
+    assert (got - want).abs().max().item() < 5e-3
+    assert (want - const).abs().max().item() > 1e-2, "the schedule must matter for the check to mean anything"
