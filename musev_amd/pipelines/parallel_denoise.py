@@ -89,12 +89,16 @@ class ParallelDenoiser:
                  guidance_scale: float = 7.5, condition_latents: Optional[torch.Tensor] = None, motion_speed: float = 8.0,
                  unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
                  reinsert_condition: bool = True, max_steps: Optional[int] = None, guidance_scale_end: Optional[float] = None,
-                 guidance_scale_method: str = "linear") -> torch.Tensor:
+                 guidance_scale_method: str = "linear", generator=None, noise_type: str = "random",
+                 w_ind_noise: float = 0.5) -> torch.Tensor:
         """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
         [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
         ``group``: torch.distributed process group to shard the units over (None = this process alone).
         ``guidance_scale_end`` / ``guidance_scale_method``: per-step guidance schedule from guidance_scale to
         guidance_scale_end ("linear", "two_stage", "three_stage", "fix_two_stage"; reference :1718-1723, :2103).
+        ``generator`` (+ ``noise_type``, ``w_ind_noise``): the caller's torch.Generator; the reference's Euler step draws
+        (and, at s_churn = 0, discards) one noise tensor per step from it, which is reproduced so that whatever the caller
+        draws AFTER the loop matches a seeded reference run.
         ``max_steps``: run only the first max_steps steps of the num_inference_steps-long schedule (smoke / bench helper).
         Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
         if latents.ndim != 5 or latents.shape[0] != 1:
@@ -177,6 +181,7 @@ class ParallelDenoiser:
                     for k, u in enumerate(shards[r]):
                         ops.window_scatter_add(recv[r * max_units + k], idx_dev[u.window], 0, 1, u.half, eps_acc, counter, False)
             sched.loop_update(lat, eps_acc, counter, guidance[step], step, t)
+            sched.consume_step_noise((1, c, T, h, w), latents.dtype, dev, generator, noise_type, w_ind_noise)
             if callback is not None:
                 callback(step, t, lat)
 

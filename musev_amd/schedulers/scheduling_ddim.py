@@ -75,6 +75,10 @@ class DDIMScheduler:
     def input_scale(self, step_index: int) -> float:
         return 1.0  # scale_model_input is the identity for DDIM
 
+    def consume_step_noise(self, shape, dtype, device, generator, noise_type: str = "random", w_ind_noise: float = 0.5) -> None:
+        """DDIM draws step noise only when eta > 0 (scheduling_ddim.py:266-295); this loop runs eta = 0: nothing to consume"""
+        return
+
     def loop_update(self, latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.Tensor, guidance: float,
                     step_index: int, timestep) -> None:
         """fused average / CFG / DDIM step on the loop state (latents fp32 [C, T, HW], in place)"""

@@ -99,6 +99,22 @@ class EulerDiscreteScheduler:
         sigma = float(self.sigmas[step_index])
         return 1.0 / (sigma ** 2 + 1) ** 0.5
 
+    def consume_step_noise(self, shape, dtype: torch.dtype, device, generator, noise_type: str = "random",
+                           w_ind_noise: float = 0.5) -> None:
+        """The reference's step draws a noise tensor of the model-output shape on EVERY step (:120-131) and only uses it
+        when s_churn > 0 -- which the pipeline never passes.  The draw still advances the caller's generator, so a seeded
+        multi-shot run (the predictor hands the same generator to the next shot) only reproduces if it is consumed
+        here too.  No-op without a generator."""
+        if generator is None:
+            return
+        from ..utils import noise_util
+        if noise_type == "video_fusion":
+            noise_util.video_fusion_noise(shape=tuple(shape), dtype=dtype, device=device, w_ind_noise=w_ind_noise, generator=generator)
+        elif noise_type == "random":
+            noise_util.random_noise(shape=tuple(shape), dtype=dtype, device=device, generator=generator)
+        else:
+            raise ValueError(f"noise_type must be 'random' or 'video_fusion', got {noise_type}")
+
     def loop_update(self, latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.Tensor, guidance: float,
                     step_index: int, timestep) -> None:
         """fused average / CFG / Euler step on the loop state (latents fp32 [C, T, HW], in place)"""

@@ -212,6 +212,23 @@ def gen_loop_utils():
             out = rn.video_fusion_noise(shape=shape, dtype=torch.float32, device="cpu", generator=gen, w_ind_noise=c["w"],
                                         initial_common_noise=common)
         arrays[name] = out.numpy()
+    # generator consumption of the reference's Euler step (it draws a noise tensor per step even at s_churn = 0)
+    import types
+    import musev
+    pkg = types.ModuleType("musev.schedulers")
+    pkg.__path__ = [os.path.join(os.path.dirname(musev.__file__), "schedulers")]
+    sys.modules.setdefault("musev.schedulers", pkg)
+    from musev.schedulers.scheduling_euler_discrete import EulerDiscreteScheduler
+    for noise_type in ("random", "video_fusion"):
+        sch = EulerDiscreteScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+        sch.set_timesteps(20)
+        g = torch.Generator().manual_seed(123)
+        x = torch.randn(1, 4, 6, 8, 8, generator=torch.Generator().manual_seed(7)) * float(sch.init_noise_sigma)
+        for i in range(3):
+            t = sch.timesteps[i]
+            eps = torch.randn(1, 4, 6, 8, 8, generator=torch.Generator().manual_seed(70 + i))
+            x = sch.step(eps, t, sch.scale_model_input(x, t), generator=g, noise_type=noise_type, w_ind_noise=0.5).prev_sample
+        arrays[f"euler_rng_after_{noise_type}"] = torch.randn(8, generator=g).numpy()
     np.savez_compressed(os.path.join(HERE, "reference_loop_utils.npz"), **arrays)
     print("loop utils:", len(table), "guidance cases,", len(arrays), "noise cases")
 

@@ -222,3 +222,24 @@ def test_initial_noise_matches_reference():
     mixed = pn.img_based_video_noise(noise, cond, img_weight=1e-3)
     ref = 1e-3 ** 0.5 * cond.mean(dim=2, keepdim=True).repeat(1, 1, 5, 1, 1) + (1 - 1e-3) ** 0.5 * noise
     assert torch.equal(mixed, ref)
+
+
+def test_euler_step_noise_consumption_matches_reference():
+    """the reference's Euler step draws one noise tensor of the model-output shape per step from the caller's generator even
+    though s_churn = 0 discards it (scheduling_euler_discrete.py:120-131): after 3 steps the generator must be in the same
+    state, for both noise types"""
+    from musev_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
+    gold = np.load(os.path.join(GOLD, "reference_loop_utils.npz"))
+    for noise_type in ("random", "video_fusion"):
+        s = EulerDiscreteScheduler()
+        s.set_timesteps(20)
+        g = torch.Generator().manual_seed(123)
+        for _ in range(3):
+            s.consume_step_noise((1, 4, 6, 8, 8), torch.float32, "cpu", g, noise_type, 0.5)
+        assert torch.equal(torch.randn(8, generator=g), torch.from_numpy(gold[f"euler_rng_after_{noise_type}"])), noise_type
+    g = torch.Generator().manual_seed(123)
+    state = g.get_state().clone()
+    d = DDIMScheduler()
+    d.consume_step_noise((1, 4, 6, 8, 8), torch.float32, "cpu", g)   # eta = 0: the reference's DDIM step draws nothing
+    EulerDiscreteScheduler().consume_step_noise((1, 4, 6, 8, 8), torch.float32, "cpu", None)
+    assert torch.equal(g.get_state(), state)
