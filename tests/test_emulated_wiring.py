@@ -193,3 +193,41 @@ def test_denoise_loop_over_the_module(scheduler, emulated):
     err = (got.float() - want).abs().max().item()
     assert err < TOL * scale, f"|delta latent|max = {err} (scale {scale})"
     assert torch.equal(got[:, :, 0].float(), want[:, :, 0])
+
+
+def test_referencenet_cfg_glue_feeds_distinct_halves(emulated):
+    """pipeline glue (pipeline_controlnet.py:838-859, 867-964): the CFG halves share the reference latents but see different
+    cross-attention tokens ([proj(zeros), proj(clip(image))]), so ReferenceNet runs on batch 2 and each half of the UNet gets
+    its own features -- module side through musev_amd.pipelines.conditioning against the same chain in the oracle."""
+    from oracle import referencenet as oref
+    from oracle import unet3d
+    from musev_amd.models.referencenet import load_referencenet_by_name
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.conditioning import cfg_refer_image_latents, get_referencenet_emb
+    case = UNET_CASES["refnet_narrow"]
+    _widths(emulated, case["arch"])
+    cfg = case_config(case)
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs, kw = case_inputs(case, cfg)
+    rcfg = oref.referencenet_config(block_out_channels=cfg["block_out_channels"])
+    rsd = oref.init_state_dict(rcfg, 21)
+    g = torch.Generator().manual_seed(78)
+    ref_lat = torch.randn(1, 4, case["h"], case["w"], generator=g)             # (b t) = 1 reference image
+    ip_tokens = torch.randn(2, 4, cfg["cross_attention_dim"], generator=g)     # [uncond, cond] image-prompt tokens
+    both = cfg_refer_image_latents(ref_lat, 1, True)
+    assert both.shape[0] == 2 and torch.equal(both[0], both[1])
+    with torch.no_grad():
+        odown, omid = oref.referencenet_forward(rsd, rcfg, both, torch.tensor(0), ip_tokens, num_frames=1)
+    want = unet3d.unet3d_forward(sd, cfg, x, t, ehs, **dict(kw, down_block_refer_embs=odown, mid_block_refer_emb=omid))
+
+    net = _cpu(load_referencenet_by_name("musev_referencenet", rsd, block_out_channels=cfg["block_out_channels"]))
+    down, mid, sa = get_referencenet_emb(net, both, 1, ip_tokens, prompt_embeds=ehs)
+    assert sa is None and down[0].shape[0] == 2
+    assert (down[1][0].float() - down[1][1].float()).abs().max().item() > 1e-3, "the halves see different tokens"
+    model = _cpu(load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]))
+    got = model(x, t, encoder_hidden_states=ehs, return_dict=False, **dict(kw, down_block_refer_embs=down, mid_block_refer_emb=mid))[0]
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL, f"|delta|max = {err}"
+    assert get_referencenet_emb(None, both, 1, ip_tokens, None) == (None, None, None)
+    with pytest.raises(ValueError):
+        get_referencenet_emb(net, both, 1, ip_tokens[:1], None)                # token batch != reference batch
