@@ -172,6 +172,13 @@ int mv_im2col3x3_f16(const void* x, int32_t cin, void* y, int32_t kpad, int64_t 
 int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
                               void* y, int32_t y_is_f32, int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
 
+/* direct 3x3 convolution, padding 1, stride 1 | 2, fused bias (+ SiLU when act = MV_ACT_SILU), any cin <= 455 (the 8 x 9 cin fp16 weight slab of a block must fit 64 KB of LDS), cout % 8 == 0:
+ * x [n_img*h*w][cin] -> y [n_img*ho*wo][cout], w packed [cout][3][3][cin] (mv_pack_conv_weight_f16).
+ * replaces: InflatedConv3d + F.silu of PoseGuider.forward (musev/models/controlnet.py:308-316,363-373) -- the conv stack
+ *   that turns pose images into pose_guider_emb, once per call (pipeline_controlnet.py:1774-1781). */
+int mv_conv3x3_direct_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias, void* y,
+                          int32_t cout, int64_t n_img, int32_t h, int32_t w_, int32_t stride, int32_t act, void* stream);
+
 /* ---- elementwise helpers -------------------------------------------------------------------------------*/
 /* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift=0): out[i, :] = [cos(t_i f), sin(t_i f)]           */
 /* replaces: diffusers Timesteps in self.time_proj / self.frame_proj (unet_3d_condition.py:343,354,888,918) */

@@ -74,6 +74,7 @@ SIGNATURES = {
                                          _f32, _vp]),
     "mv_geglu_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "mv_conv3x3_cin_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "mv_conv3x3_direct_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mv_im2col3x3_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     "mv_conv3x3_cout_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
     "mv_timestep_embedding_f16": (_i32, [_vp, _i32, _i32, _vp, _vp]),

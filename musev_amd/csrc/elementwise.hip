@@ -348,6 +348,70 @@ __global__ void probe_tr16_kernel(const short* image, short* out) {
     out[l * 4 + 3] = v[3];
 }
 
+// Direct 3x3 convolution (padding 1, stride 1 | 2) for the small-channel conv stacks either side of the hot path -- the
+// PoseGuider (3 -> 16 -> 16 -> 32 -> 32 -> 96 -> 96 -> 256 -> 320 from 512^2 down to 64^2, once per call): channels-last
+// fp16, fp32 accumulation, fused bias (+ SiLU).  One thread = one output pixel x 8 output channels; the 8 x (9 cin) weight
+// slab of the block's channel octet sits in LDS and is read as a broadcast (every lane the same address).  VALU FMAs on
+// purpose: 15 GFLOP per 512^2 frame, outside the per-step path, and Cin = 3 / 16 / 32 / 96 do not tile the MFMA K = 32.
+template <bool VEC>  // VEC: cin % 8 == 0 -> 16-byte input and weight reads
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const half_t* __restrict__ x, int cin, const half_t* __restrict__ w,
+                                                             const half_t* __restrict__ bias, half_t* __restrict__ y, int cout,
+                                                             long n_img, int h, int w_, int ho, int wo, int stride, int act) {
+    extern __shared__ __attribute__((aligned(16))) half_t dsw[];  // [8][9 * cin], row = channel inside the octet
+    const int oc0 = blockIdx.y * 8;
+    const int K = 9 * cin;
+    for (int i = threadIdx.x; i < 8 * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        dsw[i] = (oc0 + r < cout) ? w[(long)(oc0 + r) * K + k] : (half_t)0.0f;
+    }
+    __syncthreads();
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= n_img * ho * wo) return;
+    const int ox = (int)(pix % wo);
+    const long rest = pix / wo;
+    const int oy = (int)(rest % ho);
+    const long n = rest / ho;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride + ky - 1;
+        if (iy < 0 || iy >= h) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * stride + kx - 1;
+            if (ix < 0 || ix >= w_) continue;
+            const half_t* xp = x + ((n * h + iy) * (long)w_ + ix) * cin;
+            const half_t* wp = dsw + (ky * 3 + kx) * cin;
+            if constexpr (VEC) {
+                for (int c = 0; c < cin; c += 8) {
+                    const half8v v = *reinterpret_cast<const half8v*>(xp + c);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const half8v wv = *reinterpret_cast<const half8v*>(wp + r * K + c);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[r] = fmaf((float)v[j], (float)wv[j], acc[r]);
+                    }
+                }
+            } else {
+                for (int c = 0; c < cin; ++c) {
+                    const float v = (float)xp[c];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[r] = fmaf(v, (float)wp[r * K + c], acc[r]);
+                }
+            }
+        }
+    }
+    half8v o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float v = acc[r];
+        if (bias && oc0 + r < cout) v += (float)bias[oc0 + r];
+        if (act == MV_ACT_SILU) v = mv_silu(v);
+        o[r] = (half_t)v;
+    }
+    *reinterpret_cast<half8v*>(y + pix * cout + oc0) = o;  // cout % 8 == 0 (checked on the host)
+}
+
 }  // namespace
 
 extern "C" int mv_geglu_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t half_cols, void* stream) {
@@ -420,6 +484,27 @@ extern "C" int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* 
     hipLaunchKernelGGL(conv3x3_cin_small_kernel, dim3((unsigned)gcin), dim3(kBlock), smem, (hipStream_t)stream,
                        (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (const half_t*)add, (half_t*)y, cout, (long)n_img, h, w_);
     MV_CHECK_LAUNCH("mv_conv3x3_cin_small_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_conv3x3_direct_f16(const void* x, int32_t cin, const void* w, const void* bias, void* y, int32_t cout,
+                                     int64_t n_img, int32_t h, int32_t w_, int32_t stride, int32_t act, void* stream) {
+    MV_REQUIRE(x && w && y && cin > 0 && cin <= 512 && cout > 0 && cout % 8 == 0 && n_img > 0 && h > 0 && w_ > 0,
+               "mv_conv3x3_direct_f16: bad args (cin=%d cout=%d)", cin, cout);
+    MV_REQUIRE((stride == 1 || stride == 2) && (act == MV_ACT_NONE || act == MV_ACT_SILU), "mv_conv3x3_direct_f16: stride %d / act %d", stride, act);
+    const int ho = (h + 2 - 3) / stride + 1, wo = (w_ + 2 - 3) / stride + 1;
+    const long blocks = (n_img * ho * wo + 255) / 256;
+    MV_REQUIRE(blocks < (1L << 31) && cout / 8 <= 65535, "mv_conv3x3_direct_f16: grid too large");
+    const size_t smem = (size_t)8 * 9 * cin * sizeof(half_t);  // <= 72 KB at cin = 512; 36 KB at the PoseGuider's 256
+    MV_REQUIRE(smem <= 64 * 1024, "mv_conv3x3_direct_f16: weight slab does not fit LDS (cin=%d)", cin);
+    dim3 grid((unsigned)blocks, (unsigned)(cout / 8));
+    if (cin % 8 == 0)
+        hipLaunchKernelGGL(conv3x3_direct_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)x, cin,
+                           (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_, ho, wo, stride, act);
+    else
+        hipLaunchKernelGGL(conv3x3_direct_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)x, cin,
+                           (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_, ho, wo, stride, act);
+    MV_CHECK_LAUNCH("mv_conv3x3_direct_f16");
     return MV_OK;
 }
 

@@ -21,7 +21,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
 
 __all__ = [
     "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
-    "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
+    "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
     "window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
 
@@ -354,6 +354,24 @@ def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: in
     check(_lib.load().mv_conv3x3_cout_small_f16(x.data_ptr(), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
                                                 y.data_ptr(), int(out_dtype == torch.float32), cout, n_img, h, w_, _stream()),
           "mv_conv3x3_cout_small_f16")
+    return y
+
+
+def conv3x3_direct(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: int, w_: int, *, stride: int = 1,
+                   act: int = MV_ACT_NONE) -> torch.Tensor:
+    """3x3 convolution, padding 1, stride 1 | 2, fused bias (+ SiLU), for small / odd channel counts (the PoseGuider conv
+    stack): x = [n_img*h*w_, cin] contiguous, w packed [cout, 9*cin], cout % 8 == 0."""
+    x = _mat(x, "x")
+    w = _mat(w, "w")
+    cin, cout = x.shape[1], w.shape[0]
+    if not x.is_contiguous() or not w.is_contiguous() or w.shape[1] != 9 * cin or x.shape[0] != n_img * h * w_:
+        raise ValueError("conv3x3_direct: bad shapes")
+    if stride not in (1, 2):
+        raise ValueError("conv3x3_direct: stride must be 1 or 2")
+    ho, wo = (h + 2 - 3) // stride + 1, (w_ + 2 - 3) // stride + 1
+    y = torch.empty((n_img * ho * wo, cout), dtype=torch.float16, device=x.device)
+    check(_lib.load().mv_conv3x3_direct_f16(x.data_ptr(), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)), y.data_ptr(), cout,
+                                            n_img, h, w_, stride, int(act), _stream()), "mv_conv3x3_direct_f16")
     return y
 
 

@@ -305,6 +305,20 @@ def conv3x3_cout_small(x, w, bias, n_img, h, w_, out_dtype=torch.float16):
     return y.to(out_dtype).contiguous()
 
 
+def conv3x3_direct(x, w, bias, n_img, h, w_, *, stride=1, act=MV_ACT_NONE):
+    _req(x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[0] == n_img * h * w_, "conv3x3_direct: x")
+    _req(w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float16 and w.shape[1] == 9 * x.shape[1], "conv3x3_direct: w")
+    _req(w.shape[0] % 8 == 0 and x.shape[1] <= 455 and stride in (1, 2) and act in (MV_ACT_NONE, MV_ACT_SILU), "conv3x3_direct: args")
+    _req(x.storage_offset() % 8 == 0, "conv3x3_direct: 16-byte alignment")
+    _vec(bias, "bias", w.shape[0])
+    y = _rows(F.conv2d(_images(x, n_img, h, w_), _unpack(w, x.shape[1], (3, 3)), None, stride=stride, padding=1))
+    if bias is not None:
+        y = y + bias.float()
+    if act == MV_ACT_SILU:
+        y = F.silu(y)
+    return y.to(torch.float16).contiguous()
+
+
 def timestep_embedding(t, dim):
     half = dim // 2
     freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
@@ -336,7 +350,7 @@ def pack_geglu(w, bias):
 
 
 EMULATED = ["gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
-            "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "timestep_embedding", "zero_rows",
+            "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step",
             "pack_conv_weight", "pack_geglu"]
 

@@ -18,6 +18,7 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
   * reference_referencenet_*.npz musev/models/referencenet.py ReferenceNet2D.forward (block-embedding mode): 12 + 1 feature maps
   * reference_loop_utils.json / .npz  musev/utils/timesteps_util.py generate_parameters_with_timesteps (guidance schedule) and
                                 musev/utils/noise_util.py random_noise / video_fusion_noise (initial latents)
+  * reference_poseguider_*.npz  musev/models/controlnet.py PoseGuider.forward (the pose conditioning of musev_referencenet_pose)
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
 from __future__ import annotations
@@ -233,7 +234,28 @@ def gen_loop_utils():
     print("loop utils:", len(table), "guidance cases,", len(arrays), "noise cases")
 
 
+def gen_poseguider():
+    """musev/models/controlnet.py PoseGuider.forward with the oracle's seeded weights loaded strict=True (pins the key /
+    shape inventory) -- and the class's own initialisation: conv_out is zero, so a fresh PoseGuider outputs zeros."""
+    from golden_cases import POSEGUIDER_CASES, poseguider_case_inputs
+    from musev.models.controlnet import PoseGuider
+    from oracle import poseguider as opg
+    for name, c in POSEGUIDER_CASES.items():
+        net = PoseGuider(conditioning_embedding_channels=c["emb"], conditioning_channels=c["cond"], block_out_channels=c["ch"]).eval()
+        x = poseguider_case_inputs(c)
+        with torch.no_grad():
+            fresh = net(x)
+        sd = opg.init_state_dict(opg.param_shapes(c["emb"], c["cond"], c["ch"]), c["weight_seed"])
+        net.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            out = net(x)
+        np.savez_compressed(os.path.join(HERE, f"reference_poseguider_{name}.npz"), out=out.numpy(),
+                            fresh_is_zero=np.array(bool((fresh == 0).all())))
+        print("poseguider", name, tuple(out.shape), "absmax", float(out.abs().max()), "fresh zero:", bool((fresh == 0).all()))
+
+
 if __name__ == "__main__":
+    gen_poseguider()
     gen_loop_utils()
     gen_context()
     gen_ddim()

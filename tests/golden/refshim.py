@@ -634,8 +634,25 @@ def install(reference_root: str = "/root/reference") -> None:
     _mod("accelerate.utils").set_module_tensor_to_device = None
     _mod("accelerate.utils.versions").is_torch_version = lambda op, v: True
     _install_referencenet_extras()
+    _install_controlnet_extras()
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
+
+
+def _install_controlnet_extras() -> None:
+    """names musev/models/controlnet.py imports at module top; only PoseGuider (plain torch + ModelMixin) is executed, the
+    ControlNet wrappers around the un-vendored diffusers ControlNetModel are placeholders"""
+    _mod("diffusers.models.controlnet").ControlNetModel = type("ControlNetModel", (nn.Module,), {})
+    _mod("diffusers.pipelines")
+    _mod("diffusers.pipelines.controlnet")
+    _mod("diffusers.pipelines.controlnet.multicontrolnet").MultiControlNetModel = type("MultiControlNetModel", (nn.Module,), {})
+    su = _mod("diffusers.schedulers.scheduling_utils")
+    if not hasattr(su, "KarrasDiffusionSchedulers"):
+        su.KarrasDiffusionSchedulers = type("KarrasDiffusionSchedulers", (), {})
+    tu = _mod("diffusers.utils.torch_utils")
+    if not hasattr(tu, "is_compiled_module"):
+        tu.is_compiled_module = lambda m: False
+    import PIL.Image  # noqa: F401  (controlnet.py does `import PIL` and uses PIL.Image in annotations)
 
 
 def _install_referencenet_extras() -> None:

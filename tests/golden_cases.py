@@ -126,3 +126,16 @@ NOISE_CASES = {
     "fusion_per_item": dict(kind="fusion", shape=(2, 4, 6, 8, 8), seeds=[16, 17], w=0.5, per_item=True),
     "fusion_given_common": dict(kind="fusion", shape=(1, 4, 6, 8, 8), seeds=[18], w=0.7, common_seed=19),
 }
+
+
+# ---- PoseGuider: the configuration scripts/inference/video2video.py:1024-1030 builds, and the class default
+POSEGUIDER_CASES = {
+    "shipped": dict(emb=320, cond=3, ch=(16, 32, 96, 256), b=1, f=3, h=64, w=48, weight_seed=41, input_seed=51),
+    "default_b2": dict(emb=64, cond=3, ch=(16, 32, 64, 128), b=2, f=2, h=40, w=56, weight_seed=42, input_seed=52),
+}
+
+
+def poseguider_case_inputs(case: dict):
+    g = torch.Generator().manual_seed(case["input_seed"])
+    return torch.rand(case["b"], case["cond"], case["f"], case["h"], case["w"], generator=g) * 2.0 - 1.0   # images in [-1, 1]
+

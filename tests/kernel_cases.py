@@ -290,6 +290,31 @@ def case_conv_in_out():
     return r1
 
 
+def case_conv3x3_direct():
+    """the PoseGuider conv shapes: odd Cin (3), Cin % 8 == 0 (16, 96), stride 1 and 2 (even and odd sizes), with and
+    without the fused SiLU"""
+    from musev_amd import ops
+    worst = {"ok": True, "max_abs_err": 0.0, "parts": {}}
+    for i, (cin, cout, h, w, stride, act) in enumerate([(3, 16, 20, 28, 1, True), (16, 32, 20, 28, 2, True), (16, 16, 9, 11, 2, True),
+                                                         (96, 256, 12, 10, 2, True), (32, 96, 7, 9, 1, False), (256, 320, 8, 8, 1, False)]):
+        n = 3
+        x = _rand((n, cin, h, w), 300 + i)
+        wt = _rand((cout, cin, 3, 3), 310 + i, 1.0 / math.sqrt(9 * cin))
+        b = _rand((cout,), 320 + i)
+        ref = F.conv2d(x.float(), wt.float(), b.float(), stride=stride, padding=1)
+        if act:
+            ref = F.silu(ref)
+        ref = ref.permute(0, 2, 3, 1).reshape(-1, cout)
+        xl = x.permute(0, 2, 3, 1).reshape(n * h * w, cin).contiguous()
+        got = ops.conv3x3_direct(xl, ops.pack_conv_weight(wt), b, n, h, w, stride=stride, act=ops.MV_ACT_SILU if act else ops.MV_ACT_NONE)
+        r = _cmp(f"conv3x3_direct {cin}->{cout} {h}x{w} s{stride} silu{int(act)}", got, ref, atol=3e-3)
+        worst["ok"] = worst["ok"] and r["ok"] and tuple(got.shape) == tuple(ref.shape)
+        worst["max_abs_err"] = max(worst["max_abs_err"], r["max_abs_err"])
+        worst["parts"][r["name"]] = r["ok"]
+    worst["name"] = "conv3x3_direct"
+    return worst
+
+
 def case_timestep_embedding():
     from musev_amd import ops
     t = torch.tensor([951.0, 1.0, 0.0, 8.0, 96.0], device=DEV)

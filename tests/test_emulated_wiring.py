@@ -13,7 +13,8 @@ import pytest
 import torch
 
 import emu_ops
-from golden_cases import REFNET_CASES, UNET_CASES, case_config, case_inputs, refnet_case_inputs
+from golden_cases import (POSEGUIDER_CASES, REFNET_CASES, UNET_CASES, case_config, case_inputs, poseguider_case_inputs,
+                          refnet_case_inputs)
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 1e-2  # the north-star bound; fp16 storage between emulated ops gives the same error level as the kernels (~3e-3)
@@ -55,7 +56,7 @@ def test_emulation_matches_kernel_references(emulated):
         lambda: kc.case_layernorm(rows=99, c=64),
         lambda: kc.case_attention_self(d=40, b=2, t=3, lq=20, cond_idx=1), lambda: kc.case_attention_cross(d=80, nb=6, t=3, lq=13),
         lambda: kc.case_temporal_attention(b=2, t=5, hw=7, d=40), kc.case_geglu, kc.case_conv_in_out, kc.case_timestep_embedding,
-        kc.case_layout_and_misc, kc.case_window_loop, kc.case_cfg_affine_step,
+        kc.case_layout_and_misc, kc.case_window_loop, kc.case_cfg_affine_step, kc.case_conv3x3_direct,
     ]
     for fn in cases:
         res = fn()
@@ -231,3 +232,27 @@ def test_referencenet_cfg_glue_feeds_distinct_halves(emulated):
     assert get_referencenet_emb(None, both, 1, ip_tokens, None) == (None, None, None)
     with pytest.raises(ValueError):
         get_referencenet_emb(net, both, 1, ip_tokens[:1], None)                # token batch != reference batch
+
+
+# ---- 5. PoseGuider wiring -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(POSEGUIDER_CASES))
+def test_poseguider_wiring_matches_reference_golden(name, emulated):
+    from oracle import poseguider as opg
+    from musev_amd.models.controlnet import PoseGuider
+    c = POSEGUIDER_CASES[name]
+    sd = opg.init_state_dict(opg.param_shapes(c["emb"], c["cond"], c["ch"]), c["weight_seed"])
+    x = poseguider_case_inputs(c)
+    want = torch.from_numpy(np.load(os.path.join(GOLDEN, f"reference_poseguider_{name}.npz"))["out"])
+    fresh = _cpu(PoseGuider(c["emb"], c["cond"], c["ch"]).half())
+    assert sorted(fresh.state_dict()) == sorted(sd) and all(tuple(fresh.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
+    assert (fresh(x) == 0).all(), "conv_out is zero-initialised: an untrained PoseGuider adds nothing"
+    net = _cpu(PoseGuider.from_pretrained(sd, conditioning_embedding_channels=c["emb"], conditioning_channels=c["cond"],
+                                          block_out_channels=c["ch"]).half())
+    got = net(x)
+    assert got.shape == want.shape and got.dtype == x.dtype
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL, f"{name}: |delta|max = {err}"
+    with pytest.raises(ValueError):
+        net(x[:, :, 0])                       # not b c f h w
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PoseGuider(c["emb"], c["cond"], c["ch"])(x)

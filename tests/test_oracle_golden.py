@@ -243,3 +243,22 @@ def test_euler_step_noise_consumption_matches_reference():
     d.consume_step_noise((1, 4, 6, 8, 8), torch.float32, "cpu", g)   # eta = 0: the reference's DDIM step draws nothing
     EulerDiscreteScheduler().consume_step_noise((1, 4, 6, 8, 8), torch.float32, "cpu", None)
     assert torch.equal(g.get_state(), state)
+
+
+# ---- PoseGuider ---------------------------------------------------------------------------------------
+from golden_cases import POSEGUIDER_CASES, poseguider_case_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(POSEGUIDER_CASES))
+def test_oracle_poseguider_matches_reference(name):
+    """oracle/poseguider.py vs musev/models/controlnet.py PoseGuider.forward executed on the same seeded weights (loaded with
+    strict=True into the reference class: the key / shape inventory is pinned too)"""
+    from oracle import poseguider as opg
+    c = POSEGUIDER_CASES[name]
+    gold = np.load(os.path.join(GOLD, f"reference_poseguider_{name}.npz"))
+    assert bool(gold["fresh_is_zero"])  # zero_module(conv_out): an untrained PoseGuider adds nothing
+    sd = opg.init_state_dict(opg.param_shapes(c["emb"], c["cond"], c["ch"]), c["weight_seed"])
+    got = opg.poseguider_forward(sd, poseguider_case_inputs(c))
+    want = torch.from_numpy(gold["out"])
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 2e-5
