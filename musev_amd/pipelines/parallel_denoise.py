@@ -90,7 +90,9 @@ class ParallelDenoiser:
                  unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
                  reinsert_condition: bool = True, max_steps: Optional[int] = None, guidance_scale_end: Optional[float] = None,
                  guidance_scale_method: str = "linear", generator=None, noise_type: str = "random",
-                 w_ind_noise: float = 0.5) -> torch.Tensor:
+                 w_ind_noise: float = 0.5, controlnet=None, control_image: Optional[torch.Tensor] = None,
+                 controlnet_conditioning_scale: float = 1.0, control_guidance_start: float = 0.0,
+                 control_guidance_end: float = 1.0, guess_mode: bool = False) -> torch.Tensor:
         """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
         [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
         ``group``: torch.distributed process group to shard the units over (None = this process alone).
@@ -99,6 +101,10 @@ class ParallelDenoiser:
         ``generator`` (+ ``noise_type``, ``w_ind_noise``): the caller's torch.Generator; the reference's Euler step draws
         (and, at s_churn = 0, discards) one noise tensor per step from it, which is reproduced so that whatever the caller
         draws AFTER the loop matches a seeded reference run.
+        ``controlnet`` (+ ``control_image`` [1, 3, n_cond + T, 8h, 8w], ``controlnet_conditioning_scale``,
+        ``control_guidance_start`` / ``_end``, ``guess_mode``): the per-window ControlNet call of the reference
+        (get_controlnet_emb, :1202-1291; window gather of the control frames :1947-1976): its residuals are added to the
+        UNet's skips / mid block.  The control frames of a window are the condition frames followed by the window's frames.
         ``max_steps``: run only the first max_steps steps of the num_inference_steps-long schedule (smoke / bench helper).
         Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
         if latents.ndim != 5 or latents.shape[0] != 1:
@@ -155,6 +161,24 @@ class ParallelDenoiser:
         eps_acc = torch.empty((halves, c, T, hw), dtype=torch.float32, device=dev)
         tw = n_cond + win_len
 
+        # ---- ControlNet conditioning (optional) ----
+        cn_keep, ctrl_frames, ctrl_buf, text_rep = None, None, None, None
+        if controlnet is not None:
+            if control_image is None or control_image.ndim != 5 or control_image.shape[0] != 1 or control_image.shape[2] != n_cond + T:
+                raise ValueError("control_image must be [1, c, n_cond + T, H, W] (condition frames first)")
+            n_steps = len(timesteps)
+            # controlnet_keep (:1700-1710 of the reference, the diffusers recipe): 0 outside [start, end] of the schedule
+            cn_keep = [1.0 - float(i / n_steps < control_guidance_start or (i + 1) / n_steps > control_guidance_end)
+                       for i in range(n_steps)]
+            frames_all = control_image[0].to(dev).permute(1, 0, 2, 3)  # [n_cond + T, c, H, W]
+            ctrl_frames = []
+            for wd in wins:  # controlnet_context = condition indices + (window indices + n_cond)   (:1953-1961)
+                sel = torch.tensor(list(range(n_cond)) + [i + n_cond for i in wd], dtype=torch.long, device=dev)
+                ctrl_frames.append(frames_all.index_select(0, sel).to(torch.float16).contiguous())
+            ctrl_buf = torch.empty_like(ctrl_frames[0])  # static buffer: the captured graphs read the window's frames from here
+            # align_repeat_tensor_single_dim(prompt_embeds, (b t)) (:1242-1246): one row of text per frame, per CFG half
+            text_rep = embeds.repeat_interleave(tw, dim=0).contiguous()
+
         for step, t in enumerate(timesteps):
             if max_steps is not None and step >= max_steps:
                 break
@@ -165,9 +189,16 @@ class ParallelDenoiser:
             in_scale = sched.input_scale(step)
             lat_in = lat if in_scale == 1.0 else lat * in_scale
             slot = 0
+            cn = None
+            if controlnet is not None:
+                cond_scale = float(controlnet_conditioning_scale) * cn_keep[step]   # :1229-1236
+                if cond_scale != 0.0:  # a zero scale makes every residual zero: adding them is a no-op, skip the network
+                    cn = (controlnet, ctrl_buf, text_rep, cond_scale, bool(guess_mode))
             for wi, hs in my_groups:
                 x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs))
-                eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx, vis_idx, motion_speed, unet_kwargs)
+                if cn is not None:
+                    ctrl_buf.copy_(ctrl_frames[wi])
+                eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx, vis_idx, motion_speed, unet_kwargs, cn)
                 if world == 1:
                     for k, hf in enumerate(hs):
                         ops.window_scatter_add(eps[k * tw * hw:(k + 1) * tw * hw], idx_dev[wi], n_cond, 1, hf, eps_acc, counter, False)
@@ -191,16 +222,35 @@ class ParallelDenoiser:
         return out
 
     def _unet_rows(self, x, hs: tuple, halves: int, tw: int, h: int, w: int, t_dev, embeds, sub_idx, vis_idx, motion_speed,
-                   unet_kwargs: dict) -> torch.Tensor:
-        """one UNet forward on window rows; hipGraph-replayed when the call signature was captured before"""
+                   unet_kwargs: dict, cn=None) -> torch.Tensor:
+        """one UNet forward on window rows (preceded by the ControlNet forward on the same rows when ``cn`` is set);
+        hipGraph-replayed when the call signature was captured before"""
         ehs = embeds[hs[0]:hs[-1] + 1] if len(hs) == 2 else embeds[hs[0]:hs[0] + 1]
         kw = {k: (self._slice_half(v, list(hs), halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()}
 
-        def one(inp, nb, e, k):
+        def one(inp, nb, e, k, first_half=None):
+            first_half = hs[0] if first_half is None else first_half
+            if cn is not None:
+                net, ctrl, text_rep, scale, guess = cn
+                # guess mode: the ControlNet sees only the text-conditioned half, the unconditional half gets no residuals
+                # (:1218-1226, 1276-1288); this branch is only entered with one half per call
+                if not (guess and halves == 2 and first_half == 0):
+                    frames = inp.view(nb * tw, h, w, inp.shape[1]).permute(0, 3, 1, 2)   # rows -> (b t) c h w view (:1236-1238)
+                    text = text_rep[first_half * tw:(first_half + nb) * tw]
+                    down, mid = net(frames, t_dev, text, ctrl if nb == 1 else ctrl.repeat(nb, 1, 1, 1),
+                                    conditioning_scale=scale, guess_mode=guess, return_dict=False)
+                    k = dict(k, down_block_additional_residuals=down, mid_block_additional_residual=mid)
             return self.unet.forward_rows(inp, nb, tw, h, w, t_dev, e, sample_index=sub_idx,
                                           vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **k)
 
+        split_halves = len(hs) == 2 and cn is not None and cn[4]  # guess mode needs the halves apart
+
         def eager(inp):
+            if split_halves and not (self.half_streams and inp.is_cuda):
+                rows = inp.shape[0] // 2
+                kws = [{k: (self._slice_half(v, [i], halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()} for i in hs]
+                return torch.cat([one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0]),
+                                  one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])], dim=0)
             if not (self.half_streams and len(hs) == 2 and inp.is_cuda):
                 return one(inp, len(hs), ehs, kw)
             # The CFG halves only meet in the loop glue: run them as two batch-1 forwards on two HIP streams, so the
@@ -211,8 +261,8 @@ class ParallelDenoiser:
             kws = [{k: (self._slice_half(v, [i], halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()} for i in hs]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1])
-            e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0])
+                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
+            e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0])
             main.wait_stream(side)
             e1.record_stream(main)
             return torch.cat([e0, e1], dim=0)
@@ -221,7 +271,8 @@ class ParallelDenoiser:
             return eager(x)
         # a captured graph is only valid for the exact tensors it was recorded with: key on their identities
         key = (hs, tw, h, w, float(motion_speed), t_dev.data_ptr(), embeds.data_ptr(), tuple(vis_idx or ()),
-               tuple(sorted((k, _ident(v)) for k, v in kw.items())), tuple(x.shape), _param_epoch(self.unet))
+               tuple(sorted((k, _ident(v)) for k, v in kw.items())), tuple(x.shape), _param_epoch(self.unet),
+               None if cn is None else (id(cn[0]), cn[1].data_ptr(), cn[2].data_ptr(), cn[3], cn[4], _param_epoch(cn[0])))
         gf = self._graphs.get(key)
         if gf is None:
             if len(self._graphs) >= 8:  # stale captures (other prompts / sizes) would pin their activation pools

@@ -196,7 +196,9 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                  context_batch_size: int = 1, motion_speed: float = 8.0, unet_kwargs: Optional[dict] = None,
                  record: Optional[list] = None, max_steps: Optional[int] = None, scheduler: str = "ddim",
                  scheduler_kwargs: Optional[dict] = None, guidance_scale_end: Optional[float] = None,
-                 guidance_scale_method: str = "linear") -> Tensor:
+                 guidance_scale_method: str = "linear", controlnet_fn: Optional[Callable[..., tuple]] = None,
+                 control_image: Optional[Tensor] = None, controlnet_conditioning_scale: float = 1.0,
+                 control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guess_mode: bool = False) -> Tensor:
     """pipeline_controlnet.py:1832-2156.  ``max_steps`` (test helper, not in the reference): stop after the first
     max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
@@ -214,6 +216,10 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
     gscales = guidance_schedule(guidance_scale, num_inference_steps, guidance_scale_end, guidance_scale_method)  # :1718-1723
     global_context = prepare_global_context(context_schedule, num_inference_steps, T, context_frames, context_stride,
                                             context_overlap, context_batch_size)
+    n_t = len(sched.timesteps)
+    keep = [1.0 - float(i / n_t < control_guidance_start or (i + 1) / n_t > control_guidance_end) for i in range(n_t)]  # :1700-1710
+    # controlnet_fn(sample[(b t), c, h, w], t, text[(b t), L, D], cond[(b t), 3, H, W], conditioning_scale, guess_mode)
+    #   -> (down residuals, mid residual); control_image [1, 3, n_cond + T, H, W], duplicated for CFG unless guess mode (:476-477)
     for i, t in enumerate(sched.timesteps):
         if max_steps is not None and i >= max_steps:
             break
@@ -234,8 +240,26 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                 full.index_copy_(2, vis_idx, cond)                                            # data_util.py:242-268
                 full.index_copy_(2, sub_idx, x)
                 x = full
+            extra = {}
+            if controlnet_fn is not None:
+                cond_scale = controlnet_conditioning_scale * keep[i]                          # :1235
+                cctx = [list(range(n_cond)) + [ci + n_cond for ci in c] for c in context]     # :1953-1961
+                ctrl = torch.cat([control_image[:, :, c] for c in cctx])                      # :1977-1979
+                if guess_mode and do_cfg:                                                     # :1218-1226: conditional half only
+                    cin, ctext = x[x.shape[0] // 2:], prompt_embeds.chunk(2)[1]
+                else:
+                    cin, ctext = x, prompt_embeds
+                    ctrl = ctrl.repeat(2 if do_cfg else 1, 1, 1, 1, 1)                        # :476-477
+                frames = cin.permute(0, 2, 1, 3, 4).reshape(-1, cin.shape[1], *cin.shape[3:])  # "b c t h w -> (b t) c h w" (:1236)
+                text = ctext.repeat_interleave(cin.shape[2], dim=0)                           # :1242-1246
+                cimg = ctrl.permute(0, 2, 1, 3, 4).reshape(-1, ctrl.shape[1], *ctrl.shape[3:])
+                down, mid = controlnet_fn(frames, t, text, cimg, cond_scale, guess_mode)      # :1251-1260
+                if guess_mode and do_cfg:                                                     # :1276-1288
+                    down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+                    mid = torch.cat([torch.zeros_like(mid), mid])
+                extra = dict(down_block_additional_residuals=down, mid_block_additional_residual=mid)
             eps = unet_fn(x, t, prompt_embeds, sample_index=sub_idx, vision_conditon_frames_sample_index=vis_idx,
-                          sample_frame_rate=motion_speed, **unet_kwargs)                      # :2045-2067
+                          sample_frame_rate=motion_speed, **unet_kwargs, **extra)             # :2045-2067
             if condition_latents is not None:
                 eps = eps.index_select(2, sub_idx)                                            # :2068-2071
             for j, c in enumerate(context):

@@ -81,7 +81,7 @@ def init_state_dict(cfg: dict, seed: int = 3, residual_gain: float = 0.3) -> "Or
 
 
 def referencenet_forward(sd: Dict[str, Tensor], cfg: dict, sample: Tensor, timestep, encoder_hidden_states: Tensor,
-                         num_frames: int, return_ndim: int = 5) -> Tuple[List[Tensor], Tensor]:
+                         num_frames: int, return_ndim: int = 5, conv_in_add: Optional[Tensor] = None) -> Tuple[List[Tensor], Tensor]:
     """sample [(b t), c, h, w]; encoder_hidden_states [(b t), L, D] -> (12 down features, mid feature), each
     [b, c, t, h, w] (return_ndim 5, referencenet.py:1018-1033) or [(b t), c, h, w] (4)."""
     ch, heads, L = cfg["block_out_channels"], cfg["attention_head_dim"], cfg["layers_per_block"]
@@ -90,6 +90,8 @@ def referencenet_forward(sd: Dict[str, Tensor], cfg: dict, sample: Tensor, times
     emb = u.timestep_embedding_mlp(sd, "time_embedding", u.timesteps_sincos(t, ch[0]))  # :795-803
     ctx = dict(num_frames=1, vis_idx=None, vision_clip_emb=None, ip_adapter_scale=0.0, use_ip=False)
     x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)      # :914
+    if conv_in_add is not None:  # not part of ReferenceNet2D: lets oracle/controlnet.py reuse this encoder walk
+        x = x + conv_in_add
     res: List[Tensor] = [x]                                                          # :962
     for i, bt in enumerate(cfg["down_block_types"]):                                 # :963-1003
         p = f"down_blocks.{i}"

@@ -256,3 +256,100 @@ def test_poseguider_wiring_matches_reference_golden(name, emulated):
         net(x[:, :, 0])                       # not b c f h w
     with pytest.raises(RuntimeError, match="no CPU path"):
         PoseGuider(c["emb"], c["cond"], c["ch"])(x)
+
+
+# ---- 6. ControlNetModel wiring (top-level composition is unpinned, see oracle/controlnet.py) ------------------
+@pytest.mark.parametrize("guess_mode,scale", [(False, 1.0), (False, 0.6), (True, 1.0)])
+def test_controlnet_wiring_matches_oracle_and_feeds_the_unet(guess_mode, scale, emulated):
+    from oracle import controlnet as ocn
+    from oracle import unet3d
+    from musev_amd.models.controlnet import ControlNetModel
+    from musev_amd.models.unet_loader import load_unet_by_name
+    case = UNET_CASES["musev_narrow"]
+    _widths(emulated, case["arch"])
+    cfg = case_config(case)
+    ccfg = ocn.controlnet_config(block_out_channels=cfg["block_out_channels"])
+    csd = ocn.init_state_dict(ccfg, 5)
+    x, t, ehs, kw = case_inputs(case, cfg)
+    b, _, tt, h, w = x.shape
+    g = torch.Generator().manual_seed(91)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(b * tt, -1, h, w)                       # "b c t h w -> (b t) c h w" (:1236-1238)
+    text = ehs.repeat_interleave(tt, dim=0)                                            # align_repeat_tensor_single_dim (:1242-1246)
+    pose = torch.rand(b * tt, 3, 8 * h, 8 * w, generator=g) * 2 - 1
+    odown, omid = ocn.controlnet_forward(csd, ccfg, frames, t, text, pose, conditioning_scale=scale, guess_mode=guess_mode)
+    assert len(odown) == ocn.n_residuals(ccfg) == 12
+
+    net = ControlNetModel(block_out_channels=cfg["block_out_channels"])
+    assert sorted(net.state_dict()) == sorted(csd)
+    assert all(tuple(net.state_dict()[k].shape) == tuple(v.shape) for k, v in csd.items())
+    net.load_state_dict(csd, strict=True)
+    net = _cpu(net.half().eval())
+    net.controlnet_cond_embedding._device_check = False
+    down, mid = net(frames, t, text, pose, conditioning_scale=scale, guess_mode=guess_mode, return_dict=False)
+    assert len(down) == len(odown)
+    for i, (d, o) in enumerate(zip(down, odown)):
+        assert d.shape == o.shape
+        assert (d.float() - o).abs().max().item() < TOL, f"residual {i}"
+    assert (mid.float() - omid).abs().max().item() < TOL
+    out = net(frames, t, text, pose, conditioning_scale=scale, guess_mode=guess_mode)
+    assert torch.equal(out.mid_block_res_sample, mid)
+    with pytest.raises(NotImplementedError):
+        net(frames, t, text, pose, controlnet_cond_latents=frames)
+    if guess_mode or scale != 1.0:
+        return
+    # the residuals into the UNet (pipeline_controlnet.py:2045-2051), module chain vs oracle chain
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    want = unet3d.unet3d_forward(sd, cfg, x, t, ehs, **dict(kw, down_block_additional_residuals=odown, mid_block_additional_residual=omid))
+    model = _cpu(load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]))
+    got = model(x, t, encoder_hidden_states=ehs, return_dict=False,
+                **dict(kw, down_block_additional_residuals=down, mid_block_additional_residual=mid))[0]
+    assert (got.float() - want).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("guess_mode", [False, True])
+def test_denoise_loop_with_controlnet(guess_mode, emulated):
+    """the per-window ControlNet call inside the loop (get_controlnet_emb + the control-frame gather, :1202-1291, 1947-1976)
+    with control_guidance_end cutting the last step: module loop vs oracle loop"""
+    from oracle import controlnet as ocn
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.controlnet import ControlNetModel
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    arch = UNET_CASES["musev_narrow"]["arch"]
+    _widths(emulated, arch)
+    cfg = unet3d.flavour_config("musev", **arch)
+    sd = unet3d.init_state_dict(cfg, 3)
+    ccfg = ocn.controlnet_config(block_out_channels=cfg["block_out_channels"])
+    csd = ocn.init_state_dict(ccfg, 5)
+    g = torch.Generator().manual_seed(0)
+    T, win, ov, h, w = 8, 6, 2, 8, 8
+    latents = torch.randn(1, 4, T, h, w, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    pose = torch.rand(1, 3, 1 + T, 8 * h, 8 * w, generator=g) * 2 - 1
+    # first 3 steps of the 20-step schedule (the per-step bound, see tests/test_pipeline_gpu.py); keep = [1, 1, 0, ...]
+    kw = dict(num_inference_steps=20, max_steps=3, guidance_scale=3.5, condition_latents=cond, motion_speed=8.0, control_image=pose,
+              controlnet_conditioning_scale=0.8, control_guidance_end=0.1, guess_mode=guess_mode)
+    calls = []
+
+    def cn_fn(frames, t, text, cimg, scale, guess):
+        calls.append(float(scale))
+        return ocn.controlnet_forward(csd, ccfg, frames, t, text, cimg, conditioning_scale=scale, guess_mode=guess)
+
+    want = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt,
+                              context_frames=win, context_overlap=ov, controlnet_fn=cn_fn, **kw)
+    assert 0.0 in calls and 0.8 in calls
+    plain = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt,
+                               context_frames=win, context_overlap=ov, **{k: v for k, v in kw.items() if k in
+                                                                         ("num_inference_steps", "max_steps", "guidance_scale", "condition_latents", "motion_speed")})
+    assert (want - plain).abs().max().item() > 5e-2, "the ControlNet must matter for the check to mean anything"
+    net = ControlNetModel(block_out_channels=cfg["block_out_channels"])
+    net.load_state_dict(csd, strict=True)
+    net = _cpu(net.half().eval())
+    unet = _cpu(load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **arch))
+    den = ParallelDenoiser(unet, context_frames=win, context_overlap=ov)
+    den._device_check = False
+    got = den(latents, prompt, controlnet=net, **kw)
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL, f"|delta latent|max = {err}"

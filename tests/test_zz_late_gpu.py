@@ -142,3 +142,76 @@ def test_poseguider_matches_reference_golden():
         assert got.shape == want.shape
         err = (got.float().cpu() - want).abs().max().item()
         assert err < 1e-2, f"{name}: |delta|max = {err}"
+
+
+_CN_ARCH = dict(block_out_channels=(320, 640, 640), layers_per_block=1,
+                down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"))
+
+
+def test_controlnet_matches_oracle():
+    """ControlNetModel on HIP kernels against oracle/controlnet.py -- whose top-level composition restates
+    the published diffusers algorithm (unpinned), while its encoder and conditioning embedding are the pinned
+    oracle/referencenet.py and oracle/poseguider.py"""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from oracle import controlnet as ocn
+    from musev_amd.models.controlnet import ControlNetModel
+    ccfg = ocn.controlnet_config(**_CN_ARCH)
+    csd = ocn.init_state_dict(ccfg, 5)
+    g = torch.Generator().manual_seed(93)
+    n, h, w = 4, 16, 24
+    frames = torch.randn(n, 4, h, w, generator=g)
+    text = torch.randn(n, 77, 768, generator=g)
+    pose = torch.rand(n, 3, 8 * h, 8 * w, generator=g) * 2 - 1
+    net = ControlNetModel(**_CN_ARCH)
+    net.load_state_dict(csd, strict=True)
+    net = net.half().eval().to("cuda")
+    for guess, scale in ((False, 1.0), (True, 0.7)):
+        odown, omid = ocn.controlnet_forward(csd, ccfg, frames, torch.tensor(601), text, pose, conditioning_scale=scale, guess_mode=guess)
+        down, mid = net(frames.to("cuda"), torch.tensor(601, device="cuda"), text.to("cuda"), pose.to("cuda"),
+                        conditioning_scale=scale, guess_mode=guess, return_dict=False)
+        torch.cuda.synchronize()
+        assert len(down) == len(odown)
+        for i, (d, o) in enumerate(zip(down, odown)):
+            assert d.shape == o.shape
+            assert (d.float().cpu() - o).abs().max().item() < 1e-2, f"guess={guess} residual {i}"
+        assert (mid.float().cpu() - omid).abs().max().item() < 1e-2
+
+
+def test_loop_with_controlnet_first_steps():
+    """the per-window ControlNet call inside the loop (hipGraph-captured together with the UNet forward, two streams)"""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from test_pipeline_gpu import ARCH
+    from oracle import controlnet as ocn
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.controlnet import ControlNetModel
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    cfg = unet3d.flavour_config("musev", **ARCH)
+    sd = unet3d.init_state_dict(cfg, 3)
+    cn_arch = dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"))
+    ccfg = ocn.controlnet_config(**cn_arch)
+    csd = ocn.init_state_dict(ccfg, 5)
+    g = torch.Generator().manual_seed(0)
+    T, win, ov, h, w = 8, 6, 2, 8, 8
+    latents = torch.randn(1, 4, T, h, w, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    pose = torch.rand(1, 3, 1 + T, 8 * h, 8 * w, generator=g) * 2 - 1
+    kw = dict(num_inference_steps=20, max_steps=2, guidance_scale=3.5, motion_speed=8.0, controlnet_conditioning_scale=0.8)
+    want = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt,
+                              context_frames=win, context_overlap=ov, condition_latents=cond, control_image=pose,
+                              controlnet_fn=lambda f, t, tx, ci, s, gm: ocn.controlnet_forward(csd, ccfg, f, t, tx, ci, conditioning_scale=s, guess_mode=gm),
+                              **kw)
+    dev = torch.device("cuda", 0)
+    net = ControlNetModel(**cn_arch)
+    net.load_state_dict(csd, strict=True)
+    net = net.half().eval().to(dev)
+    unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+    den = ParallelDenoiser(unet, context_frames=win, context_overlap=ov)
+    got = den(latents.to(dev), prompt.to(dev), condition_latents=cond.to(dev), controlnet=net, control_image=pose.to(dev), **kw)
+    got2 = den(latents.to(dev), prompt.to(dev), condition_latents=cond.to(dev), controlnet=net, control_image=pose.to(dev), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2), "the loop must be deterministic"
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err < 1e-2, f"|delta latent|max = {err}"
