@@ -353,6 +353,7 @@ __global__ void probe_tr16_kernel(const short* image, short* out) {
 // fp16, fp32 accumulation, fused bias (+ SiLU).  One thread = one output pixel x 8 output channels; the 8 x (9 cin) weight
 // slab of the block's channel octet sits in LDS and is read as a broadcast (every lane the same address).  VALU FMAs on
 // purpose: 15 GFLOP per 512^2 frame, outside the per-step path, and Cin = 3 / 16 / 32 / 96 do not tile the MFMA K = 32.
+// [cpu-sim:begin conv3x3_direct]  (tests/cpu_sim: this kernel is also compiled for the host and run thread-per-thread)
 template <bool VEC>  // VEC: cin % 8 == 0 -> 16-byte input and weight reads
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const half_t* __restrict__ x, int cin, const half_t* __restrict__ w,
                                                              const half_t* __restrict__ bias, half_t* __restrict__ y, int cout,
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const half_t* __res
     }
     *reinterpret_cast<half8v*>(y + pix * cout + oc0) = o;  // cout % 8 == 0 (checked on the host)
 }
+// [cpu-sim:end conv3x3_direct]
 
 }  // namespace
 
