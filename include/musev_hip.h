@@ -143,7 +143,9 @@ typedef struct mv_attn_desc {
 int mv_attention_f16(const mv_attn_desc* d, void* stream);
 /* tuning knob (A/B runs): bits 0-1: 1 = single-buffered K/V tiles (default), 2 = double-buffered tiles for d <= 80,
  * 3 = variant 1 with the reduced softmax VALU work (row sums through a ones column in the P.V MFMA at d = 40);
- * +4 = temporal attention v1 (per-lane global K/V fetch) instead of v2 (K/V staged in LDS, default) */
+ * +4 = temporal attention v1 (per-lane global K/V fetch) instead of v2 (K/V staged in LDS, default);
+ * +8 = round-toward-zero packing of the probabilities (d = 40); +16 = K/V tiles fetched through buffer descriptors
+ * (scalar tile advance, out-of-range offsets for the rows past a segment's end) instead of per-lane pointers (d = 40 / 80) */
 int mv_set_attn_variant(int variant);
 
 /* ---- temporal self-attention over T <= 32 frames per pixel (K6c) -------------------------------------

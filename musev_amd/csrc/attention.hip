@@ -99,6 +99,10 @@ __device__ __forceinline__ void attn_commit(const u32x4 (&pf)[AttnCfg<D>::PF], c
     }
 }
 
+// OPT = 3: OPT 1 with the K/V tile fetch through buffer descriptors (one per operand and segment): a thread's chunk offsets
+// are fixed for the whole segment, the tile advance is the scalar offset, and rows past the segment end use an out-of-range
+// offset that reads zero -- the per-tile 64-bit pointer selects of the register-staged prefetch (~25 VALU ops of a
+// VALU-bound loop) disappear.  K and V chunks are fetched by separate instructions so that the descriptor is uniform.
 // OPT = 1 (d = 40 only, where the softmax VALU work -- not the MFMAs -- bounds the kernel): the row sums come out of
 // the P.V MFMA itself through a column of ones parked in the unused d-columns [40, 48) of the V tile, the running max
 // uses 3-input maxima, and the O rescale is skipped (exactly: alpha == 1) while no row maximum of the wave moves.
@@ -165,6 +169,21 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
         stg.goff[i] = ch * 8;  // + row * ld, filled per segment
     }
 
+    constexpr bool BUF = (OPT == 3);
+    constexpr int PFH = (C::CHUNKS + 255) / 256;  // BUF: 16-byte chunks per thread and operand
+    constexpr unsigned kOOBA = 0x80000000u;       // out of range for every descriptor below (num_records < 2 GiB)
+    u32x4 pfk[PFH], pfv[PFH];
+    // chunk (tid + 256 i) of a tile: row = chunk / DCH, 16-byte slot = chunk % DCH; only the LDS offsets are kept in
+    // registers, row / slot are recomputed where a segment or a partial tile needs them (register budget: 128 at d = 40)
+    int b_loffk[PFH], b_loffv[PFH];
+#pragma unroll
+    for (int i = 0; i < PFH; ++i) {
+        const int cidx = tid + 256 * i;
+        const int row = cidx / C::DCH, ch = cidx - row * C::DCH;
+        b_loffk[i] = row * C::KRS + ch * 8;
+        b_loffv[i] = C::KV * C::KRS + row * C::VRS + ch * 8;
+    }
+
 #pragma unroll 1
     for (int seg = 0; seg < p.nseg; ++seg) {
         const int len = ATTN_SEG_FIELD(p, seg, len);
@@ -174,18 +193,63 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
         const half_t* kb = ATTN_SEG_FIELD(p, seg, k) + kvb * len * ldk + h * D;
         const half_t* vb = ATTN_SEG_FIELD(p, seg, v) + kvb * len * ldv + h * D;
         AttnStage<D> st = stg;
+        // BUF: per-segment byte offsets of this thread's chunks inside a tile; descriptors over this (frame, head)'s rows
+        unsigned b_vk[PFH], b_vv[PFH];
+        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
+        auto buf_prefetch = [&](int b0) __attribute__((always_inline)) {
+            if (b0 >= len) return;  // uniform: nothing follows the last tile of a segment
+            const int sk = b0 * (int)ldk * 2, sv = b0 * (int)ldv * 2;  // scalar byte offsets of the tile
+            if (b0 + C::KV > len) {  // uniform: the partial last tile masks its rows past the end
 #pragma unroll
-        for (int i = 0; i < C::PF; ++i) {
-            const int r = st.row[i] < C::KV ? st.row[i] : 0;
-            st.goff[i] += (long)r * (st.isv[i] ? ldv : ldk);
+                for (int i = 0; i < PFH; ++i) {
+                    const bool ok = b0 + (tid + 256 * i) / C::DCH < len;  // inactive chunks already carry kOOBA
+                    pfk[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)(ok ? b_vk[i] : kOOBA), sk, 0);
+                    pfv[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)(ok ? b_vv[i] : kOOBA), sv, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PFH; ++i) {
+                    pfk[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)b_vk[i], sk, 0);
+                    pfv[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)b_vv[i], sv, 0);
+                }
+            }
+        };
+        if constexpr (BUF) {
+#pragma unroll
+            for (int i = 0; i < PFH; ++i) {
+                const int cidx = tid + 256 * i;
+                const int row = cidx / C::DCH, ch = cidx - row * C::DCH;
+                const bool act = cidx < C::CHUNKS;
+                b_vk[i] = act ? (unsigned)((row * (int)ldk + ch * 8) * 2) : kOOBA;
+                b_vv[i] = act ? (unsigned)((row * (int)ldv + ch * 8) * 2) : kOOBA;
+            }
+            buf_prefetch(0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::PF; ++i) {
+                const int r = st.row[i] < C::KV ? st.row[i] : 0;
+                st.goff[i] += (long)r * (st.isv[i] ? ldv : ldk);
+            }
+            attn_prefetch<D>(pf, st, kb, vb, ldk, ldv, 0, len, zero);
         }
-        attn_prefetch<D>(pf, st, kb, vb, ldk, ldv, 0, len, zero);
       for (int cur_base = 0; cur_base < len; cur_base += C::KV) {
         __syncthreads();  // previous tile fully consumed (also orders the initial zero fill)
-        attn_commit<D>(pf, st, lds);
+        if constexpr (BUF) {
+#pragma unroll
+            for (int i = 0; i < PFH; ++i) {
+                if (tid + 256 * i < C::CHUNKS) {
+                    *reinterpret_cast<u32x4*>(lds + b_loffk[i]) = pfk[i];
+                    *reinterpret_cast<u32x4*>(lds + b_loffv[i]) = pfv[i];
+                }
+            }
+        } else {
+            attn_commit<D>(pf, st, lds);
+        }
         __syncthreads();
-        // prefetch the next tile of this segment while this one is computed (past the end: zero page)
-        attn_prefetch<D>(pf, st, kb, vb, ldk, ldv, cur_base + C::KV, len, zero);
+        // prefetch the next tile of this segment while this one is computed (past the end: zero page / nothing)
+        if constexpr (BUF) buf_prefetch(cur_base + C::KV);
+        else attn_prefetch<D>(pf, st, kb, vb, ldk, ldv, cur_base + C::KV, len, zero);
 
         // ---- S^T = K Q^T : acc_s[qt][st][r] = S[q = l15][kv = 16 st + 4 g + r] ----
         float4v acc_s[C::QT][4];
@@ -599,6 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
 }
 
 int g_attn_pkrtz = 0;    // +8 on mv_set_attn_variant: round-toward-zero packing of P (variant 3, d = 40)
+int g_attn_buf = 0;      // +16: K/V tiles fetched through buffer descriptors (attn_kernel<D, 3>, d = 40 / 80)
 int g_attn_variant = 3;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
 
 // ------------------------------------------------------------------------------------------------------
@@ -797,11 +862,12 @@ int g_tattn_variant = 2;  // 1 = tattn_kernel, 2 = tattn2_kernel where it applie
 }  // namespace
 
 extern "C" int mv_set_attn_variant(int v) {
-    // bits 0-1: spatial attention kernel (1 | 2); +4: temporal attention v1 instead of v2
+    // bits 0-1: spatial attention kernel (1 | 2 | 3); +4: temporal attention v1 instead of v2; +8: pkrtz; +16: buffer-descriptor K/V fetch
     MV_REQUIRE((v & 3) >= 1, "mv_set_attn_variant: variant %d", v);
     g_attn_variant = v & 3;
     g_tattn_variant = (v & 4) ? 1 : 2;
     g_attn_pkrtz = (v & 8) ? 1 : 0;
+    g_attn_buf = (v & 16) ? 1 : 0;
     return MV_OK;
 }
 
@@ -832,6 +898,8 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->d == 40 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<40>, grid, dim3(256), 0, s, a);
     else if (d->d == 80 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<80>, grid, dim3(256), 0, s, a);
+    else if (d->d == 40 && g_attn_variant == 3 && g_attn_buf) hipLaunchKernelGGL((attn_kernel<40, 3>), grid, dim3(256), 0, s, a);
+    else if (d->d == 80 && g_attn_variant == 3 && g_attn_buf) hipLaunchKernelGGL((attn_kernel<80, 3>), grid, dim3(256), 0, s, a);
     else if (d->d == 40 && g_attn_variant == 3 && g_attn_pkrtz) hipLaunchKernelGGL((attn_kernel<40, 2>), grid, dim3(256), 0, s, a);
     else if (d->d == 40 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<40, 1>), grid, dim3(256), 0, s, a);
     else if (d->d == 80 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<80, 1>), grid, dim3(256), 0, s, a);
