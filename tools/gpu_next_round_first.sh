@@ -18,3 +18,6 @@ cat $OUT/${TAG}_bench_v8.log
 ( MUSEV_GEMM_TILE_GROUP=0 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200 ) > $OUT/${TAG}_bench_mmajor.log
 ( timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200 ) > $OUT/${TAG}_bench_grouped.log
 cat $OUT/${TAG}_bench_mmajor.log $OUT/${TAG}_bench_grouped.log
+# 5. kernel-level A/B incl. the attention variants (3 default, 11 pkrtz, 19 buffer-descriptor K/V fetch) and GEMM variants 2 / 8
+( timeout 420 python tools/gpu_gemm_ab.py ${TAG}_ab 2 8 2>&1 | tail -60 ) > $OUT/${TAG}_kernel_ab.log
+tail -45 $OUT/${TAG}_kernel_ab.log
