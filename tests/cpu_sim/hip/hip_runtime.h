@@ -1,0 +1,179 @@
+// Host stand-in for <hip/hip_runtime.h> (TEST INFRASTRUCTURE, tests/test_kernel_cpu_sim.py): lets the UNMODIFIED kernel
+// sources of musev_amd/csrc be compiled for x86 and executed thread-per-lane, so that the index arithmetic, predicates,
+// LDS layouts, barrier protocol and MFMA fragment layouts of a kernel can be checked against a torch reference without a
+// GPU.  What it models:
+//   * a block = blockDim.x OS threads; __syncthreads / s_barrier = pthread barrier; one 64-thread barrier per wave;
+//   * v_mfma_f32_16x16x32_f16 with the CDNA3/4 lane layout (A: lane l -> row l%16, k 8*(l/16)..+7; B alike with the column;
+//     D: lane l -> rows 4*(l/16)..+3 of column l%16), fp32 accumulation;
+//   * buffer descriptors: raw_ptr_buffer_load_lds / raw_buffer_load_b128 with the range check on the VGPR offset (an offset
+//     >= num_records reads zero) and a hard failure if an in-range lane would touch bytes outside the allocation;
+//   * LDS-DMA completion time: SIM_DEFER=1 delays every LDS-DMA write until the issuing thread's next s_waitcnt vmcnt(N) /
+//     __syncthreads (the LATEST legal landing), SIM_DEFER=0 performs it at issue (the EARLIEST) -- a kernel has to be right
+//     under both;
+//   * dynamic shared memory = one global `smem` array (blocks run one after another).
+// What it cannot model: timing, bank conflicts, occupancy, alignment faults, anything about performance.
+#pragma once
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <deque>
+#include <functional>
+#include <thread>
+#include <vector>
+
+struct uint4 { unsigned x, y, z, w; };
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipFuncAttributeMaxDynamicSharedMemorySize = 8, hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "sim"; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) {  // SIM_CUS: lets small problems meet the one-round-grid rules
+    const char* e = getenv("SIM_CUS");
+    *v = e ? atoi(e) : 256;
+    return hipSuccess;
+}
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__
+#define __expf expf
+
+static thread_local dim3 threadIdx, blockIdx;
+static dim3 blockDim, gridDim;
+namespace {  // a block-scope `extern char smem[]` inside the kernels' anonymous namespace names a member of THAT namespace
+alignas(64) char smem[160 * 1024];  // `extern __shared__ ... char smem[]` of the kernels binds to this
+}
+static pthread_barrier_t sim_block_bar;
+static pthread_barrier_t sim_wave_bar[16];
+static int sim_defer = 0;
+
+typedef _Float16 sim_half8 __attribute__((ext_vector_type(8)));
+typedef float sim_float4 __attribute__((ext_vector_type(4)));
+typedef unsigned sim_u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- pending LDS-DMA writes of the calling thread (SIM_DEFER) ----
+struct SimDma { unsigned char data[16]; void* dst; };
+static thread_local std::deque<SimDma> sim_dma;
+static inline void sim_retire(size_t keep) {
+    while (sim_dma.size() > keep) {
+        memcpy(sim_dma.front().dst, sim_dma.front().data, 16);
+        sim_dma.pop_front();
+    }
+}
+static inline void sim_waitcnt_vm(int n) { sim_retire((size_t)n); }
+static inline void __syncthreads() { sim_retire(0); pthread_barrier_wait(&sim_block_bar); }  // s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
+static inline void sim_s_barrier() { pthread_barrier_wait(&sim_block_bar); }
+static inline void sim_wave_barrier() { pthread_barrier_wait(&sim_wave_bar[threadIdx.x >> 6]); }
+#define __builtin_amdgcn_s_barrier sim_s_barrier
+#define __builtin_amdgcn_wave_barrier sim_wave_barrier
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+template <typename T> static inline T __shfl_xor(T v, int, int) { return v; }  // declared for common.h; unused by the simulated kernels
+
+static void sim_dma_write(void* dst, const void* src16) {
+    if (sim_defer) {
+        SimDma d;
+        if (src16) memcpy(d.data, src16, 16); else memset(d.data, 0, 16);
+        d.dst = dst;
+        sim_dma.push_back(d);
+    } else if (src16) memcpy(dst, src16, 16); else memset(dst, 0, 16);
+}
+
+// ---- buffer descriptors ----
+struct SimRsrc { const char* base; unsigned num; };
+#define __amdgpu_buffer_rsrc_t SimRsrc
+static inline SimRsrc sim_make_rsrc(void* p, int, unsigned num, unsigned) { return SimRsrc{(const char*)p, num}; }
+#define __builtin_amdgcn_make_buffer_rsrc sim_make_rsrc
+static inline const char* sim_buf_addr(const SimRsrc& r, int voff, int soff, int ioff) {
+    const unsigned vo = (unsigned)voff + (unsigned)ioff;
+    if (vo >= r.num) return nullptr;  // range check on the VGPR (+ instruction) offset: reads zero
+    const unsigned long total = (unsigned long)vo + (unsigned)soff;
+    if (r.num != 0x7fffffffu && total + 16 > r.num) {  // an in-range lane must stay inside the bytes the descriptor covers
+        fprintf(stderr, "SIM: buffer load overruns its descriptor: voffset %u + soffset %u + 16 > %u\n", vo, (unsigned)soff, r.num);
+        abort();
+    }
+    return r.base + total;
+}
+static inline void sim_buffer_load_lds(SimRsrc r, __attribute__((address_space(3))) void* lds, int size, int voff, int soff, int ioff, int) {
+    if (size != 16) abort();
+    sim_dma_write((char*)(void*)lds + 16 * (threadIdx.x & 63), sim_buf_addr(r, voff, soff, ioff));
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds sim_buffer_load_lds
+static inline sim_u32x4 sim_buffer_load_b128(SimRsrc r, int voff, int soff, int) {
+    sim_u32x4 v = {0, 0, 0, 0};
+    const char* a = sim_buf_addr(r, voff, soff, 0);
+    if (a) memcpy(&v, a, 16);
+    return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b128 sim_buffer_load_b128
+static inline void sim_global_load_lds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* lds, int size, int off, int) {
+    if (size != 16) abort();
+    sim_dma_write((char*)(void*)lds + 16 * (threadIdx.x & 63), (const char*)(const void*)g + off);
+}
+#define __builtin_amdgcn_global_load_lds sim_global_load_lds
+
+// ---- MFMA 16x16x32 f16 ----
+static _Float16 sim_mfma_a[16][64][8], sim_mfma_b[16][64][8];
+static inline sim_float4 sim_mfma_16x16x32_f16(sim_half8 a, sim_half8 b, sim_float4 c, int, int, int) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = 0; j < 8; ++j) {
+        sim_mfma_a[wave][lane][j] = a[j];
+        sim_mfma_b[wave][lane][j] = b[j];
+    }
+    sim_wave_barrier();
+    const int col = lane & 15, g = lane >> 4;
+    sim_float4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k)
+            acc += (float)sim_mfma_a[wave][(k >> 3) * 16 + row][k & 7] * (float)sim_mfma_b[wave][(k >> 3) * 16 + col][k & 7];
+        d[r] += acc;
+    }
+    sim_wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 sim_mfma_16x16x32_f16
+
+// ---- launch ----
+static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
+    if (smem_bytes > sizeof(smem) || block.x % 64 != 0 || block.x > 1024) { fprintf(stderr, "SIM: bad launch\n"); abort(); }
+    gridDim = grid;
+    blockDim = block;
+    const char* e = getenv("SIM_DEFER");
+    sim_defer = e ? atoi(e) : 0;
+    if (getenv("SIM_TRACE")) fprintf(stderr, "SIM launch grid %u x %u x %u block %u smem %zu\n", grid.x, grid.y, grid.z, block.x, smem_bytes);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                memset(smem, 0xCD, smem_bytes ? smem_bytes : 64);  // poison: reading LDS before it is written shows up as NaN-ish garbage
+                pthread_barrier_init(&sim_block_bar, nullptr, block.x);
+                for (unsigned w = 0; w < block.x / 64; ++w) pthread_barrier_init(&sim_wave_bar[w], nullptr, 64);
+                std::vector<std::thread> ts;
+                ts.reserve(block.x);
+                for (unsigned t = 0; t < block.x; ++t)
+                    ts.emplace_back([&, t]() {
+                        threadIdx = dim3(t, 0, 0);
+                        blockIdx = dim3(bx, by, bz);
+                        sim_dma.clear();
+                        body();
+                        sim_retire(0);
+                    });
+                for (auto& th : ts) th.join();
+                pthread_barrier_destroy(&sim_block_bar);
+                for (unsigned w = 0; w < block.x / 64; ++w) pthread_barrier_destroy(&sim_wave_bar[w]);
+            }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, smem_bytes, stream, ...) \
+    sim_launch(dim3(grid), dim3(block), (smem_bytes), [&]() { kernel(__VA_ARGS__); })

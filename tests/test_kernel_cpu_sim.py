@@ -67,3 +67,242 @@ def test_conv3x3_direct_kernel_on_the_host(conv_direct_bin, cin, cout, h, w, str
     err = (got - ref).abs()
     assert torch.isfinite(got).all()
     assert (err <= 3e-3 + 2e-3 * ref.abs()).all(), f"max err {err.max().item()}"
+
+
+# ---- the implicit-GEMM kernels (MFMA + LDS-DMA) through the real mv_gemm_f16 dispatch, on the host simulator -------------
+HIP_SIM = os.path.join(SIM, "hip")
+
+
+def _transform_gemm_source(text: str, big_tiles_everywhere: bool = False) -> str:
+    text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(ROOT, "musev_amd", "csrc", "common.h"))
+    # GCN inline assembly cannot be assembled for x86: the counted waits become simulator calls
+    text, n = re.subn(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)" ::: "memory"\)', r"sim_waitcnt_vm(\1)", text)
+    assert n >= 10
+    if big_tiles_everywhere:  # let small problems reach the 256x320 / 256x256 tiles (the rule wants >= 200 blocks on the GPU)
+        text, n = re.subn(r">= 200", ">= 1", text)
+        assert n >= 1
+    return text
+
+
+def _build_gemm_sim(work, big: bool):
+    src = open(os.path.join(ROOT, "musev_amd", "csrc", "gemm.hip")).read()
+    (work / "gemm_sim.inc").write_text(_transform_gemm_source(src, big))
+    shutil.copy(os.path.join(SIM, "gemm_main.cpp"), work / "gemm_main.cpp")
+    exe = work / ("gemm_sim_big" if big else "gemm_sim")
+    r = subprocess.run([CLANG, "-O1", "-std=c++17", "-pthread", "-w", "-I", SIM, "-I", str(work), "-o", str(exe), str(work / "gemm_main.cpp")],
+                       cwd=work, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def gemm_sim(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm host clang not available")
+    work = tmp_path_factory.mktemp("gemm_sim")
+    return work, _build_gemm_sim(work, False)
+
+
+def _run_gemm_job(work, exe, name, tensors: dict, ints: dict, defer: int, timeout=600, env_extra=None, trace=None):
+    d = work / name
+    d.mkdir(exist_ok=True)
+    for fn in ("a", "a2", "w", "bias", "rowbias", "residual", "alpha", "c"):
+        p = d / f"{fn}.bin"
+        if p.exists():
+            p.unlink()
+    for k, t in tensors.items():
+        if t is not None:
+            t.contiguous().numpy().tofile(d / f"{k}.bin")
+    (d / "job.txt").write_text("".join(f"{k} {int(v)}\n" for k, v in ints.items()))
+    env = dict(os.environ, SIM_DEFER=str(defer), SIM_TRACE="1", **(env_extra or {}))
+    r = subprocess.run([str(exe), str(d)], capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    if trace is not None:
+        trace.append(r.stderr)
+    M, ldc = ints["M"], ints["ldc"]
+    return torch.from_numpy(np.fromfile(d / "c.bin", dtype=np.float16).reshape(M, ldc)).float()
+
+
+def _close(got, ref, atol=4e-3, rtol=2e-3):
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    assert (err <= atol + rtol * ref.abs()).all(), f"max err {err.max().item()} (ref absmax {ref.abs().max().item()})"
+
+
+def _rnd(shape, seed, scale=1.0):
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).half()
+
+
+_BASE = dict(lda2=0, ldr=0, ldrb=0, c2=0, mode=0, stride=1, upsample=0, hin=0, win=0, hout=0, wout=0, t=0, hw=0, rows_per_group=0,
+             act=0, geglu=0, variant=2)
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+def test_gemm_linear_epilogue_on_the_host(gemm_sim, defer):
+    """ragged M (200 = 128 + 72), two n-tiles, K = 128 (two K steps), bias + per-group row bias + |alpha| + residual"""
+    work, exe = gemm_sim
+    M, N, K = 200, 320, 128
+    a, w, bias, res = _rnd((M, K), 1), _rnd((N, K), 2, 1 / math.sqrt(K)), _rnd((N,), 3), _rnd((M, N), 4)
+    rpg = 70
+    rowbias = _rnd((3, N), 5)
+    alpha = torch.tensor([-0.37])
+    ref = a.float() @ w.float().t() + bias.float() + rowbias.float()[torch.arange(M) // rpg]
+    ref = ref * 0.37 + res.float()
+    got = _run_gemm_job(work, exe, f"lin{defer}", dict(a=a, w=w, bias=bias, rowbias=rowbias, residual=res, alpha=alpha),
+                        dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, ldr=N, ldrb=N, c1=K, rows_per_group=rpg), defer)
+    _close(got, ref)
+
+
+def _conv_ref(x, wt, bias, stride=1, upsample=False):
+    xr = x.float()
+    if upsample:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xr, wt.float(), bias.float(), stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1).reshape(-1, wt.shape[0]), y.shape[2], y.shape[3]
+
+
+def _pack(wt):  # [O, I, *k] -> [O, taps * I], tap-major / channel-minor (mv_pack_conv_weight_f16)
+    o, i = wt.shape[0], wt.shape[1]
+    return wt.reshape(o, i, -1).permute(0, 2, 1).reshape(o, -1).contiguous()
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+@pytest.mark.parametrize("kind", ["plain", "stride2", "upsample", "two_src"])
+def test_gemm_conv3x3_on_the_host(gemm_sim, kind, defer):
+    """implicit-GEMM 3x3 convolution: halo predicates, tap-major K walk (9 taps x 64 channels = 9 K steps), stride 2,
+    fused nearest x2 upsample, two-source channel concat, bias + per-image row bias + residual"""
+    work, exe = gemm_sim
+    n, h, w, c1, c2, cout = 2, 6, 10, 64, 0, 160
+    stride, up = (2, False) if kind == "stride2" else (1, kind == "upsample")
+    if kind == "two_src":
+        c2 = 64
+    cin = c1 + c2
+    x = _rnd((n, cin, h, w), 20)
+    wt = _rnd((cout, cin, 3, 3), 21, 1 / math.sqrt(9 * cin))
+    bias = _rnd((cout,), 22)
+    ref, ho, wo = _conv_ref(x, wt, bias, stride, up)
+    temb = _rnd((n, cout), 23)
+    res = _rnd((n * ho * wo, cout), 24)
+    ref = ref + temb.float().repeat_interleave(ho * wo, dim=0) + res.float()
+    xl = x.permute(0, 2, 3, 1).reshape(n * h * w, cin).contiguous()
+    tensors = dict(a=xl[:, :c1].contiguous(), w=_pack(wt), bias=bias, rowbias=temb, residual=res)
+    if c2:
+        tensors["a2"] = xl[:, c1:].contiguous()
+    ints = dict(_BASE, M=n * ho * wo, N=cout, K=9 * cin, lda=c1, lda2=c2, ldc=cout, ldr=cout, ldrb=cout, c1=c1, c2=c2, mode=1,
+                stride=stride, upsample=int(up), hin=h, win=w, hout=ho, wout=wo, rows_per_group=ho * wo)
+    _close(_run_gemm_job(work, exe, f"conv_{kind}{defer}", tensors, ints, defer), ref, atol=6e-3)
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+def test_gemm_tconv3_geglu_and_narrow_on_the_host(gemm_sim, defer):
+    work, exe = gemm_sim
+    # temporal conv (3,1,1): rows (b, t, p), taps walk t -+ 1 with zero padding at the clip ends; |alpha| * conv + residual
+    b, t, hw, c = 2, 5, 12, 64
+    x = _rnd((b, c, t, hw, 1), 30)
+    wt = _rnd((c, c, 3, 1, 1), 31, 1 / math.sqrt(3 * c))
+    bias = _rnd((c,), 32)
+    ref = x.float() + 0.6 * F.conv3d(x.float(), wt.float(), bias.float(), padding=(1, 0, 0))
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(b * t * hw, c)
+    xl = x.permute(0, 2, 3, 4, 1).reshape(b * t * hw, c).contiguous()
+    got = _run_gemm_job(work, exe, f"tconv{defer}", dict(a=xl, w=_pack(wt), bias=bias, residual=xl, alpha=torch.tensor([0.6])),
+                        dict(_BASE, M=b * t * hw, N=c, K=3 * c, lda=c, ldc=c, ldr=c, c1=c, mode=2, t=t, hw=hw), defer)
+    _close(got, ref)
+    # GEGLU epilogue: packed [16 value | 16 gate] weight rows, output N/2 columns
+    M, C = 77, 64
+    a, wf, bf = _rnd((M, C), 33), _rnd((8 * C, C), 34, 1 / math.sqrt(C)), _rnd((8 * C,), 35, 0.1)
+    hfull = a.float() @ wf.float().t() + bf.float()
+    ref = hfull[:, :4 * C] * F.gelu(hfull[:, 4 * C:])
+    idx = torch.arange(4 * C).view(-1, 16)
+    perm = torch.cat([idx, idx + 4 * C], dim=1).reshape(-1)
+    got = _run_gemm_job(work, exe, f"geglu{defer}", dict(a=a, w=wf[perm].contiguous(), bias=bf[perm].contiguous()),
+                        dict(_BASE, M=M, N=8 * C, K=C, lda=C, ldc=4 * C, c1=C, geglu=1), defer)
+    _close(got, ref)
+    # narrow epilogue: N = 36 (not a multiple of 8), ragged K = 72, SiLU
+    M, N, K = 50, 36, 72
+    a, w2, b2 = _rnd((M, K), 36), _rnd((N, K), 37, 1 / math.sqrt(K)), _rnd((N,), 38)
+    got = _run_gemm_job(work, exe, f"narrow{defer}", dict(a=a, w=w2, bias=b2), dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, c1=K, act=1), defer)
+    _close(got, F.silu(a.float() @ w2.float().t() + b2.float()))
+
+
+@pytest.mark.parametrize("variant", [1, 4, 5, 6])
+def test_gemm_variants_on_the_host(gemm_sim, variant):
+    """the knob-selected kernels: v1 LDS-DMA (1), persistent tile loop (4), 8-wave tiles on the three-stage counted-wait ring
+    (5), BK-32 four-stage ring (6) -- with the LATEST legal LDS-DMA landing (SIM_DEFER=1), which is what a counted
+    s_waitcnt vmcnt(N) protocol has to survive"""
+    work, exe = gemm_sim
+    M, N, K = 300, 320, 256
+    a, w, bias, res = _rnd((M, K), 40), _rnd((N, K), 41, 1 / math.sqrt(K)), _rnd((N,), 42), _rnd((M, N), 43)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    got = _run_gemm_job(work, exe, f"var{variant}", dict(a=a, w=w, bias=bias, residual=res),
+                        dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, ldr=N, c1=K, variant=variant), 1)
+    _close(got, ref)
+
+
+@pytest.mark.parametrize("group", [0, 8])
+def test_gemm_tile_order_on_the_host(gemm_sim, group):
+    """a grid 2 x 10 tiles (wider than the group of 8): every output element is produced exactly once in either order, and
+    the two orders give bit-identical results"""
+    work, exe = gemm_sim
+    M, N, K = 200, 1600, 64
+    a, w = _rnd((M, K), 50), _rnd((N, K), 51, 1 / math.sqrt(K))
+    got = _run_gemm_job(work, exe, f"order{group}", dict(a=a, w=w), dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, c1=K, tile_group=group), 0)
+    _close(got, a.float() @ w.float().t())
+    (work / f"order_result_{group}.pt").write_bytes(got.numpy().tobytes())
+    other = work / f"order_result_{8 - group}.pt"
+    if other.exists():
+        assert other.read_bytes() == got.numpy().tobytes(), "grouped and m-major tile orders must give identical bits"
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+def test_gemm_eight_wave_three_stage_ring_on_the_host(gemm_sim, defer):
+    """the DEFAULT rule's one-round-grid kernel (8 waves, 256x160, three LDS stages behind counted s_waitcnt vmcnt(N) + raw
+    s_barrier): reached here by telling the dispatch the chip has 4 CUs; K = 320 = 5 K steps through a 3-deep ring"""
+    work, exe = gemm_sim
+    M, N, K = 500, 320, 320
+    a, w, bias, res = _rnd((M, K), 60), _rnd((N, K), 61, 1 / math.sqrt(K)), _rnd((N,), 62), _rnd((M, N), 63)
+    trace = []
+    got = _run_gemm_job(work, exe, f"ring{defer}", dict(a=a, w=w, bias=bias, residual=res),
+                        dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, ldr=N, c1=K), defer, env_extra=dict(SIM_CUS="4"), trace=trace)
+    assert "block 512" in trace[0], trace[0]
+    _close(got, a.float() @ w.float().t() + bias.float() + res.float())
+
+
+@pytest.fixture(scope="module")
+def gemm_sim_big(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm host clang not available")
+    work = tmp_path_factory.mktemp("gemm_sim_big")
+    return work, _build_gemm_sim(work, True)
+
+
+@pytest.mark.parametrize("kind", ["linear320", "conv320", "geglu256"])
+def test_gemm_big_tiles_on_the_host(gemm_sim_big, kind):
+    """the opt-in 256x320 (8 waves as 2x4, wave tile 128x80) and 256x256-GEGLU tiles (MUSEV_GEMM_VARIANT=8), with the
+    >= 200-block rule relaxed in this build of the dispatch so that a small problem reaches them"""
+    work, exe = gemm_sim_big
+    trace = []
+    if kind == "linear320":
+        M, N, K = 300, 640, 640
+        a, w, bias, res = _rnd((M, K), 70), _rnd((N, K), 71, 1 / math.sqrt(K)), _rnd((N,), 72), _rnd((M, N), 73)
+        got = _run_gemm_job(work, exe, kind, dict(a=a, w=w, bias=bias, residual=res),
+                            dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, ldr=N, c1=K, variant=8), 1, trace=trace)
+        ref = a.float() @ w.float().t() + bias.float() + res.float()
+    elif kind == "conv320":
+        n, h, w_, cin, cout = 2, 12, 12, 128, 320
+        x, wt, bias = _rnd((n, cin, h, w_), 74), _rnd((cout, cin, 3, 3), 75, 1 / math.sqrt(9 * cin)), _rnd((cout,), 76)
+        ref, ho, wo = _conv_ref(x, wt, bias)
+        xl = x.permute(0, 2, 3, 1).reshape(n * h * w_, cin).contiguous()
+        got = _run_gemm_job(work, exe, kind, dict(a=xl, w=_pack(wt), bias=bias),
+                            dict(_BASE, M=n * ho * wo, N=cout, K=9 * cin, lda=cin, ldc=cout, c1=cin, mode=1, hin=h, win=w_, hout=ho, wout=wo,
+                                 variant=8), 1, trace=trace)
+    else:
+        M, C = 300, 64
+        a, wf, bf = _rnd((M, C), 77), _rnd((8 * C, C), 78, 1 / math.sqrt(C)), _rnd((8 * C,), 79, 0.1)
+        hfull = a.float() @ wf.float().t() + bf.float()
+        ref = hfull[:, :4 * C] * F.gelu(hfull[:, 4 * C:])
+        idx = torch.arange(4 * C).view(-1, 16)
+        perm = torch.cat([idx, idx + 4 * C], dim=1).reshape(-1)
+        got = _run_gemm_job(work, exe, kind, dict(a=a, w=wf[perm].contiguous(), bias=bf[perm].contiguous()),
+                            dict(_BASE, M=M, N=8 * C, K=C, lda=C, ldc=4 * C, c1=C, geglu=1, variant=8), 1, trace=trace)
+    assert "block 512" in trace[0], trace[0]
+    _close(got, ref, atol=6e-3)
