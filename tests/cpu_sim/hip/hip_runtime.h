@@ -45,7 +45,11 @@ static inline hipError_t hipDeviceGetAttribute(int* v, int, int) {  // SIM_CUS: 
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#ifdef SIM_SHARED_STATIC  // kernels with `__shared__ T buf[N];` inside the function: one static buffer, blocks run one at a time
+#define __shared__ static
+#else
 #define __shared__
+#endif
 #define __expf expf
 
 static thread_local dim3 threadIdx, blockIdx;
@@ -79,7 +83,6 @@ static inline void sim_wave_barrier() { pthread_barrier_wait(&sim_wave_bar[threa
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-template <typename T> static inline T __shfl_xor(T v, int, int) { return v; }  // declared for common.h; unused by the simulated kernels
 
 static void sim_dma_write(void* dst, const void* src16) {
     if (sim_defer) {
@@ -145,6 +148,61 @@ static inline sim_float4 sim_mfma_16x16x32_f16(sim_half8 a, sim_half8 b, sim_flo
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 sim_mfma_16x16x32_f16
+
+// ---- cross-lane operations (one exchange buffer per wave, two wave barriers per operation) ----
+static float sim_xchg[16][64];
+static inline float sim_lane_read(float v, int src_lane) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    sim_xchg[wave][lane] = v;
+    sim_wave_barrier();
+    const float r = sim_xchg[wave][src_lane & 63];
+    sim_wave_barrier();
+    return r;
+}
+static inline float __shfl_xor(float v, int mask, int) { return sim_lane_read(v, (int)(threadIdx.x & 63) ^ mask); }
+static inline float __shfl(float v, int src, int) { return sim_lane_read(v, src); }
+static inline int __any(int pred) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    sim_xchg[wave][lane] = pred ? 1.f : 0.f;
+    sim_wave_barrier();
+    int r = 0;
+    for (int i = 0; i < 64; ++i) r |= sim_xchg[wave][i] != 0.f;
+    sim_wave_barrier();
+    return r;
+}
+// ds_read_b64_tr_b16 as measured by mv_probe_tr16 on the MI355X (tests/kernel_cases.case_tr16_probe): the 16 lanes of a group
+// each address 4 consecutive 16-bit elements; lane i of the group receives element (i & 3) of the chunks of lanes
+// 4j + (i >> 2), j = 0..3 -- i.e. column i of the 4 x 16 block the group addresses row-wise
+typedef short sim_short4 __attribute__((ext_vector_type(4)));
+static short sim_tr[16][64][4];
+static inline sim_short4 sim_ds_read_tr16_b64(__attribute__((address_space(3))) sim_short4* p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    memcpy(sim_tr[wave][lane], (const void*)p, 8);
+    sim_wave_barrier();
+    const int g = lane >> 4, i = lane & 15;
+    sim_short4 r;
+    for (int j = 0; j < 4; ++j) r[j] = sim_tr[wave][16 * g + 4 * j + (i >> 2)][i & 3];
+    sim_wave_barrier();
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16 sim_ds_read_tr16_b64
+#define __builtin_amdgcn_exp2f exp2f
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+typedef __fp16 sim_fp16x2 __attribute__((ext_vector_type(2)));
+static inline uint16_t sim_rtz_half_bits(float x) {  // v_cvt_pkrtz_f16_f32: round toward zero
+    _Float16 h = (_Float16)x;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    if (fabsf((float)h) > fabsf(x)) b -= 1;  // one ulp toward zero (same sign, smaller magnitude)
+    return b;
+}
+static inline sim_fp16x2 sim_cvt_pkrtz(float a, float b) {
+    const uint16_t bits[2] = {sim_rtz_half_bits(a), sim_rtz_half_bits(b)};
+    sim_fp16x2 r;
+    memcpy(&r, bits, 4);
+    return r;
+}
+#define __builtin_amdgcn_cvt_pkrtz sim_cvt_pkrtz
 
 // ---- launch ----
 static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {

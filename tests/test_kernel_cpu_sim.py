@@ -306,3 +306,105 @@ def test_gemm_big_tiles_on_the_host(gemm_sim_big, kind):
                             dict(_BASE, M=M, N=8 * C, K=C, lda=C, ldc=4 * C, c1=C, geglu=1, variant=8), 1, trace=trace)
     assert "block 512" in trace[0], trace[0]
     _close(got, ref, atol=6e-3)
+
+
+# ---- the attention kernels (MFMA, transpose LDS reads, cross-lane softmax reductions) on the host simulator ---------------
+@pytest.fixture(scope="module")
+def attn_sim(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm host clang not available")
+    work = tmp_path_factory.mktemp("attn_sim")
+    text = open(os.path.join(ROOT, "musev_amd", "csrc", "attention.hip")).read()
+    text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(ROOT, "musev_amd", "csrc", "common.h"))
+    # dynamic LDS (`extern __shared__ T name[];`) becomes a pointer into the simulator's block buffer; static LDS -> `static`
+    text, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) (\w+) (\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(smem);", text)
+    assert n >= 1
+    (work / "attention_sim.inc").write_text(text)
+    shutil.copy(os.path.join(SIM, "attention_main.cpp"), work / "attention_main.cpp")
+    exe = work / "attention_sim"
+    r = subprocess.run([CLANG, "-O1", "-std=c++17", "-pthread", "-w", "-I", SIM, "-I", str(work), "-o", str(exe), str(work / "attention_main.cpp")],
+                       cwd=work, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return work, exe
+
+
+def _run_attn_job(work, exe, name, tensors: dict, kv: dict, timeout=900):
+    d = work / name
+    d.mkdir(exist_ok=True)
+    for p in d.glob("*.bin"):
+        p.unlink()
+    for k, t in tensors.items():
+        t.contiguous().numpy().tofile(d / f"{k}.bin")
+    (d / "job.txt").write_text("".join(f"{k} {float(v)!r}\n" for k, v in kv.items()))
+    r = subprocess.run([str(exe), str(d)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, SIM_TRACE="1"))
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    return torch.from_numpy(np.fromfile(d / "out.bin", dtype=np.float16).reshape(int(kv["rows"]), int(kv["ldo"]))).float()
+
+
+def _attn_ref(q, ks, vs, heads, d, scale):
+    nb, lq, c = q.shape
+    qh = q.float().view(nb, lq, heads, d).transpose(1, 2)
+    kh = ks.float().view(nb, -1, heads, d).transpose(1, 2)
+    vh = vs.float().view(nb, -1, heads, d).transpose(1, 2)
+    o = torch.softmax((qh @ kh.transpose(-1, -2)) * scale, dim=-1) @ vh
+    return o.transpose(1, 2).reshape(nb * lq, c)
+
+
+@pytest.mark.parametrize("d,variant", [(40, 3), (40, 19), (40, 11), (40, 1), (80, 3), (80, 19), (160, 3), (40, 2)])
+def test_attention_self_plus_condition_frame_on_the_host(attn_sim, d, variant):
+    """reference-only self-attention: two segments (own frame | vision-condition frame of the batch item), ragged lengths
+    (lq = 70: a partial query tile; 70 keys per segment: a partial key tile), fused QKV storage (ld = 3C)"""
+    work, exe = attn_sim
+    heads, b, t, lq = 2, 1, 2, 70
+    c, nb = heads * d, 1 * 2
+    qkv = _rnd((nb * lq, 3 * c), 80 + d)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    scale = d ** -0.5
+    k3, v3 = k.reshape(nb, lq, c), v.reshape(nb, lq, c)
+    cond = [(n // t) * t + 1 for n in range(nb)]
+    ref = _attn_ref(q.reshape(nb, lq, c), torch.cat([k3, k3[cond]], 1), torch.cat([v3, v3[cond]], 1), heads, d, scale)
+    # the kernels read q / k / v as column slices of ONE fused buffer: hand the simulator the same strided layout
+    kvj = dict(rows=nb * lq, ldo=c, variant=variant, temporal=0, ldq=3 * c, nb=nb, lq=lq, heads=heads, d=d, scale=scale, nseg=2,
+               accumulate=0, out_scale=1.0, ldk0=3 * c, ldv0=3 * c, len0=lq, div0=1, mul0=1, add0=0, ldk1=3 * c, ldv1=3 * c, len1=lq,
+               div1=t, mul1=t, add1=1)
+    flat = qkv.reshape(-1)
+    tensors = dict(q=flat, k0=flat[c:], v0=flat[2 * c:], k1=flat[c:], v1=flat[2 * c:])
+    got = _run_attn_job(work, exe, f"self_d{d}_v{variant}", tensors, kvj)
+    _close(got, ref, atol=3e-3)
+
+
+def test_attention_cross_accumulate_and_temporal_on_the_host(attn_sim):
+    work, exe = attn_sim
+    # text cross-attention (77 keys shared by the t frames of a batch item) + IP-Adapter second attention accumulated with a scale
+    heads, d, nb, t, lq, lk = 2, 80, 4, 2, 40, 77
+    c, b = heads * d, 2
+    q = _rnd((nb * lq, c), 90)
+    kvt = _rnd((b * lk, 2 * c), 91)
+    bidx = [n // t for n in range(nb)]
+    ref = _attn_ref(q.reshape(nb, lq, c), kvt[:, :c].reshape(b, lk, c)[bidx], kvt[:, c:].reshape(b, lk, c)[bidx], heads, d, d ** -0.5)
+    base = dict(rows=nb * lq, ldo=c, variant=3, temporal=0, ldq=c, nb=nb, lq=lq, heads=heads, d=d, scale=d ** -0.5, nseg=1, accumulate=0,
+                out_scale=1.0, ldk0=2 * c, ldv0=2 * c, len0=lk, div0=t, mul0=1, add0=0)
+    flat = kvt.reshape(-1)
+    got = _run_attn_job(work, exe, "cross", dict(q=q, k0=flat, v0=flat[c:]), base)
+    _close(got, ref, atol=3e-3)
+    kvi = _rnd((b * 4, 2 * c), 92)
+    ref_ip = _attn_ref(q.reshape(nb, lq, c), kvi[:, :c].reshape(b, 4, c)[bidx], kvi[:, c:].reshape(b, 4, c)[bidx], heads, d, d ** -0.5)
+    fl2 = kvi.reshape(-1)
+    got2 = _run_attn_job(work, exe, "cross_ip", dict(q=q, k0=fl2, v0=fl2[c:], out0=got.half()),
+                         dict(base, len0=4, accumulate=1, out_scale=0.7))
+    _close(got2, got.half().float() + 0.7 * ref_ip, atol=3e-3)
+    # temporal attention over t = 13 frames per pixel (rows stay in (b, t, p) order), both kernels
+    bb, tt, hw, heads, d = 1, 13, 9, 2, 40
+    c = heads * d
+    qkv = _rnd((bb * tt * hw, 3 * c), 93)
+
+    def seq(x):
+        return x.reshape(bb, tt, hw, c).permute(0, 2, 1, 3).reshape(bb * hw, tt, c)
+    ref = _attn_ref(seq(qkv[:, :c]), seq(qkv[:, c:2 * c]), seq(qkv[:, 2 * c:]), heads, d, d ** -0.5)
+    ref = ref.reshape(bb, hw, tt, c).permute(0, 2, 1, 3).reshape(bb * tt * hw, c)
+    flat = qkv.reshape(-1)
+    for variant in (3, 7):  # 3: K/V staged in LDS (tattn2); +4: per-lane global fetch (tattn v1)
+        got = _run_attn_job(work, exe, f"temporal{variant}", dict(q=flat, k0=flat[c:], v0=flat[2 * c:]),
+                            dict(rows=bb * tt * hw, ldo=c, variant=variant, temporal=1, ldq=3 * c, ldk0=3 * c, ldv0=3 * c, b=bb, t=tt, hw=hw,
+                                 heads=heads, d=d, scale=d ** -0.5))
+        _close(got, ref, atol=3e-3)
