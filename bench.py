@@ -184,6 +184,33 @@ def cpu_baseline(flavour: str, full_flops: float, frames: int, threads: int, sta
     }
 
 
+def build_unet(flavour: str, dev):
+    """real architecture, seeded random fp16 weights (the same on every rank): built on the meta device and materialised +
+    randomised directly on the GPU (a CPU init of 1.42 B parameters would burn minutes of GPU-box time); the philox generator
+    gives every rank identical weights"""
+    from musev_amd.models.layers import bump_pack_epoch
+    from musev_amd.models.unet_loader import load_unet_by_name
+    with torch.device("meta"):
+        unet = load_unet_by_name(flavour, dtype=torch.float16)
+    unet = unet.to_empty(device=dev)
+    gg = torch.Generator(device=dev).manual_seed(3)
+    res_out = ("conv2.weight", "to_out.0.weight", "ff.net.2.weight", "proj_out.weight", "conv4.3.weight")
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if name.endswith("temporal_weight"):   # the reference zero-initialises these branches (SURVEY 8c): re-randomise
+                p.copy_(0.1 + 0.9 * torch.rand(p.shape, generator=gg, device=dev))
+            elif p.ndim >= 2:
+                gain = 0.3 if name.endswith(res_out) else 1.0
+                p.copy_(torch.randn(p.shape, generator=gg, device=dev) * (gain / p[0].numel() ** 0.5))
+            elif name.endswith(".weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=gg, device=dev))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=gg, device=dev))
+    unet.eval()
+    bump_pack_epoch()
+    return unet
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,28 +255,7 @@ def main():
         T = 12 if world == 1 else 8 * world
     h = w = args.size // 8
 
-    # ---- model: real architecture, seeded random fp16 weights (same on every rank) ----
-    # built on the meta device and materialised + randomised directly on the GPU (a CPU init of 1.42 B parameters
-    # would burn minutes of GPU-box time); the philox generator gives every rank identical weights
-    with torch.device("meta"):
-        unet = load_unet_by_name(flavour, dtype=torch.float16)
-    unet = unet.to_empty(device=dev)
-    gg = torch.Generator(device=dev).manual_seed(3)
-    res_out = ("conv2.weight", "to_out.0.weight", "ff.net.2.weight", "proj_out.weight", "conv4.3.weight")
-    with torch.no_grad():
-        for name, p in unet.named_parameters():
-            if name.endswith("temporal_weight"):   # the reference zero-initialises these branches: re-randomise
-                p.copy_(0.1 + 0.9 * torch.rand(p.shape, generator=gg, device=dev))
-            elif p.ndim >= 2:
-                gain = 0.3 if name.endswith(res_out) else 1.0
-                p.copy_(torch.randn(p.shape, generator=gg, device=dev) * (gain / p[0].numel() ** 0.5))
-            elif name.endswith(".weight"):
-                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=gg, device=dev))
-            else:
-                p.copy_(0.05 * torch.randn(p.shape, generator=gg, device=dev))
-    unet.eval()
-    from musev_amd.models.layers import bump_pack_epoch
-    bump_pack_epoch()
+    unet = build_unet(flavour, dev)
 
     g = torch.Generator().manual_seed(0)
     latents = torch.randn(1, 4, T, h, w, generator=g).to(dev)

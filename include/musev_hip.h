@@ -79,6 +79,14 @@ int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
  * 6 = BK-32 four-stage ring, 7 = 256x320 tiles wherever they fit, 8 = 2 + 256x256 tiles for the GEGLU GEMM */
 int mv_set_gemm_variant(int variant);
 
+/* tile-configuration catalogue of the implicit-GEMM kernel (block tile, waves, K depth, LDS stages), for the per-shape
+ * tuner (tools/gpu_gemm_tune.py -> musev_amd/csrc/gemm_tuned.h) and A/B runs.  mv_set_gemm_force: cfg >= 0 uses that
+ * configuration wherever it applies (the GEGLU epilogue needs an even number of 16-column tiles per wave), -1 = tuned table +
+ * rules (default), -2 = rules only.  mv_gemm_config_desc fills {block rows, block columns, waves, BK, LDS stages}. */
+int mv_set_gemm_force(int cfg);
+int mv_gemm_num_configs(void);
+int mv_gemm_config_desc(int cfg, int32_t* desc5);
+
 /* workgroup -> output-tile order of the implicit-GEMM kernel: logical ids (contiguous per XCD) walk groups of `group`
  * m-tiles m-fastest when the grid is more than `group` n-tiles wide, so that the ~64 blocks resident on one XCD cover
  * ~8 x 8 tiles (what its L2 must fetch per window) instead of 1-3 m-tiles x the whole weight matrix.  Default 8;

@@ -62,6 +62,9 @@ SIGNATURES = {
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "mv_set_gemm_variant": (_i32, [_i32]),
     "mv_set_gemm_tile_group": (_i32, [_i32]),
+    "mv_set_gemm_force": (_i32, [_i32]),
+    "mv_gemm_num_configs": (_i32, []),
+    "mv_gemm_config_desc": (_i32, [_i32, _vp]),
     "mv_gemm_tile_order": (_i32, [_i32, _i32, _i32, _vp, _vp]),
     "mv_groupnorm_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
                                 _vp, _i32, _vp, _vp]),
@@ -113,6 +116,9 @@ def load() -> C.CDLL:
     variant = os.environ.get("MUSEV_GEMM_VARIANT")  # tuning knob for A/B runs (see mv_set_gemm_variant)
     if variant is not None:
         lib.mv_set_gemm_variant(int(variant))
+    force = os.environ.get("MUSEV_GEMM_FORCE")  # tile configuration id (see mv_set_gemm_force); -2 = ignore the tuned table
+    if force is not None:
+        lib.mv_set_gemm_force(int(force))
     group = os.environ.get("MUSEV_GEMM_TILE_GROUP")  # 0 = plain m-major tile order (see mv_set_gemm_tile_group)
     if group is not None:
         lib.mv_set_gemm_tile_group(int(group))

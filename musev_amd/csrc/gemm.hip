@@ -1144,11 +1144,66 @@ int launch_cfg2(const GemmArgs2& a, hipStream_t stream) {
     return launch_cfg2s<MODE, TM, TN, WGM, WGN, 0>(a, stream);
 }
 
+// ---- tile-configuration catalogue --------------------------------------------------------------------------------------
+// Every (wave tile TM x TN in 16-row / 16-column MFMA tiles, waves WGM x WGN, schedule) the kernel is instantiated for, under
+// a stable id: block tile = 16 TM WGM rows x 16 TN WGN columns.  The ids are what mv_set_gemm_force() and the per-shape table
+// of gemm_tuned.h (written by tools/gpu_gemm_tune.py from timings on the MI355X) refer to.  SCHED 0: BK 64, two LDS stages
+// behind __syncthreads; 3: BK 64, three stages behind counted waits; 4: BK 32, four stages behind counted waits.
+#define MV_GEMM_CFGS(X)                                                                                              \
+    X(0, 4, 5, 2, 2, 0)  /* 128x160, 4 waves            */ X(1, 2, 5, 2, 2, 0)   /* 64x160                     */      \
+    X(2, 4, 4, 2, 2, 0)  /* 128x128                     */ X(3, 2, 4, 2, 2, 0)   /* 64x128                     */      \
+    X(4, 4, 5, 4, 2, 3)  /* 256x160, 8 waves, 3 stages  */ X(5, 4, 4, 4, 2, 3)   /* 256x128, 8 waves, 3 stages */      \
+    X(6, 8, 5, 2, 4, 0)  /* 256x320, 8 waves            */ X(7, 8, 4, 2, 4, 0)   /* 256x256, 8 waves           */      \
+    X(8, 4, 5, 4, 2, 0)  /* 256x160, 8 waves, 2 stages  */ X(9, 4, 4, 4, 2, 0)   /* 256x128, 8 waves, 2 stages */      \
+    X(10, 4, 5, 2, 2, 4) /* 128x160, BK 32 x 4 stages   */ X(11, 2, 5, 2, 2, 4)  /* 64x160, BK 32 x 4          */      \
+    X(12, 4, 4, 2, 2, 4) /* 128x128, BK 32 x 4          */ X(13, 2, 4, 2, 2, 4)  /* 64x128, BK 32 x 4          */      \
+    X(14, 8, 4, 2, 4, 4) /* 256x256, 8 waves, BK 32 x 4 */ X(15, 4, 4, 2, 4, 3)  /* 128x256, 8 waves, 3 stages */      \
+    X(16, 4, 5, 2, 4, 0) /* 128x320, 8 waves            */ X(17, 2, 5, 4, 2, 3)  /* 128x160, 8 waves, 3 stages */      \
+    X(18, 8, 5, 2, 4, 4) /* 256x320, 8 waves, BK 32 x 4 */
+constexpr int kNumGemmCfgs = 19;
+struct GemmCfgDesc { int tm, tn, wgm, wgn, sched; };
+constexpr GemmCfgDesc kGemmCfgs[kNumGemmCfgs] = {
+#define MV_X(id, tm, tn, wgm, wgn, sched) {tm, tn, wgm, wgn, sched},
+    MV_GEMM_CFGS(MV_X)
+#undef MV_X
+};
+
+// a configuration can run a problem iff its epilogue can: the GEGLU gate pairs 16-column tiles, so TN must be even
+inline bool gemm_cfg_applies(int id, const GemmArgs& g) {
+    return id >= 0 && id < kNumGemmCfgs && (!g.geglu || (kGemmCfgs[id].tn & 1) == 0);
+}
+
+template <int MODE>
+int launch_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
+    switch (id) {
+#define MV_X(cid, tm, tn, wgm, wgn, sched) \
+    case cid: return launch_cfg2s<MODE, tm, tn, wgm, wgn, sched>(a, stream);
+        MV_GEMM_CFGS(MV_X)
+#undef MV_X
+    }
+    mv_set_error("mv_gemm_f16: unknown tile configuration %d", id);
+    return MV_ERR_INVALID;
+}
+
+// per-shape choices measured on the MI355X (exact match on mode / M / N / K / geglu; anything else follows the rules below)
+struct GemmTuned { int mode; long M; int N, K, geglu, cfg; };
+#include "gemm_tuned.h"
+int g_gemm_force = -1;      // mv_set_gemm_force: use this configuration wherever it applies (tuner / A-B runs); -1 = off
+int g_gemm_use_tuned = 1;   // the table applies to the default variant only
+
 // tile selection for the v2 kernel.  variant 2: the 4-wave tiles of v1; variant 3: 8-wave 256x160 tiles where the grid
 // still fills the chip (>= 2 blocks per CU worth of work).
 template <int MODE>
 int launch_mode2(const GemmArgs2& a, hipStream_t stream, int variant) {
     const GemmArgs& g = a.g;
+    if (g_gemm_force >= 0 && gemm_cfg_applies(g_gemm_force, g)) return launch_by_id<MODE>(a, stream, g_gemm_force);
+    if (variant == 2 && g_gemm_force < 0 && g_gemm_use_tuned) {
+        for (int i = 0; i < kNumGemmTuned; ++i) {
+            const GemmTuned& e = kGemmTuned[i];
+            if (e.mode == MODE && e.M == g.M && e.N == g.N && e.K == g.K && e.geglu == g.geglu && gemm_cfg_applies(e.cfg, g))
+                return launch_by_id<MODE>(a, stream, e.cfg);
+        }
+    }
     if (g.geglu) {
         // 256x256 tile (8 waves as 2 x 4, wave tile 128x64) where it still gives every CU a block: +5..+14 % on the FF1
         // projections (profiles/r01m_gemm_variant_ab.log); opt-in (variant 8), see the note on the 256x320 tile below
@@ -1208,6 +1263,26 @@ int launch_mode(const GemmArgs& a, hipStream_t stream) {
 extern "C" int mv_set_gemm_variant(int v) {
     MV_REQUIRE(v >= 0 && v <= 8, "mv_set_gemm_variant: variant %d not in [0, 8]", v);
     g_gemm_stage = v;
+    return MV_OK;
+}
+
+extern "C" int mv_set_gemm_force(int cfg) {
+    MV_REQUIRE(cfg >= -2 && cfg < kNumGemmCfgs, "mv_set_gemm_force: configuration %d not in [-2, %d)", cfg, kNumGemmCfgs);
+    g_gemm_use_tuned = cfg != -2;  // -2: rules only (ignore the tuned table); -1: table + rules; >= 0: this configuration
+    g_gemm_force = cfg < 0 ? -1 : cfg;
+    return MV_OK;
+}
+
+extern "C" int mv_gemm_num_configs(void) { return kNumGemmCfgs; }
+
+extern "C" int mv_gemm_config_desc(int cfg, int32_t* desc5) {
+    MV_REQUIRE(cfg >= 0 && cfg < kNumGemmCfgs && desc5, "mv_gemm_config_desc: bad args");
+    const GemmCfgDesc& c = kGemmCfgs[cfg];
+    desc5[0] = 16 * c.tm * c.wgm;  // block rows
+    desc5[1] = 16 * c.tn * c.wgn;  // block columns
+    desc5[2] = c.wgm * c.wgn;      // waves
+    desc5[3] = c.sched == 4 ? 32 : 64;                    // BK
+    desc5[4] = c.sched == 4 ? 4 : c.sched == 3 ? 3 : 2;   // LDS stages
     return MV_OK;
 }
 

@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
     d.alpha = alpha.empty() ? nullptr : (const float*)alpha.data();
     if (mv_set_gemm_variant((int)kv["variant"]) != 0) return 4;
     if (kv.count("tile_group")) mv_set_gemm_tile_group((int)kv["tile_group"]);
+    if (kv.count("force") && mv_set_gemm_force((int)kv["force"]) != 0) return 6;
     const int rc = mv_gemm_f16(&d, nullptr);
     if (rc != 0) {
         fprintf(stderr, "mv_gemm_f16 failed (%d): %s\n", rc, g_err);

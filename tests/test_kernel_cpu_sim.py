@@ -75,6 +75,7 @@ HIP_SIM = os.path.join(SIM, "hip")
 
 def _transform_gemm_source(text: str, big_tiles_everywhere: bool = False) -> str:
     text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(ROOT, "musev_amd", "csrc", "common.h"))
+    text = text.replace('#include "gemm_tuned.h"', '#include "%s"' % os.path.join(ROOT, "musev_amd", "csrc", "gemm_tuned.h"))
     # GCN inline assembly cannot be assembled for x86: the counted waits become simulator calls
     text, n = re.subn(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)" ::: "memory"\)', r"sim_waitcnt_vm(\1)", text)
     assert n >= 10
@@ -408,3 +409,65 @@ def test_attention_cross_accumulate_and_temporal_on_the_host(attn_sim):
                             dict(rows=bb * tt * hw, ldo=c, variant=variant, temporal=1, ldq=3 * c, ldk0=3 * c, ldv0=3 * c, b=bb, t=tt, hw=hw,
                                  heads=heads, d=d, scale=d ** -0.5))
         _close(got, ref, atol=3e-3)
+
+
+# ---- the tile-configuration catalogue (mv_set_gemm_force): what the per-shape tuner may pick must be right everywhere ------
+def _catalogue():
+    import ctypes as C
+    from musev_amd import _lib
+    lib = _lib.load()
+    out = []
+    for i in range(lib.mv_gemm_num_configs()):
+        d = (C.c_int32 * 5)()
+        assert lib.mv_gemm_config_desc(i, d) == 0
+        out.append(tuple(d))
+    return out
+
+
+def test_gemm_catalogue_is_consistent():
+    cat = _catalogue()
+    assert len(cat) == 19 and len(set(cat)) == len(cat), "configurations must be distinct"
+    for rows, cols, waves, bk, stages in cat:
+        assert rows in (64, 128, 256) and cols in (128, 160, 256, 320) and waves in (4, 8) and (bk, stages) in ((64, 2), (64, 3), (32, 4))
+        assert stages * (rows + cols) * bk * 2 <= 160 * 1024, "operand stages must fit the 160 KB LDS"
+
+
+@pytest.mark.parametrize("cfg", list(range(19)))
+def test_gemm_every_configuration_on_the_host(gemm_sim, cfg):
+    """linear GEMM with the full epilogue, forced onto each catalogue entry: ragged M (300) and N = 640 (ragged for the 256-wide
+    tiles), K = 192 = three 64-deep or six 32-deep K steps (every ring wraps), LATEST legal LDS-DMA landing; the GEGLU
+    epilogue on the even-TN configurations"""
+    work, exe = gemm_sim
+    rows, cols, waves, bk, stages = _catalogue()[cfg]
+    M, N, K = 300, 640, 192
+    a, w, bias, res = _rnd((M, K), 100), _rnd((N, K), 101, 1 / math.sqrt(K)), _rnd((N,), 102), _rnd((M, N), 103)
+    rowbias = _rnd((2, N), 104)
+    trace = []
+    got = _run_gemm_job(work, exe, f"cfg{cfg}", dict(a=a, w=w, bias=bias, rowbias=rowbias, residual=res),
+                        dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, ldr=N, ldrb=N, c1=K, rows_per_group=150, force=cfg), 1, trace=trace)
+    assert f"block {64 * waves} " in trace[0] and f"grid {((M + rows - 1) // rows) * ((N + cols - 1) // cols)} " in trace[0], trace[0]
+    _close(got, a.float() @ w.float().t() + bias.float() + rowbias.float()[torch.arange(M) // 150] + res.float())
+    if cols in (128, 256):  # even TN: the GEGLU epilogue applies
+        Mg, C = 140, 32
+        ag, wf, bf = _rnd((Mg, 2 * C), 105), _rnd((16 * C, 2 * C), 106, 1 / math.sqrt(2 * C)), _rnd((16 * C,), 107, 0.1)
+        hfull = ag.float() @ wf.float().t() + bf.float()
+        idx = torch.arange(8 * C).view(-1, 16)
+        perm = torch.cat([idx, idx + 8 * C], dim=1).reshape(-1)
+        gotg = _run_gemm_job(work, exe, f"cfg{cfg}g", dict(a=ag, w=wf[perm].contiguous(), bias=bf[perm].contiguous()),
+                             dict(_BASE, M=Mg, N=16 * C, K=2 * C, lda=2 * C, ldc=8 * C, c1=2 * C, geglu=1, force=cfg), 1)
+        _close(gotg, hfull[:, :8 * C] * F.gelu(hfull[:, 8 * C:]))
+
+
+@pytest.mark.parametrize("cfg", [14, 15, 16, 17, 18])
+def test_gemm_new_configurations_conv_on_the_host(gemm_sim, cfg):
+    """the configurations added for the tuner, on the two-source 3x3 convolution with stride 2 (halo + tap walk + concat)"""
+    work, exe = gemm_sim
+    n, h, w, c1, c2, cout = 2, 9, 12, 64, 64, 320
+    cin = c1 + c2
+    x, wt, bias = _rnd((n, cin, h, w), 110), _rnd((cout, cin, 3, 3), 111, 1 / math.sqrt(9 * cin)), _rnd((cout,), 112)
+    ref, ho, wo = _conv_ref(x, wt, bias, stride=2)
+    xl = x.permute(0, 2, 3, 1).reshape(n * h * w, cin).contiguous()
+    got = _run_gemm_job(work, exe, f"cfgconv{cfg}", dict(a=xl[:, :c1].contiguous(), a2=xl[:, c1:].contiguous(), w=_pack(wt), bias=bias),
+                        dict(_BASE, M=n * ho * wo, N=cout, K=9 * cin, lda=c1, lda2=c2, ldc=cout, c1=c1, c2=c2, mode=1, stride=2, hin=h, win=w,
+                             hout=ho, wout=wo, force=cfg), 1)
+    _close(got, ref, atol=6e-3)

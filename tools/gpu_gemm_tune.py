@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Per-shape tile-configuration tuner for the implicit-GEMM kernel (run on the MI355X):
+
+    python tools/gpu_gemm_tune.py [tag] [--size 512] [--reps 3] [--min-gain 0.03]
+
+Times every launch of ONE window forward of the benchmark model (config 2: B = 2, T = 13, 64x64 latents) in situ -- HIP
+events around each mv_gemm_f16 launch on the launch stream (musev_amd.ops.GEMM_PROFILE), eager launches, one stream -- once per
+catalogue configuration (mv_set_gemm_force), plus once under the built-in rules.  For every distinct problem
+(mode, M, N, K, geglu) it keeps the fastest configuration if that beats the rules by more than --min-gain, and writes
+
+    gpurun_out/<tag>_gemm_tuned.h      -> copy to musev_amd/csrc/gemm_tuned.h, rebuild (exact-match table in front of the rules)
+    gpurun_out/<tag>_gemm_tune.json    -> per problem: launches per forward, ms under the rules and under every configuration
+
+Nothing here touches results: every configuration reduces over K in the same order (tests/test_kernel_cpu_sim.py runs all of
+them against torch on the host simulator; tests/test_kernels_gpu.py on the GPU)."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag", nargs="?", default="tune")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--min-gain", type=float, default=0.03)
+    ap.add_argument("--flavour", default="musev")
+    args = ap.parse_args()
+    import bench
+    from musev_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    unet = bench.build_unet(args.flavour, dev)
+    h = w = args.size // 8
+    b, t = 2, 13
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(b * t * h * w, 4, generator=g).half().to(dev)
+    ehs = torch.randn(b, 77, 768, generator=g).to(dev)
+    t_dev = torch.full((1,), 601.0, device=dev)
+    kw = dict(sample_index=torch.arange(1, t, device=dev), vision_conditon_frames_sample_index=[0], sample_frame_rate=8.0)
+    if args.flavour == "musev_referencenet":
+        shapes, mid = bench.refer_shapes(h, w)
+        kw["down_block_refer_embs"] = [torch.randn(b, c, 1, a, b_, generator=g).to(dev) for c, a, b_ in shapes]
+        kw["mid_block_refer_emb"] = torch.randn(b, mid[0], 1, mid[1], mid[2], generator=g).to(dev)
+        kw["vision_clip_emb"] = torch.randn(b, 4, 768, generator=g).to(dev)
+
+    def forward():
+        return unet.forward_rows(x, b, t, h, w, t_dev, ehs, **kw)
+
+    n_cfg = lib.mv_gemm_num_configs()
+    descs = []
+    for i in range(n_cfg):
+        d = (C.c_int32 * 5)()
+        lib.mv_gemm_config_desc(i, d)
+        descs.append(list(d))
+    names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
+    table = {}   # key -> {"n": launches, "ms": {cfg: mean ms per launch}}
+    ref_out = None
+    for cfg in [-2] + list(range(n_cfg)):
+        assert lib.mv_set_gemm_force(cfg) == 0
+        out = forward()   # warm-up (packed weights, caches, code objects)
+        torch.cuda.synchronize()
+        if ref_out is None:
+            ref_out = out.clone()
+        elif not torch.equal(out, ref_out):   # every configuration reduces in the same order: results must not move
+            print(f"WARNING: configuration {cfg} changed the forward's output by {(out - ref_out).abs().max().item():.3e}", flush=True)
+        ops.GEMM_PROFILE = []
+        for _ in range(args.reps):
+            forward()
+        torch.cuda.synchronize()
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        acc = {}
+        for mode, M, N, K, geglu, e0, e1, _ in prof:
+            key = (mode, M, N, K, geglu)
+            a = acc.setdefault(key, [0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+        for key, (ms, n) in acc.items():
+            ent = table.setdefault(key, {"n": n // args.reps, "ms": {}})
+            ent["ms"][cfg] = ms / n
+        tot = sum(ms for ms, _ in acc.values()) / args.reps
+        label = "rules" if cfg == -2 else f"cfg {cfg:2d} {descs[cfg][0]}x{descs[cfg][1]} {descs[cfg][2]}w BK{descs[cfg][3]}x{descs[cfg][4]}"
+        print(f"{label:34s} GEMM family {tot:7.2f} ms / forward", flush=True)
+    lib.mv_set_gemm_force(-1)
+
+    rules_total = tuned_total = 0.0
+    entries, report = [], []
+    for key, ent in sorted(table.items(), key=lambda kv: -kv[1]["ms"].get(-2, 0.0) * kv[1]["n"]):
+        base = ent["ms"][-2]
+        best = min((c for c in ent["ms"] if c >= 0), key=lambda c: ent["ms"][c])
+        pick = best if ent["ms"][best] < (1.0 - args.min_gain) * base else None
+        rules_total += base * ent["n"]
+        tuned_total += (ent["ms"][pick] if pick is not None else base) * ent["n"]
+        mode, M, N, K, geglu = key
+        flops = 2.0 * M * N * K
+        report.append({"mode": names[mode], "M": M, "N": N, "K": K, "geglu": geglu, "launches": ent["n"], "rules_ms": base,
+                       "rules_tflops": flops / base / 1e9, "best_cfg": best, "best_ms": ent["ms"][best],
+                       "best_tflops": flops / ent["ms"][best] / 1e9, "picked": pick, "ms": {str(c): v for c, v in ent["ms"].items()}})
+        if pick is not None:
+            entries.append((mode, M, N, K, geglu, pick, base, ent["ms"][pick]))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"{args.tag}_gemm_tune.json"), "w") as f:
+        json.dump({"device": torch.cuda.get_device_name(0), "size": args.size, "flavour": args.flavour, "configs": descs,
+                   "rules_ms_per_forward": rules_total, "tuned_ms_per_forward": tuned_total, "problems": report}, f, indent=1)
+    lines = ["// gemm_tuned.h -- per-shape tile configurations of the implicit-GEMM kernel, measured on the MI355X.",
+             "// GENERATED by tools/gpu_gemm_tune.py (do not edit by hand); ids refer to MV_GEMM_CFGS in gemm.hip.",
+             f"// {torch.cuda.get_device_name(0)}; {args.flavour}, {args.size}x{args.size}, B = 2, T = 13; rules {rules_total:.2f} ms -> table "
+             f"{tuned_total:.2f} ms of GEMM time per forward.",
+             "// {mode, M, N, K, geglu, cfg}", "static const GemmTuned kGemmTuned[] = {"]
+    for mode, M, N, K, geglu, pick, base, best in entries:
+        lines.append(f"    {{{mode}, {M}, {N}, {K}, {geglu}, {pick}}},  // {names[mode]}: {base * 1e3:.0f} -> {best * 1e3:.0f} us")
+    lines += ["    {-1, 0, 0, 0, 0, -1},  // sentinel (never matches)", "};", f"static const int kNumGemmTuned = {len(entries)};", ""]
+    with open(os.path.join(out_dir, f"{args.tag}_gemm_tuned.h"), "w") as f:
+        f.write("\n".join(lines))
+    print(f"rules {rules_total:.2f} ms -> tuned {tuned_total:.2f} ms per forward over {len(table)} problems, {len(entries)} table entries")
+    for r in report[:16]:
+        print(f"{r['mode']:8s} M{r['M']:<7d} N{r['N']:<6d} K{r['K']:<6d} g{r['geglu']} x{r['launches']:<3d} rules {r['rules_ms'] * 1e3:6.0f} us "
+              f"{r['rules_tflops']:5.0f} TF | best cfg {r['best_cfg']:2d} {r['best_ms'] * 1e3:6.0f} us {r['best_tflops']:5.0f} TF")
+
+
+if __name__ == "__main__":
+    main()

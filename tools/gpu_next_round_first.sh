@@ -21,3 +21,6 @@ cat $OUT/${TAG}_bench_mmajor.log $OUT/${TAG}_bench_grouped.log
 # 5. kernel-level A/B incl. the attention variants (3 default, 11 pkrtz, 19 buffer-descriptor K/V fetch) and GEMM variants 2 / 8
 ( timeout 420 python tools/gpu_gemm_ab.py ${TAG}_ab 2 8 2>&1 | tail -60 ) > $OUT/${TAG}_kernel_ab.log
 tail -45 $OUT/${TAG}_kernel_ab.log
+# 6. per-shape tile tuner: writes gpurun_out/${TAG}_gemm_tuned.h (copy to musev_amd/csrc/gemm_tuned.h, rebuild, re-bench)
+( timeout 420 python tools/gpu_gemm_tune.py ${TAG} 2>&1 | tail -45 ) > $OUT/${TAG}_gemm_tune.log
+cat $OUT/${TAG}_gemm_tune.log
