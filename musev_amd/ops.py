@@ -54,6 +54,11 @@ def _launch_gemm(d: GemmDesc, what: str) -> None:
     GEMM_PROFILE.append((int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu), e0, e1, nbytes))
 
 
+def _on_gpu(t: torch.Tensor) -> bool:
+    """every wrapper refuses tensors that are not in device memory through this one predicate (there is no CPU path)"""
+    return t.is_cuda
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -61,7 +66,7 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dim() != 2 or t.stride(1) != 1:
         raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
-    if t.dtype != torch.float16 or not t.is_cuda:
+    if t.dtype != torch.float16 or not _on_gpu(t):
         raise ValueError(f"{name}: expected a CUDA fp16 tensor, got {t.dtype} on {t.device}")
     return t
 
@@ -69,7 +74,7 @@ def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
 def _vec(t: Optional[torch.Tensor], name: str, n: Optional[int] = None) -> Optional[torch.Tensor]:
     if t is None:
         return None
-    if t.dtype != torch.float16 or not t.is_cuda or not t.is_contiguous():
+    if t.dtype != torch.float16 or not _on_gpu(t) or not t.is_contiguous():
         raise ValueError(f"{name}: expected a contiguous CUDA fp16 tensor")
     if n is not None and t.numel() != n:
         raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
@@ -89,7 +94,7 @@ def _fill_epilogue(d: GemmDesc, N: int, M: int, bias, rowbias, rows_per_group, r
             raise ValueError("residual: shape mismatch")
         d.residual, d.ldr = r.data_ptr(), r.stride(0)
     if alpha is not None:
-        if alpha.dtype != torch.float32 or alpha.numel() != 1 or not alpha.is_cuda:
+        if alpha.dtype != torch.float32 or alpha.numel() != 1 or not _on_gpu(alpha):
             raise ValueError("alpha: expected a CUDA fp32 scalar tensor")
         d.alpha = alpha.data_ptr()
     d.act = int(act)
@@ -403,7 +408,7 @@ def bcthw_to_bthwc(x: torch.Tensor) -> torch.Tensor:
 
 
 def bthwc_to_bcthw(x: torch.Tensor, b: int, t: int, h: int, w: int, dtype=torch.float16) -> torch.Tensor:
-    if x.dim() != 2 or not x.is_contiguous() or not x.is_cuda or x.dtype not in (torch.float16, torch.float32):
+    if x.dim() != 2 or not x.is_contiguous() or not _on_gpu(x) or x.dtype not in (torch.float16, torch.float32):
         raise ValueError("bthwc_to_bcthw: contiguous 2-D CUDA fp16|fp32 input expected")
     c = x.shape[1]
     y = torch.empty((b, c, t, h, w), dtype=dtype, device=x.device)

@@ -1,6 +1,5 @@
 // host run of mv_attention_f16 / mv_temporal_attention_f16 (real dispatch + kernels of musev_amd/csrc/attention.hip)
 //   argv: dir     dir/job.txt "key value" lines; dir/q.bin, k<i>.bin, v<i>.bin (fp16), out0.bin (initial out when accumulating)
-#define SIM_SHARED_STATIC 1
 #include "attention_sim.inc"
 
 #include <map>

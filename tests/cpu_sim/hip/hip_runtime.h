@@ -10,7 +10,9 @@
 //   * LDS-DMA completion time: SIM_DEFER=1 delays every LDS-DMA write until the issuing thread's next s_waitcnt vmcnt(N) /
 //     __syncthreads (the LATEST legal landing), SIM_DEFER=0 performs it at issue (the EARLIEST) -- a kernel has to be right
 //     under both;
-//   * dynamic shared memory = one global `smem` array (blocks run one after another).
+//   * dynamic shared memory = one global buffer (blocks run one after another); static __shared__ arrays = function statics.
+//   * all simulator state is C++17 `inline` (one instance per process): the kernel sources include this header from several
+//     translation units, and common.h's non-static inline helpers are merged by the linker across them.
 // What it cannot model: timing, bank conflicts, occupancy, alignment faults, anything about performance.
 #pragma once
 #include <math.h>
@@ -45,21 +47,16 @@ static inline hipError_t hipDeviceGetAttribute(int* v, int, int) {  // SIM_CUS: 
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#ifdef SIM_SHARED_STATIC  // kernels with `__shared__ T buf[N];` inside the function: one static buffer, blocks run one at a time
-#define __shared__ static
-#else
-#define __shared__
-#endif
+#define __shared__ static  // `__shared__ T buf[N];` inside a kernel: one function-local static buffer, blocks run one at a time
 #define __expf expf
 
-static thread_local dim3 threadIdx, blockIdx;
-static dim3 blockDim, gridDim;
-namespace {  // a block-scope `extern char smem[]` inside the kernels' anonymous namespace names a member of THAT namespace
-alignas(64) char smem[160 * 1024];  // `extern __shared__ ... char smem[]` of the kernels binds to this
-}
-static pthread_barrier_t sim_block_bar;
-static pthread_barrier_t sim_wave_bar[16];
-static int sim_defer = 0;
+inline thread_local dim3 threadIdx, blockIdx;
+inline dim3 blockDim, gridDim;
+alignas(64) inline char sim_smem_buf[160 * 1024];  // the block's LDS: the tests' source transform turns `extern __shared__ T name[];` into `T* name = (T*)sim_smem_buf;`
+inline pthread_barrier_t sim_block_bar;
+inline pthread_barrier_t sim_wave_bar[16];
+inline unsigned sim_wave_lanes[16];  // threads of each wave of the running block (the last wave may be partial)
+inline int sim_defer = 0;
 
 typedef _Float16 sim_half8 __attribute__((ext_vector_type(8)));
 typedef float sim_float4 __attribute__((ext_vector_type(4)));
@@ -67,7 +64,7 @@ typedef unsigned sim_u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- pending LDS-DMA writes of the calling thread (SIM_DEFER) ----
 struct SimDma { unsigned char data[16]; void* dst; };
-static thread_local std::deque<SimDma> sim_dma;
+inline thread_local std::deque<SimDma> sim_dma;
 static inline void sim_retire(size_t keep) {
     while (sim_dma.size() > keep) {
         memcpy(sim_dma.front().dst, sim_dma.front().data, 16);
@@ -127,7 +124,7 @@ static inline void sim_global_load_lds(const __attribute__((address_space(1))) v
 #define __builtin_amdgcn_global_load_lds sim_global_load_lds
 
 // ---- MFMA 16x16x32 f16 ----
-static _Float16 sim_mfma_a[16][64][8], sim_mfma_b[16][64][8];
+inline _Float16 sim_mfma_a[16][64][8], sim_mfma_b[16][64][8];
 static inline sim_float4 sim_mfma_16x16x32_f16(sim_half8 a, sim_half8 b, sim_float4 c, int, int, int) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int j = 0; j < 8; ++j) {
@@ -150,31 +147,35 @@ static inline sim_float4 sim_mfma_16x16x32_f16(sim_half8 a, sim_half8 b, sim_flo
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 sim_mfma_16x16x32_f16
 
 // ---- cross-lane operations (one exchange buffer per wave, two wave barriers per operation) ----
-static float sim_xchg[16][64];
-static inline float sim_lane_read(float v, int src_lane) {
+inline double sim_xchg[16][64];  // 8-byte slots: float, int and double payloads
+template <typename T>
+static inline T sim_lane_read(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "exchange slot");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    sim_xchg[wave][lane] = v;
+    memcpy(&sim_xchg[wave][lane], &v, sizeof(T));
     sim_wave_barrier();
-    const float r = sim_xchg[wave][src_lane & 63];
+    T r;
+    memcpy(&r, &sim_xchg[wave][src_lane & 63], sizeof(T));
     sim_wave_barrier();
     return r;
 }
-static inline float __shfl_xor(float v, int mask, int) { return sim_lane_read(v, (int)(threadIdx.x & 63) ^ mask); }
-static inline float __shfl(float v, int src, int) { return sim_lane_read(v, src); }
+template <typename T> static inline T __shfl_xor(T v, int mask, int) { return sim_lane_read(v, (int)(threadIdx.x & 63) ^ mask); }
+template <typename T> static inline T __shfl(T v, int src, int) { return sim_lane_read(v, src); }
 static inline int __any(int pred) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    sim_xchg[wave][lane] = pred ? 1.f : 0.f;
+    sim_xchg[wave][lane] = pred ? 1.0 : 0.0;
     sim_wave_barrier();
     int r = 0;
-    for (int i = 0; i < 64; ++i) r |= sim_xchg[wave][i] != 0.f;
+    for (int i = 0; i < (int)sim_wave_lanes[wave]; ++i) r |= sim_xchg[wave][i] != 0.0;
     sim_wave_barrier();
     return r;
 }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 // ds_read_b64_tr_b16 as measured by mv_probe_tr16 on the MI355X (tests/kernel_cases.case_tr16_probe): the 16 lanes of a group
 // each address 4 consecutive 16-bit elements; lane i of the group receives element (i & 3) of the chunks of lanes
 // 4j + (i >> 2), j = 0..3 -- i.e. column i of the 4 x 16 block the group addresses row-wise
 typedef short sim_short4 __attribute__((ext_vector_type(4)));
-static short sim_tr[16][64][4];
+inline short sim_tr[16][64][4];
 static inline sim_short4 sim_ds_read_tr16_b64(__attribute__((address_space(3))) sim_short4* p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     memcpy(sim_tr[wave][lane], (const void*)p, 8);
@@ -206,7 +207,8 @@ static inline sim_fp16x2 sim_cvt_pkrtz(float a, float b) {
 
 // ---- launch ----
 static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
-    if (smem_bytes > sizeof(smem) || block.x % 64 != 0 || block.x > 1024) { fprintf(stderr, "SIM: bad launch\n"); abort(); }
+    if (smem_bytes > sizeof(sim_smem_buf) || block.x == 0 || block.x > 1024 || block.y != 1 || block.z != 1) { fprintf(stderr, "SIM: bad launch\n"); abort(); }
+    const unsigned n_waves = (block.x + 63) / 64;
     gridDim = grid;
     blockDim = block;
     const char* e = getenv("SIM_DEFER");
@@ -215,9 +217,12 @@ static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::func
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
-                memset(smem, 0xCD, smem_bytes ? smem_bytes : 64);  // poison: reading LDS before it is written shows up as NaN-ish garbage
+                memset(sim_smem_buf, 0xCD, smem_bytes ? smem_bytes : 64);  // poison: reading LDS before it is written shows up as NaN-ish garbage
                 pthread_barrier_init(&sim_block_bar, nullptr, block.x);
-                for (unsigned w = 0; w < block.x / 64; ++w) pthread_barrier_init(&sim_wave_bar[w], nullptr, 64);
+                for (unsigned w = 0; w < n_waves; ++w) {
+                    sim_wave_lanes[w] = (block.x - 64 * w < 64) ? block.x - 64 * w : 64;
+                    pthread_barrier_init(&sim_wave_bar[w], nullptr, sim_wave_lanes[w]);
+                }
                 std::vector<std::thread> ts;
                 ts.reserve(block.x);
                 for (unsigned t = 0; t < block.x; ++t)
@@ -230,7 +235,7 @@ static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::func
                     });
                 for (auto& th : ts) th.join();
                 pthread_barrier_destroy(&sim_block_bar);
-                for (unsigned w = 0; w < block.x / 64; ++w) pthread_barrier_destroy(&sim_wave_bar[w]);
+                for (unsigned w = 0; w < n_waves; ++w) pthread_barrier_destroy(&sim_wave_bar[w]);
             }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, smem_bytes, stream, ...) \

@@ -1,0 +1,76 @@
+"""CPU (-m "not gpu"): the product's Python wrappers (musev_amd.ops) -> ctypes -> the C ABI -> the REAL kernel sources, compiled
+for the host and executed thread-per-lane (tests/sim_lib.py, tests/cpu_sim/hip/hip_runtime.h), against the same torch fp32
+reference expressions the kernels are verified against on the MI355X (tests/kernel_cases.py, here with DEV = "cpu" and small
+shapes).  Functional only -- see the header for what the simulator does and does not model.
+
+Every case runs in its own interpreter under a hard timeout: a simulated kernel that deadlocks on a barrier sits in C code
+and cannot be interrupted from within the process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import sim_lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    "tr16_probe": "kc.case_tr16_probe()",
+    "gemm": "kc.case_gemm(M=200, N=320, K=256)",
+    "gemm_two_src": "kc.case_gemm(M=130, N=160, K=448, two_src=True)",
+    "gemm_plain": "kc.case_gemm(M=64, N=64, K=64, epilogue=False)",
+    "gemm_geglu": "kc.case_gemm_geglu(M=77, C=64)",
+    "conv3x3": "kc.case_conv3x3(n=2, h=8, w=12, c1=64, cout=64)",
+    "conv3x3_two_src": "kc.case_conv3x3(n=2, h=8, w=12, c1=64, c2=64, cout=64)",
+    "conv3x3_stride2_odd": "kc.case_conv3x3(n=2, h=7, w=9, c1=64, cout=64, stride=2)",
+    "conv3x3_upsample": "kc.case_conv3x3(n=1, h=6, w=8, c1=64, cout=64, upsample=True)",
+    "tconv3": "kc.case_tconv3(b=2, t=5, hw=12, c=64)",
+    "groupnorm": "kc.case_groupnorm(n=3, rows=50, c1=64)",
+    "groupnorm_two_src": "kc.case_groupnorm(n=2, rows=50, c1=64, c2=32, silu=False)",
+    "layernorm": "kc.case_layernorm(rows=99, c=64)",
+    "attention_self": "kc.case_attention_self(d=40, b=1, t=2, lq=70, cond_idx=1)",
+    "attention_cross_ip": "kc.case_attention_cross(d=80, nb=4, t=2, lq=40)",
+    "temporal_attention": "kc.case_temporal_attention(b=1, t=13, hw=9, d=40)",
+    "conv_in_out": "kc.case_conv_in_out()",
+    "timestep_embedding": "kc.case_timestep_embedding()",
+    "layout_and_misc": "kc.case_layout_and_misc()",
+    "window_loop": "kc.case_window_loop()",
+    "cfg_affine_step": "kc.case_cfg_affine_step()",
+}
+
+_RUNNER = """
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import torch
+torch.set_num_threads(2)
+import sim_lib
+class MP:
+    def setattr(self, o, n, v): setattr(o, n, v)
+    def setenv(self, k, v): os.environ[k] = v
+sim_lib.install(MP(), {so!r})
+import kernel_cases as kc
+kc.DEV = "cpu"
+res = {expr}
+print("RESULT " + json.dumps({{k: v for k, v in res.items() if isinstance(v, (bool, int, float, str))}}))
+"""
+
+
+@pytest.fixture(scope="module")
+def sim_so(tmp_path_factory):
+    if not os.path.exists(sim_lib.CLANG):
+        pytest.skip("ROCm host clang not available")
+    return sim_lib.build(tmp_path_factory.mktemp("sim_lib"))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_kernel_case_through_the_simulated_library(sim_so, name):
+    if name == "conv_in_out" and not os.environ.get("MUSEV_SIM_FULL"):
+        pytest.skip("one minute of simulated conv_in / conv_out at the case's fixed size: set MUSEV_SIM_FULL=1")
+    code = _RUNNER.format(root=sim_lib.ROOT, here=HERE, so=sim_so, expr=CASES[name])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert res["ok"], res
