@@ -74,3 +74,36 @@ def test_kernel_case_through_the_simulated_library(sim_so, name):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     res = json.loads(line[len("RESULT "):])
     assert res["ok"], res
+
+
+_POSEGUIDER = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import numpy as np, torch
+torch.set_num_threads(2)
+import sim_lib
+class MP:
+    def setattr(self, o, n, v): setattr(o, n, v)
+    def setenv(self, k, v): os.environ[k] = v
+sim_lib.install(MP(), {so!r})
+from golden_cases import POSEGUIDER_CASES, poseguider_case_inputs
+from oracle import poseguider as opg
+from musev_amd.models.controlnet import PoseGuider
+c = POSEGUIDER_CASES["default_b2"]
+sd = opg.init_state_dict(opg.param_shapes(c["emb"], c["cond"], c["ch"]), c["weight_seed"])
+net = PoseGuider.from_pretrained(sd, conditioning_embedding_channels=c["emb"], conditioning_channels=c["cond"], block_out_channels=c["ch"]).half()
+net._device_check = False
+got = net(poseguider_case_inputs(c))
+want = torch.from_numpy(np.load(os.path.join({here!r}, "golden", "reference_poseguider_default_b2.npz"))["out"])
+print("RESULT", float((got.float() - want).abs().max()))
+"""
+
+
+def test_poseguider_module_through_the_simulated_library(sim_so):
+    """the whole PoseGuider module (layout kernels + eight mv_conv3x3_direct_f16 launches with fused bias / SiLU) on the
+    simulated kernels against the output recorded from the reference's own class"""
+    r = subprocess.run([sys.executable, "-c", _POSEGUIDER.format(root=sim_lib.ROOT, here=HERE, so=sim_so)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    err = float([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1].split()[1])
+    assert err < 1e-2, err
