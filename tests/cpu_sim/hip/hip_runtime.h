@@ -206,6 +206,9 @@ static inline sim_fp16x2 sim_cvt_pkrtz(float a, float b) {
 #define __builtin_amdgcn_cvt_pkrtz sim_cvt_pkrtz
 
 // ---- launch ----
+// One pool of blockDim.x threads per launch; the blocks of the grid run one after another on it (a barrier between blocks),
+// so a grid of thousands of small blocks costs a barrier per block instead of a thread creation per simulated thread.
+inline pthread_barrier_t sim_pool_bar;
 static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
     if (smem_bytes > sizeof(sim_smem_buf) || block.x == 0 || block.x > 1024 || block.y != 1 || block.z != 1) { fprintf(stderr, "SIM: bad launch\n"); abort(); }
     const unsigned n_waves = (block.x + 63) / 64;
@@ -214,29 +217,34 @@ static void sim_launch(dim3 grid, dim3 block, size_t smem_bytes, const std::func
     const char* e = getenv("SIM_DEFER");
     sim_defer = e ? atoi(e) : 0;
     if (getenv("SIM_TRACE")) fprintf(stderr, "SIM launch grid %u x %u x %u block %u smem %zu\n", grid.x, grid.y, grid.z, block.x, smem_bytes);
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                memset(sim_smem_buf, 0xCD, smem_bytes ? smem_bytes : 64);  // poison: reading LDS before it is written shows up as NaN-ish garbage
-                pthread_barrier_init(&sim_block_bar, nullptr, block.x);
-                for (unsigned w = 0; w < n_waves; ++w) {
-                    sim_wave_lanes[w] = (block.x - 64 * w < 64) ? block.x - 64 * w : 64;
-                    pthread_barrier_init(&sim_wave_bar[w], nullptr, sim_wave_lanes[w]);
+    pthread_barrier_init(&sim_block_bar, nullptr, block.x);
+    pthread_barrier_init(&sim_pool_bar, nullptr, block.x);
+    for (unsigned w = 0; w < n_waves; ++w) {
+        sim_wave_lanes[w] = (block.x - 64 * w < 64) ? block.x - 64 * w : 64;
+        pthread_barrier_init(&sim_wave_bar[w], nullptr, sim_wave_lanes[w]);
+    }
+    const unsigned long n_blocks = (unsigned long)grid.x * grid.y * grid.z;
+    std::vector<std::thread> ts;
+    ts.reserve(block.x);
+    for (unsigned t = 0; t < block.x; ++t)
+        ts.emplace_back([&, t]() {
+            for (unsigned long b = 0; b < n_blocks; ++b) {
+                if (smem_bytes) {  // poison the block's LDS: reading it before writing shows up as garbage, not as a stale tile
+                    if (t == 0) memset(sim_smem_buf, 0xCD, smem_bytes);
+                    pthread_barrier_wait(&sim_pool_bar);
                 }
-                std::vector<std::thread> ts;
-                ts.reserve(block.x);
-                for (unsigned t = 0; t < block.x; ++t)
-                    ts.emplace_back([&, t]() {
-                        threadIdx = dim3(t, 0, 0);
-                        blockIdx = dim3(bx, by, bz);
-                        sim_dma.clear();
-                        body();
-                        sim_retire(0);
-                    });
-                for (auto& th : ts) th.join();
-                pthread_barrier_destroy(&sim_block_bar);
-                for (unsigned w = 0; w < n_waves; ++w) pthread_barrier_destroy(&sim_wave_bar[w]);
+                threadIdx = dim3(t, 0, 0);
+                blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((unsigned long)grid.x * grid.y)));
+                sim_dma.clear();
+                body();
+                sim_retire(0);
+                pthread_barrier_wait(&sim_pool_bar);  // every simulated thread of block b is done before block b + 1 starts
             }
+        });
+    for (auto& th : ts) th.join();
+    pthread_barrier_destroy(&sim_block_bar);
+    pthread_barrier_destroy(&sim_pool_bar);
+    for (unsigned w = 0; w < n_waves; ++w) pthread_barrier_destroy(&sim_wave_bar[w]);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, smem_bytes, stream, ...) \
     sim_launch(dim3(grid), dim3(block), (smem_bytes), [&]() { kernel(__VA_ARGS__); })
