@@ -1159,8 +1159,9 @@ int launch_cfg2(const GemmArgs2& a, hipStream_t stream) {
     X(12, 4, 4, 2, 2, 4) /* 128x128, BK 32 x 4          */ X(13, 2, 4, 2, 2, 4)  /* 64x128, BK 32 x 4          */      \
     X(14, 8, 4, 2, 4, 4) /* 256x256, 8 waves, BK 32 x 4 */ X(15, 4, 4, 2, 4, 3)  /* 128x256, 8 waves, 3 stages */      \
     X(16, 4, 5, 2, 4, 0) /* 128x320, 8 waves            */ X(17, 2, 5, 4, 2, 3)  /* 128x160, 8 waves, 3 stages */      \
-    X(18, 8, 5, 2, 4, 4) /* 256x320, 8 waves, BK 32 x 4 */
-constexpr int kNumGemmCfgs = 19;
+    X(18, 8, 5, 2, 4, 4) /* 256x320, 8 waves, BK 32 x 4 */ X(19, 2, 5, 2, 1, 0)  /* 64x80, 2 waves (small grids)  */      \
+    X(20, 2, 5, 1, 2, 0) /* 32x160, 2 waves             */
+constexpr int kNumGemmCfgs = 21;
 struct GemmCfgDesc { int tm, tn, wgm, wgn, sched; };
 constexpr GemmCfgDesc kGemmCfgs[kNumGemmCfgs] = {
 #define MV_X(id, tm, tn, wgm, wgn, sched) {tm, tn, wgm, wgn, sched},
