@@ -42,20 +42,26 @@ def main():
     torch.cuda.set_device(dev)
     unet = bench.build_unet(args.flavour, dev)
     h = w = args.size // 8
-    b, t = 2, 13
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(b * t * h * w, 4, generator=g).half().to(dev)
-    ehs = torch.randn(b, 77, 768, generator=g).to(dev)
+    t = 13
     t_dev = torch.full((1,), 601.0, device=dev)
-    kw = dict(sample_index=torch.arange(1, t, device=dev), vision_conditon_frames_sample_index=[0], sample_frame_rate=8.0)
-    if args.flavour == "musev_referencenet":
-        shapes, mid = bench.refer_shapes(h, w)
-        kw["down_block_refer_embs"] = [torch.randn(b, c, 1, a, b_, generator=g).to(dev) for c, a, b_ in shapes]
-        kw["mid_block_refer_emb"] = torch.randn(b, mid[0], 1, mid[1], mid[2], generator=g).to(dev)
-        kw["vision_clip_emb"] = torch.randn(b, 4, 768, generator=g).to(dev)
+    # the loop runs the CFG halves as two batch-1 forwards on two streams by default and as one batch-2 forward otherwise
+    # (MUSEV_HALF_STREAMS=0, bench.py's instrumented pass): both sets of problem sizes are tuned
+    inputs = {}
+    for b in (1, 2):
+        g = torch.Generator().manual_seed(b)
+        kw = dict(sample_index=torch.arange(1, t, device=dev), vision_conditon_frames_sample_index=[0], sample_frame_rate=8.0)
+        if args.flavour == "musev_referencenet":
+            shapes, mid = bench.refer_shapes(h, w)
+            kw["down_block_refer_embs"] = [torch.randn(b, c, 1, a, b_, generator=g).to(dev) for c, a, b_ in shapes]
+            kw["mid_block_refer_emb"] = torch.randn(b, mid[0], 1, mid[1], mid[2], generator=g).to(dev)
+            kw["vision_clip_emb"] = torch.randn(b, 4, 768, generator=g).to(dev)
+        inputs[b] = (torch.randn(b * t * h * w, 4, generator=g).half().to(dev), torch.randn(b, 77, 768, generator=g).to(dev), kw)
 
     def forward():
-        return unet.forward_rows(x, b, t, h, w, t_dev, ehs, **kw)
+        outs = []
+        for b, (x, ehs, kw) in inputs.items():
+            outs.append(unet.forward_rows(x, b, t, h, w, t_dev, ehs, **kw))
+        return torch.cat(outs, dim=0)
 
     n_cfg = lib.mv_gemm_num_configs()
     descs = []
@@ -115,8 +121,8 @@ def main():
                    "rules_ms_per_forward": rules_total, "tuned_ms_per_forward": tuned_total, "problems": report}, f, indent=1)
     lines = ["// gemm_tuned.h -- per-shape tile configurations of the implicit-GEMM kernel, measured on the MI355X.",
              "// GENERATED by tools/gpu_gemm_tune.py (do not edit by hand); ids refer to MV_GEMM_CFGS in gemm.hip.",
-             f"// {torch.cuda.get_device_name(0)}; {args.flavour}, {args.size}x{args.size}, B = 2, T = 13; rules {rules_total:.2f} ms -> table "
-             f"{tuned_total:.2f} ms of GEMM time per forward.",
+             f"// {torch.cuda.get_device_name(0)}; {args.flavour}, {args.size}x{args.size}, T = 13, one batch-1 + one batch-2 forward; rules "
+             f"{rules_total:.2f} ms -> table {tuned_total:.2f} ms of GEMM time.",
              "// {mode, M, N, K, geglu, cfg}", "static const GemmTuned kGemmTuned[] = {"]
     for mode, M, N, K, geglu, pick, base, best in entries:
         lines.append(f"    {{{mode}, {M}, {N}, {K}, {geglu}, {pick}}},  // {names[mode]}: {base * 1e3:.0f} -> {best * 1e3:.0f} us")
