@@ -51,7 +51,26 @@ __global__ void gn_stats_kernel(const GnArgs a) {
     float s[8], ss[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
-    for (long r = r0 + rl; r < r1; r += a.rl) {
+    // four independent 16-byte loads in flight per thread (a single load per iteration left the kernel at a third of the
+    // HBM rate: bytes in flight, not bandwidth, was the limit); the rows are still accumulated in ascending order
+    long r = r0 + rl;
+    const long st = a.rl;
+    for (; r + 3 * st < r1; r += 4 * st) {
+        half8v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(gn_src(a, item, r + u * st, o));
+        __builtin_amdgcn_sched_barrier(0);  // all four loads are issued before the first one is consumed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[u][j];
+                s[j] += f;
+                ss[j] += f * f;
+            }
+        }
+    }
+    for (; r < r1; r += st) {
         half8v v = *reinterpret_cast<const half8v*>(gn_src(a, item, r, o));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -146,8 +165,7 @@ __global__ void gn_apply_kernel(const GnArgs a) {
         sc[j] = ssp[j];
         sh[j] = ssp[C + j];
     }
-    for (long r = r0 + rl; r < r1; r += a.rl) {
-        half8v v = *reinterpret_cast<const half8v*>(gn_src(a, item, r, o));
+    auto norm = [&](const half8v& v) __attribute__((always_inline)) {
         half8v w;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -155,53 +173,82 @@ __global__ void gn_apply_kernel(const GnArgs a) {
             if (a.silu) f = mv_silu(f);
             w[j] = (half_t)f;
         }
-        *reinterpret_cast<half8v*>(a.y + (item * a.rows + r) * a.ldy + o * 8) = w;
+        return w;
+    };
+    long r = r0 + rl;
+    const long st = a.rl;
+    for (; r + 3 * st < r1; r += 4 * st) {  // four loads in flight per thread (see gn_stats_kernel)
+        half8v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(gn_src(a, item, r + u * st, o));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<half8v*>(a.y + (item * a.rows + r + u * st) * a.ldy + o * 8) = norm(v[u]);
     }
+    for (; r < r1; r += st)
+        *reinterpret_cast<half8v*>(a.y + (item * a.rows + r) * a.ldy + o * 8) =
+            norm(*reinterpret_cast<const half8v*>(gn_src(a, item, r, o)));
 }
 
-// ---- LayerNorm: one wave per row, up to 3 octets per lane (C <= 1536) ----
-template <int NO>
+// ---- LayerNorm: one wave per group of R rows, up to 3 octets per lane and row (C <= 1536) ----
+// All R rows' loads are issued before any is reduced: with one row per wave a lane had a single 16-byte load in flight
+// (C = 320) and the kernel ran at half the HBM rate.  Per row the arithmetic (and its order) is unchanged.
+template <int NO, int kLnRows>  // kLnRows = R: 4 at C <= 512 (one octet per lane), else 2
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, half_t* y, int ldy, long rows, int c,
                                                         const half_t* gamma, const half_t* beta, float eps) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kLnRows;
+    if (row0 >= rows) return;
     const int oc = c >> 3;
-    half8v v[NO];
-    float sum = 0.f;
+    half8v v[kLnRows][NO];
 #pragma unroll
-    for (int k = 0; k < NO; ++k) {
-        const int o = lane + 64 * k;
-        if (o < oc) {
-            v[k] = *reinterpret_cast<const half8v*>(x + row * ldx + o * 8);
+    for (int q = 0; q < kLnRows; ++q) {
+        const long row = row0 + q;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += (float)v[k][j];
+        for (int k = 0; k < NO; ++k) {
+            const int o = lane + 64 * k;
+            if (o < oc && row < rows) v[q][k] = *reinterpret_cast<const half8v*>(x + row * ldx + o * 8);
         }
     }
-    const float mean = wave_sum(sum) / (float)c;
-    float sq = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < NO; ++k) {
-        const int o = lane + 64 * k;
-        if (o < oc) {
+    for (int q = 0; q < kLnRows; ++q) {
+        const long row = row0 + q;
+        if (row >= rows) break;  // wave-uniform
+        float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float d = (float)v[k][j] - mean;
-                sq += d * d;
+        for (int k = 0; k < NO; ++k) {
+            const int o = lane + 64 * k;
+            if (o < oc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += (float)v[q][k][j];
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)c + eps);
+        const float mean = wave_sum(sum) / (float)c;
+        float sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < NO; ++k) {
-        const int o = lane + 64 * k;
-        if (o < oc) {
-            half8v gm = *reinterpret_cast<const half8v*>(gamma + o * 8);
-            half8v bt = *reinterpret_cast<const half8v*>(beta + o * 8);
-            half8v w;
+        for (int k = 0; k < NO; ++k) {
+            const int o = lane + 64 * k;
+            if (o < oc) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = (half_t)(((float)v[k][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
-            *reinterpret_cast<half8v*>(y + row * ldy + o * 8) = w;
+                for (int j = 0; j < 8; ++j) {
+                    float d = (float)v[q][k][j] - mean;
+                    sq += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)c + eps);
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            const int o = lane + 64 * k;
+            if (o < oc) {
+                half8v gm = *reinterpret_cast<const half8v*>(gamma + o * 8);
+                half8v bt = *reinterpret_cast<const half8v*>(beta + o * 8);
+                half8v w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = (half_t)(((float)v[q][k][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+                *reinterpret_cast<half8v*>(y + row * ldy + o * 8) = w;
+            }
         }
     }
 }
@@ -261,15 +308,16 @@ extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy
     MV_REQUIRE(c > 0 && c % 8 == 0 && c <= 1536, "mv_layernorm_f16: need C %% 8 == 0 and C <= 1536 (C=%d)", c);
     MV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && rows > 0, "mv_layernorm_f16: bad leading dims / rows");
     hipStream_t s = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((rows + 3) / 4);
     const int oc = c / 8;
+    const int rpw = oc <= 64 ? 4 : 2;  // rows per wave (4 waves per block)
+    const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
     const half_t* xp = (const half_t*)x;
     half_t* yp = (half_t*)y;
     const half_t* g = (const half_t*)gamma;
     const half_t* b = (const half_t*)beta;
-    if (oc <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
-    else if (oc <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    if (oc <= 64) hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    else if (oc <= 128) hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<3, 2>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
     MV_CHECK_LAUNCH("mv_layernorm_f16");
     return MV_OK;
 }

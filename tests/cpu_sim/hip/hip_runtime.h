@@ -78,6 +78,7 @@ static inline void sim_wave_barrier() { pthread_barrier_wait(&sim_wave_bar[threa
 #define __builtin_amdgcn_s_barrier sim_s_barrier
 #define __builtin_amdgcn_wave_barrier sim_wave_barrier
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
