@@ -776,25 +776,33 @@ __global__ __launch_bounds__(16 * IPB) void tattn2_kernel(const TAttnArgs a) {
     half_t* sv = tsm + IPB * a.t * D;
     const int tid = threadIdx.x;
     const long item0 = (long)blockIdx.x * IPB;
-    // ---- stage K and V: chunk index fastest, then item, then frame ----
+    // ---- stage K and V: chunk index fastest, then item, then frame.  All of a thread's global loads (its K / V chunks and
+    // its query row) are issued before the first LDS store: t * DCH <= 16 * DCH chunks per item -> at most DCH rounds ----
     const int nchunk = IPB * a.t * DCH;
-    for (int idx = tid; idx < nchunk; idx += 16 * IPB) {
+    u32x4 kreg[DCH], vreg[DCH];
+#pragma unroll
+    for (int it = 0; it < DCH; ++it) {
+        const int idx = tid + it * 16 * IPB;
+        // branch-free: a chunk that does not exist loads element 0 of K / V (always mapped) and is zeroed afterwards, so the
+        // loads of all rounds sit in one basic block and go out back to back
         const int ch = idx % DCH;
         const int rest = idx / DCH;
         const int il = rest % IPB, j = rest / IPB;
         const long item = item0 + il;
-        u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-        if (item < a.items) {
-            const int h = (int)(item % a.heads);
-            const long bp = item / a.heads;
-            const int pix = (int)(bp % a.hw);
-            const int b = (int)(bp / a.hw);
-            const long row = ((long)b * a.t + j) * a.hw + pix;
-            kv = *reinterpret_cast<const u32x4*>(a.k + row * a.ldk + h * D + ch * 8);
-            vv = *reinterpret_cast<const u32x4*>(a.v + row * a.ldv + h * D + ch * 8);
+        const bool ok = idx < nchunk && item < a.items;
+        const int h = (int)(item % a.heads);
+        const long bp = item / a.heads;
+        const int pix = (int)(bp % a.hw);
+        const int b = (int)(bp / a.hw);
+        const long row = ((long)b * a.t + j) * a.hw + pix;
+        const long ko = ok ? row * a.ldk + h * D + ch * 8 : 0;
+        const long vo = ok ? row * a.ldv + h * D + ch * 8 : 0;
+        kreg[it] = *reinterpret_cast<const u32x4*>(a.k + ko);
+        vreg[it] = *reinterpret_cast<const u32x4*>(a.v + vo);
+        if (!ok) {
+            kreg[it] = u32x4{0, 0, 0, 0};
+            vreg[it] = u32x4{0, 0, 0, 0};
         }
-        *reinterpret_cast<u32x4*>(sk + (il * a.t + j) * D + ch * 8) = kv;
-        *reinterpret_cast<u32x4*>(sv + (il * a.t + j) * D + ch * 8) = vv;
     }
     const int il = tid >> 4, gl = tid & 15;
     const long item = item0 + il;
@@ -809,6 +817,18 @@ __global__ __launch_bounds__(16 * IPB) void tattn2_kernel(const TAttnArgs a) {
     half8v qv[DCH];
 #pragma unroll
     for (int ch = 0; ch < DCH; ++ch) qv[ch] = *reinterpret_cast<const half8v*>(a.q + qrow * a.ldq + h * D + ch * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < DCH; ++it) {
+        const int idx = tid + it * 16 * IPB;
+        if (idx < nchunk) {
+            const int ch = idx % DCH;
+            const int rest = idx / DCH;
+            const int il2 = rest % IPB, j = rest / IPB;
+            *reinterpret_cast<u32x4*>(sk + (il2 * a.t + j) * D + ch * 8) = kreg[it];
+            *reinterpret_cast<u32x4*>(sv + (il2 * a.t + j) * D + ch * 8) = vreg[it];
+        }
+    }
     __syncthreads();
 
     const half_t* kb = sk + il * a.t * D;
