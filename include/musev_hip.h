@@ -155,7 +155,8 @@ int mv_attention_f16(const mv_attn_desc* d, void* stream);
  * +8 = round-toward-zero packing of the probabilities (d = 40); +16 = K/V tiles fetched through buffer descriptors
  * (scalar tile advance, out-of-range offsets for the rows past a segment's end) instead of per-lane pointers (d = 40 / 80);
  * +32 = K tile row stride DP + 16 halfs instead of DP + 8 (which of the two is free of LDS bank conflicts depends on how the
- * hardware groups the lanes of a ds_read_b128; d = 40 / 80) */
+ * hardware groups the lanes of a ds_read_b128; d = 40 / 80); +64 = V tile rows unpadded (the conflict-free stride of the
+ * transpose read if it is served 32 lanes at a time) */
 int mv_set_attn_variant(int variant);
 
 /* ---- temporal self-attention over T <= 32 frames per pixel (K6c) -------------------------------------

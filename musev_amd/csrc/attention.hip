@@ -40,7 +40,7 @@ struct AttnArgs {
     float out_scale;
 };
 
-template <int D, int KPAD = 8>  // KPAD: halfs of padding per K-tile row (see KRS)
+template <int D, int KPAD = 8, int VPAD = 8>  // KPAD / VPAD: halfs of padding per K- / V-tile row (see KRS, VRS)
 struct AttnCfg {
     static constexpr int DP = ((D + 31) / 32) * 32;  // padded QK^T contraction length
     static constexpr int NC = DP / 32;               // 32-wide k chunks
@@ -51,7 +51,10 @@ struct AttnCfg {
     // 2-way conflicted for the fragment pattern (row l%16, slot l/16) and DP + 16 is the conflict-free stride.  Both are
     // instantiated; which one the hardware prefers is an A/B (mv_set_attn_variant +32).
     static constexpr int KRS = DP + KPAD;
-    static constexpr int VRS = NDT * 16 + 8;         // V tile row stride (halfs): odd number of 16-byte slots
+    // V tile row stride (halfs).  The transpose read (ds_read_b64_tr_b16: 8 bytes per lane, rows 4g + l15/4) is served 32
+    // lanes at a time: with the 16-byte pad, rows 0 and 7 of a pass overlap in 4 banks (28 r mod 64 dwords); without it the
+    // eight rows land on disjoint 8-bank ranges (24 r / 40 r mod 64 at d = 40 / 80).  A/B: mv_set_attn_variant +64.
+    static constexpr int VRS = NDT * 16 + VPAD;
     static constexpr int KV = 64;                    // keys per tile
     static constexpr int QT = (D > 80) ? 1 : 2;      // 16-row query tiles per wave (register budget at d = 160)
     static constexpr int QB = 64 * QT;               // query rows per block
@@ -110,9 +113,9 @@ __device__ __forceinline__ void attn_commit(const u32x4 (&pf)[AttnCfg<D>::PF], c
 // OPT = 1 (d = 40 only, where the softmax VALU work -- not the MFMAs -- bounds the kernel): the row sums come out of
 // the P.V MFMA itself through a column of ones parked in the unused d-columns [40, 48) of the V tile, the running max
 // uses 3-input maxima, and the O rescale is skipped (exactly: alpha == 1) while no row maximum of the wave moves.
-template <int D, int OPT, int KPAD = 8>
+template <int D, int OPT, int KPAD = 8, int VPAD = 8>
 __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kernel(const AttnArgs p) {
-    using C = AttnCfg<D, KPAD>;
+    using C = AttnCfg<D, KPAD, VPAD>;
     constexpr bool ONES = (OPT >= 1) && (C::NDT * 16 > D);
     __shared__ __attribute__((aligned(16))) half_t lds[C::LDS_HALFS];
     half_t* sK = lds;
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
 int g_attn_pkrtz = 0;    // +8 on mv_set_attn_variant: round-toward-zero packing of P (variant 3, d = 40)
 int g_attn_buf = 0;      // +16: K/V tiles fetched through buffer descriptors (attn_kernel<D, 3>, d = 40 / 80)
 int g_attn_kpad16 = 0;   // +32: K tile row stride DP + 16 instead of DP + 8 (variant 3, d = 40 / 80)
+int g_attn_vpad0 = 0;    // +64: V tile rows without padding (variant 3, d = 40 / 80)
 int g_attn_variant = 3;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
 
 // ------------------------------------------------------------------------------------------------------
@@ -888,13 +892,14 @@ int g_tattn_variant = 2;  // 1 = tattn_kernel, 2 = tattn2_kernel where it applie
 
 extern "C" int mv_set_attn_variant(int v) {
     // bits 0-1: spatial attention kernel (1 | 2 | 3); +4: temporal attention v1 instead of v2; +8: pkrtz; +16: buffer-descriptor K/V
-    // fetch; +32: K tile row stride DP + 16
+    // fetch; +32: K tile row stride DP + 16; +64: V tile rows unpadded
     MV_REQUIRE((v & 3) >= 1, "mv_set_attn_variant: variant %d", v);
     g_attn_variant = v & 3;
     g_tattn_variant = (v & 4) ? 1 : 2;
     g_attn_pkrtz = (v & 8) ? 1 : 0;
     g_attn_buf = (v & 16) ? 1 : 0;
     g_attn_kpad16 = (v & 32) ? 1 : 0;
+    g_attn_vpad0 = (v & 64) ? 1 : 0;
     return MV_OK;
 }
 
@@ -925,15 +930,23 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->d == 40 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<40>, grid, dim3(256), 0, s, a);
     else if (d->d == 80 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<80>, grid, dim3(256), 0, s, a);
-    else if (d->d == 40 && g_attn_variant == 3 && g_attn_buf && g_attn_kpad16) hipLaunchKernelGGL((attn_kernel<40, 3, 16>), grid, dim3(256), 0, s, a);
-    else if (d->d == 80 && g_attn_variant == 3 && g_attn_buf && g_attn_kpad16) hipLaunchKernelGGL((attn_kernel<80, 3, 16>), grid, dim3(256), 0, s, a);
-    else if (d->d == 40 && g_attn_variant == 3 && g_attn_kpad16 && !g_attn_pkrtz) hipLaunchKernelGGL((attn_kernel<40, 1, 16>), grid, dim3(256), 0, s, a);
-    else if (d->d == 80 && g_attn_variant == 3 && g_attn_kpad16) hipLaunchKernelGGL((attn_kernel<80, 1, 16>), grid, dim3(256), 0, s, a);
-    else if (d->d == 40 && g_attn_variant == 3 && g_attn_buf) hipLaunchKernelGGL((attn_kernel<40, 3>), grid, dim3(256), 0, s, a);
-    else if (d->d == 80 && g_attn_variant == 3 && g_attn_buf) hipLaunchKernelGGL((attn_kernel<80, 3>), grid, dim3(256), 0, s, a);
-    else if (d->d == 40 && g_attn_variant == 3 && g_attn_pkrtz) hipLaunchKernelGGL((attn_kernel<40, 2>), grid, dim3(256), 0, s, a);
-    else if (d->d == 40 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<40, 1>), grid, dim3(256), 0, s, a);
-    else if (d->d == 80 && g_attn_variant == 3) hipLaunchKernelGGL((attn_kernel<80, 1>), grid, dim3(256), 0, s, a);
+    else if (g_attn_variant == 3 && (d->d == 40 || d->d == 80)) {
+        // the variant-3 family: OPT 1 (register-staged K/V prefetch) | 2 (+ pkrtz, d = 40) | 3 (buffer-descriptor fetch), K row pad
+        // 8 | 16, V row pad 8 | 0 -- every combination instantiated for the A/B (tools/gpu_gemm_ab.py); default 1 / 8 / 8
+        const int opt = g_attn_buf ? 3 : ((g_attn_pkrtz && d->d == 40 && !g_attn_kpad16 && !g_attn_vpad0) ? 2 : 1);
+        const int kp = g_attn_kpad16 ? 16 : 8, vp = g_attn_vpad0 ? 0 : 8;
+        bool launched = false;
+#define MV_ATTN_TRY(D_, OPT_, KP_, VP_)                                                              \
+    if (!launched && d->d == D_ && opt == OPT_ && kp == KP_ && vp == VP_) {                           \
+        hipLaunchKernelGGL((attn_kernel<D_, OPT_, KP_, VP_>), grid, dim3(256), 0, s, a);             \
+        launched = true;                                                                             \
+    }
+#define MV_ATTN_PADS(D_, OPT_) MV_ATTN_TRY(D_, OPT_, 8, 8) MV_ATTN_TRY(D_, OPT_, 16, 8) MV_ATTN_TRY(D_, OPT_, 8, 0) MV_ATTN_TRY(D_, OPT_, 16, 0)
+        MV_ATTN_PADS(40, 1) MV_ATTN_PADS(40, 3) MV_ATTN_PADS(80, 1) MV_ATTN_PADS(80, 3) MV_ATTN_TRY(40, 2, 8, 8)
+#undef MV_ATTN_PADS
+#undef MV_ATTN_TRY
+        MV_REQUIRE(launched, "mv_attention_f16: no kernel for variant bits (d=%d opt=%d kpad=%d vpad=%d)", d->d, opt, kp, vp);
+    }
     else if (d->d == 40) hipLaunchKernelGGL((attn_kernel<40, 0>), grid, dim3(256), 0, s, a);
     else if (d->d == 80) hipLaunchKernelGGL((attn_kernel<80, 0>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<160, 0>), grid, dim3(256), 0, s, a);

@@ -358,11 +358,11 @@ def _attn_ref(q, ks, vs, heads, d, scale):
     return o.transpose(1, 2).reshape(nb * lq, c)
 
 
-@pytest.mark.parametrize("d,variant", [(40, 3), (40, 19), (40, 11), (40, 1), (80, 3), (80, 19), (160, 3), (40, 2), (40, 35), (40, 51), (80, 35), (80, 51)])
+@pytest.mark.parametrize("d,variant", [(40, 3), (40, 19), (40, 11), (40, 1), (80, 3), (80, 19), (160, 3), (40, 2), (40, 35), (40, 51), (80, 35), (80, 51), (40, 67), (40, 99), (40, 115), (80, 67), (80, 115)])
 def test_attention_self_plus_condition_frame_on_the_host(attn_sim, d, variant):
     """reference-only self-attention: two segments (own frame | vision-condition frame of the batch item), ragged lengths
     (lq = 70: a partial query tile; 70 keys per segment: a partial key tile), fused QKV storage (ld = 3C)"""
-    _subset((d, variant) in ((40, 3), (40, 19), (80, 3), (160, 3), (40, 35)))
+    _subset((d, variant) in ((40, 3), (40, 19), (80, 3), (160, 3), (40, 115)))
     work, exe = attn_sim
     heads, b, t, lq = 2, 1, 2, 70
     c, nb = heads * d, 1 * 2

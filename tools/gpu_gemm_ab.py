@@ -99,7 +99,9 @@ def main():
     # ---- attention kernel variants: parity of every attention case + the reference-only self-attention shapes ----
     from musev_amd import ops
     report["attn"] = {}
-    for av in (3, 11, 19, 35, 51):  # 3: default; +8: pkrtz packing of P; +16: buffer-descriptor K/V fetch; +32: K row stride DP + 16
+    # 3: default; +8: pkrtz packing of P; +16: buffer-descriptor K/V fetch; +32: K row stride DP + 16; +64: V rows unpadded
+    ATTN_VARIANTS = (3, 11, 19, 35, 67, 99, 51, 83, 115)
+    for av in ATTN_VARIANTS:
         assert lib.mv_set_attn_variant(av) == 0
         rep = {"cases": {}, "bench": {}}
         for name, fn in ALL_CASES:
@@ -127,7 +129,7 @@ def main():
         print(f"attn variant {av}: ok={rep['all_ok']} " + " ".join(f"{k}: {b['ms']:.3f} ms {b['tflops']:.0f} TF" for k, b in rep["bench"].items()), flush=True)
     def _attn_ms(v):
         return sum(b["ms"] for b in report["attn"][str(v)]["bench"].values())
-    best_attn = min((v for v in (3, 11, 19, 35, 51) if report["attn"][str(v)]["all_ok"]), key=_attn_ms, default=3)
+    best_attn = min((v for v in ATTN_VARIANTS if report["attn"][str(v)]["all_ok"]), key=_attn_ms, default=3)
     report["best_attn"] = best_attn
     lib.mv_set_attn_variant(best_attn)
     print(f"{'shape':44s}" + "".join(f"  v{v:>1d} TF/s   ms   " for v in variants))
