@@ -482,3 +482,36 @@ def test_gemm_new_configurations_conv_on_the_host(gemm_sim, cfg):
                         dict(_BASE, M=n * ho * wo, N=cout, K=9 * cin, lda=c1, lda2=c2, ldc=cout, c1=c1, c2=c2, mode=1, stride=2, hin=h, win=w,
                              hout=ho, wout=wo, force=cfg), 1)
     _close(got, ref, atol=6e-3)
+
+
+def test_gemm_tuned_table_lookup_on_the_host(tmp_path_factory):
+    """the exact-match table of gemm_tuned.h (written by tools/gpu_gemm_tune.py): a build with a two-entry table must send the
+    matching problems to the listed configurations (and only those), with unchanged results; MUSEV_GEMM_FORCE=-2 semantics
+    (rules only) through mv_set_gemm_force"""
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm host clang not available")
+    import sim_lib
+    work = tmp_path_factory.mktemp("gemm_sim_tuned")
+    table = work / "gemm_tuned_test.h"
+    table.write_text("static const GemmTuned kGemmTuned[] = {\n    {0, 300, 320, 192, 0, 6},\n    {0, 140, 512, 64, 1, 7},\n"
+                     "    {-1, 0, 0, 0, 0, -1},\n};\nstatic const int kNumGemmTuned = 2;\n")
+    src = open(os.path.join(ROOT, "musev_amd", "csrc", "gemm.hip")).read().replace('#include "gemm_tuned.h"', f'#include "{table}"')
+    (work / "gemm_sim.inc").write_text(sim_lib.transform(src))
+    shutil.copy(os.path.join(SIM, "gemm_main.cpp"), work / "gemm_main.cpp")
+    exe = work / "gemm_sim"
+    r = subprocess.run([CLANG, "-O1", "-std=c++17", "-pthread", "-w", "-I", SIM, "-I", str(work), "-o", str(exe), str(work / "gemm_main.cpp")],
+                       cwd=work, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    M, N, K = 300, 320, 192
+    a, w = _rnd((M, K), 120), _rnd((N, K), 121, 1 / math.sqrt(K))
+    ref = a.float() @ w.float().t()
+    base = dict(_BASE, M=M, N=N, K=K, lda=K, ldc=N, c1=K)
+    for extra, block in ((dict(), 512), (dict(force=-2), 256), (dict(force=0), 256)):   # table -> cfg 6 (8 waves); rules; forced cfg 0
+        trace = []
+        got = _run_gemm_job(work, exe, "t" + str(block) + str(len(extra)), dict(a=a, w=w), dict(base, **extra), 1, trace=trace)
+        assert f"block {block} " in trace[0], (extra, trace[0])
+        _close(got, ref)
+    trace = []   # a problem that is NOT in the table follows the rules
+    got = _run_gemm_job(work, exe, "tmiss", dict(a=a[:299], w=w), dict(base, M=299), 1, trace=trace)
+    assert "block 256 " in trace[0]
+    _close(got, ref[:299])
