@@ -588,9 +588,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
     constexpr int NW = WGM * WGN;
-    // SCHED: 0 = BK 64, two stages, __syncthreads ring; 3 = BK 64, three stages, counted waits; 4 = BK 32, four stages,
+    // SCHED: 0 = BK 64, two stages, __syncthreads ring; 6 = the same with BK 32 (half the LDS per block: more blocks per CU for
+    // the short-K, memory-bound projections); 3 = BK 64, three stages, counted waits; 4 = BK 32, four stages,
     // counted waits (three K tiles in flight per block: 3/4 of the block's LDS is "in the air" instead of 1/2)
-    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, BK = (SCHED == 4) ? 32 : 64;
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, BK = (SCHED == 4 || SCHED == 6) ? 32 : 64;
     constexpr int RP = 512 / BK;             // tile rows per 1-KiB LDS-DMA piece: 8 rows of 128 B or 16 rows of 64 B
     constexpr int CA = BM / RP, CB = BN / RP;
     constexpr int AI = (CA + NW - 1) / NW, BI = (CB + NW - 1) / NW;
@@ -752,7 +753,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int b_row0 = wn * 16 * TN + l15;
     const int swz = l15 & 7;
 
-    if constexpr (SCHED >= 3) {
+    // the MFMAs of one LDS stage: two 32-deep fragment sets of a 64-deep tile, or the single set of a 32-deep tile
+    auto mma_stage = [&](int st) __attribute__((always_inline)) {
+        if constexpr (BK == 64) {
+            mma_tile<TM, TN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g);
+        } else {
+            const half_t* cA = sA + st * (BM * BK);
+            const half_t* cB = sB + st * (BN * BK);
+            const int slot_off = ((g + 2 * ((l15 >> 2) & 1)) & 3) << 3;
+            half8v af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (SCHED == 3 || SCHED == 4) {
         // NST-stage ring with COUNTED waits: NST-1 K tiles are in flight while one is multiplied, and nothing ever drains
         // the LDS-DMA queue inside the loop.  Per K step: this wave waits until its own pieces of tile kt have landed
         // (s_waitcnt vmcnt(pieces of the younger tiles)), one raw s_barrier makes every wave's pieces visible and proves
@@ -796,23 +817,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
                 prepare();
                 issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);  // (cur + NST - 1) % NST: the stage tile kt-1 just left
             }
-            if constexpr (BK == 64) {
-                mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
-            } else {
-                const half_t* cA = sA + cur * (BM * BK);
-                const half_t* cB = sB + cur * (BN * BK);
-                const int slot_off = ((g + 2 * ((l15 >> 2) & 1)) & 3) << 3;
-                half8v af[TM], wf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
-            }
+            mma_stage(cur);
             cur = (cur == NST - 1) ? 0 : cur + 1;
         }
     } else {
@@ -823,13 +828,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             const int cur = kt & 1;
             prepare();
             issue(cur ^ 1, kt + 1);
-            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
+            mma_stage(cur);
             __syncthreads();
         }
-        {
-            const int cur = (nk - 1) & 1;
-            mma_tile<TM, TN>(sA + cur * (BM * BK), sB + cur * (BN * BK), acc, a_row0, b_row0, swz, g);
-        }
+        mma_stage((nk - 1) & 1);
     }
 
     // ---- epilogue ----
@@ -842,10 +844,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         // consecutive lanes cover consecutive bytes of a row (residual loads and output stores in whole 128-byte lines).
         __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused
         float* stg = reinterpret_cast<float*>(smem);
-        static_assert(NW * 32 * (16 * TN + 4) * 4 <= NST * (BM + BN) * BK * 2, "output staging does not fit the operand LDS");
+        // (the launcher sizes the dynamic LDS as max(operand stages, this staging area))
         // 16-row tiles staged per pass: the 128-row wave tiles of the 256-row blocks sit at the 256-register cap, where the
         // residual prefetch of a 32-row pass (20 registers) spilled an accumulator to scratch; 16-row passes keep it in registers
-        constexpr int EIT = (TM >= 8) ? 1 : 2;
+        constexpr int EIT = (TM >= 8 || SCHED == 6) ? 1 : 2;  // SCHED 6: 16-row passes keep the block's LDS small (blocks per CU)
         if (p.geglu) {
             if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, EIT>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
         } else {
@@ -1117,7 +1119,10 @@ int launch_mode3(const GemmArgs2& a, hipStream_t stream) {
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
-    constexpr int smem = (SCHED == 4 ? 4 * 32 : SCHED == 3 ? 3 * 64 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
+    constexpr int smem_ops = (SCHED == 4 ? 4 * 32 : SCHED == 3 ? 3 * 64 : SCHED == 6 ? 2 * 32 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
+    // the LDS-staged epilogue reuses the operand LDS: 32 (or 16) fp32 rows of (16 TN + 4) floats per wave must fit as well
+    constexpr int smem_epi = WGM * WGN * ((TM >= 8 || SCHED == 6) ? 16 : 32) * (16 * TN + 4) * 4;
+    constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
     GemmArgs2 a = a0;
     a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
@@ -1160,8 +1165,9 @@ int launch_cfg2(const GemmArgs2& a, hipStream_t stream) {
     X(14, 8, 4, 2, 4, 4) /* 256x256, 8 waves, BK 32 x 4 */ X(15, 4, 4, 2, 4, 3)  /* 128x256, 8 waves, 3 stages */      \
     X(16, 4, 5, 2, 4, 0) /* 128x320, 8 waves            */ X(17, 2, 5, 4, 2, 3)  /* 128x160, 8 waves, 3 stages */      \
     X(18, 8, 5, 2, 4, 4) /* 256x320, 8 waves, BK 32 x 4 */ X(19, 2, 5, 2, 1, 0)  /* 64x80, 2 waves (small grids)  */      \
-    X(20, 2, 5, 1, 2, 0) /* 32x160, 2 waves             */
-constexpr int kNumGemmCfgs = 21;
+    X(20, 2, 5, 1, 2, 0) /* 32x160, 2 waves             */ X(21, 2, 5, 2, 2, 6)  /* 64x160, BK 32 x 2 (4 blocks/CU) */   \
+    X(22, 2, 4, 2, 2, 6) /* 64x128, BK 32 x 2           */
+constexpr int kNumGemmCfgs = 23;
 struct GemmCfgDesc { int tm, tn, wgm, wgn, sched; };
 constexpr GemmCfgDesc kGemmCfgs[kNumGemmCfgs] = {
 #define MV_X(id, tm, tn, wgm, wgn, sched) {tm, tn, wgm, wgn, sched},
@@ -1282,7 +1288,7 @@ extern "C" int mv_gemm_config_desc(int cfg, int32_t* desc5) {
     desc5[0] = 16 * c.tm * c.wgm;  // block rows
     desc5[1] = 16 * c.tn * c.wgn;  // block columns
     desc5[2] = c.wgm * c.wgn;      // waves
-    desc5[3] = c.sched == 4 ? 32 : 64;                    // BK
+    desc5[3] = (c.sched == 4 || c.sched == 6) ? 32 : 64;  // BK
     desc5[4] = c.sched == 4 ? 4 : c.sched == 3 ? 3 : 2;   // LDS stages
     return MV_OK;
 }
