@@ -1166,8 +1166,9 @@ int launch_cfg2(const GemmArgs2& a, hipStream_t stream) {
     X(16, 4, 5, 2, 4, 0) /* 128x320, 8 waves            */ X(17, 2, 5, 4, 2, 3)  /* 128x160, 8 waves, 3 stages */      \
     X(18, 8, 5, 2, 4, 4) /* 256x320, 8 waves, BK 32 x 4 */ X(19, 2, 5, 2, 1, 0)  /* 64x80, 2 waves (small grids)  */      \
     X(20, 2, 5, 1, 2, 0) /* 32x160, 2 waves             */ X(21, 2, 5, 2, 2, 6)  /* 64x160, BK 32 x 2 (4 blocks/CU) */   \
-    X(22, 2, 4, 2, 2, 6) /* 64x128, BK 32 x 2           */
-constexpr int kNumGemmCfgs = 23;
+    X(22, 2, 4, 2, 2, 6) /* 64x128, BK 32 x 2           */ X(23, 2, 5, 4, 2, 0)  /* 128x160, 8 waves of 32x80: 4 waves/SIMD */ \
+    X(24, 2, 4, 4, 2, 0) /* 128x128, 8 waves of 32x64   */
+constexpr int kNumGemmCfgs = 25;
 struct GemmCfgDesc { int tm, tn, wgm, wgn, sched; };
 constexpr GemmCfgDesc kGemmCfgs[kNumGemmCfgs] = {
 #define MV_X(id, tm, tn, wgm, wgn, sched) {tm, tn, wgm, wgn, sched},
