@@ -1,0 +1,123 @@
+"""CPU dry run of tools/gpu_gemm_tune.py (the first GPU call of the next round depends on it): the model is the small `musev`
+architecture on the emulated kernels, the CUDA bits are stand-ins, and every GEMM-family launch reports a synthetic duration
+that depends on the forced configuration -- so the aggregation, the choice rule and the generated gemm_tuned.h can be checked
+without a GPU.  The header it writes is then compiled into the host-simulator build of gemm.hip."""
+import importlib.util
+import os
+import re
+import sys
+import types
+
+import pytest
+import torch
+
+import emu_ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _FakeEvent:
+    def __init__(self, ms):
+        self.ms = ms
+
+    def elapsed_time(self, other):
+        return other.ms - self.ms
+
+
+def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
+    from musev_amd import _lib, ops
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    emu_ops.install(monkeypatch)
+    monkeypatch.setattr(emu_ops, "STRICT_WIDTHS", True)
+    lib = _lib.load()
+    state = {"force": -2}
+    real_force = lib.mv_set_gemm_force
+
+    class LibProxy:  # records the forced configuration, everything else is the real (host-side) library
+        def __getattr__(self, name):
+            return getattr(lib, name)
+
+        def mv_set_gemm_force(self, cfg):
+            state["force"] = cfg
+            return real_force(cfg)
+
+    monkeypatch.setattr(_lib, "load", lambda: LibProxy())
+
+    # synthetic timing model: rules = 1.0 ms; configuration 6 is 20 % faster on conv3x3 problems, configuration 21 is 10 % faster
+    # on linear problems with K <= 320, configuration 3 is 1 % faster everywhere (below the 3 % threshold: must NOT be picked)
+    def fake_ms(mode, K):
+        cfg = state["force"]
+        if cfg == 6 and mode == 1:
+            return 0.8
+        if cfg == 21 and mode == 0 and K <= 320:
+            return 0.9
+        if cfg == 3:
+            return 0.99
+        return 1.0 if cfg == -2 else 1.05
+
+    def wrap(name, mode_of):
+        inner = getattr(emu_ops, name)
+
+        def f(*a, **k):
+            out = inner(*a, **k)
+            if ops.GEMM_PROFILE is not None:
+                w = a[1]
+                mode = mode_of
+                M, N, K = out.shape[0], w.shape[0], w.shape[1]
+                geglu = int(bool(k.get("geglu")))
+                ops.GEMM_PROFILE.append((mode, M, N, K, geglu, _FakeEvent(0.0), _FakeEvent(fake_ms(mode, K)), 0))
+            return out
+        monkeypatch.setattr(ops, name, f)
+
+    wrap("gemm", 0)
+    wrap("conv3x3", 1)
+    wrap("tconv3", 2)
+
+    arch = dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
+    cfg = unet3d.flavour_config("musev", **arch)
+    sd = unet3d.init_state_dict(cfg, 3)
+
+    def build_unet(flavour, dev):
+        m = load_unet_by_name(flavour, sd_unet_model=sd, dtype=torch.float16, **arch)
+        m._device_check = False
+        return m
+
+    spec = importlib.util.spec_from_file_location("gpu_gemm_tune", os.path.join(ROOT, "tools", "gpu_gemm_tune.py"))
+    tune = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tune)
+    import bench
+    monkeypatch.setattr(bench, "build_unet", build_unet)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(torch.cuda, "get_device_name", lambda *a: "dry run")
+    real_device = torch.device
+    monkeypatch.setattr(tune.torch, "device", lambda *a, **k: real_device("cpu"))
+    monkeypatch.setattr(tune, "ROOT", str(tmp_path))
+    monkeypatch.setattr(sys, "argv", ["gpu_gemm_tune.py", "dry", "--size", "64", "--reps", "1"])
+    tune.main()
+    assert state["force"] == -1, "the tuner must leave the library on `table + rules`"
+
+    hdr = open(tmp_path / "gpurun_out" / "dry_gemm_tuned.h").read()
+    entries = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", hdr)]
+    n_decl = int(re.search(r"kNumGemmTuned = (\d+);", hdr).group(1))
+    assert n_decl == len(entries) > 0
+    assert all(c == 6 for mode, M, N, K, g, c in entries if mode == 1) and any(mode == 1 for mode, *_ in entries)
+    assert all(c == 21 for mode, M, N, K, g, c in entries if mode == 0) and all(K <= 320 for mode, M, N, K, g, c in entries if mode == 0)
+    assert not any(mode == 2 for mode, *_ in entries), "a 1 % gain is below the threshold"
+    import json
+    rep = json.load(open(tmp_path / "gpurun_out" / "dry_gemm_tune.json"))
+    assert rep["tuned_ms_per_forward"] < rep["rules_ms_per_forward"] and len(rep["problems"]) > 10
+    # the generated header must compile into gemm.hip (host-simulator build)
+    import shutil
+    import subprocess
+    import sim_lib
+    if not os.path.exists(sim_lib.CLANG):
+        return
+    src = open(os.path.join(ROOT, "musev_amd", "csrc", "gemm.hip")).read().replace('#include "gemm_tuned.h"', '#include "%s"' % (tmp_path / "gpurun_out" / "dry_gemm_tuned.h"))
+    (tmp_path / "gemm_sim.inc").write_text(sim_lib.transform(src))
+    shutil.copy(os.path.join(sim_lib.SIM, "gemm_main.cpp"), tmp_path / "gemm_main.cpp")
+    r = subprocess.run([sim_lib.CLANG, "-O0", "-std=c++17", "-pthread", "-w", "-fsyntax-only", "-I", sim_lib.SIM, "-I", str(tmp_path), str(tmp_path / "gemm_main.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
