@@ -109,3 +109,42 @@ def test_poseguider_module_through_the_simulated_library(sim_so):
     assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
     err = float([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1].split()[1])
     assert err < 1e-2, err
+
+
+_UNET = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import torch
+torch.set_num_threads(2)
+import sim_lib
+class MP:
+    def setattr(self, o, n, v): setattr(o, n, v)
+    def setenv(self, k, v): os.environ[k] = v
+sim_lib.install(MP(), {so!r})
+from oracle import unet3d
+from musev_amd.models.unet_loader import load_unet_by_name
+from model_cases import ARCHS, make_inputs
+flavour = {flavour!r}
+over = ARCHS["small" if flavour == "musev" else "small3"]
+cfg = unet3d.flavour_config(flavour, **over)
+sd = unet3d.init_state_dict(cfg, 3)
+x, ehs, kw = make_inputs(cfg, b=1, t=3, h=8, w=8, seed=103, n_cond=1)
+ref = unet3d.unet3d_forward(sd, cfg, x, torch.tensor(601), ehs, **kw)
+model = load_unet_by_name(flavour, sd_unet_model=sd, dtype=torch.float16, **over)
+model._device_check = False
+got = model(x, torch.tensor(601), encoder_hidden_states=ehs, return_dict=False, **kw)[0]
+print("RESULT", float((got.float() - ref).abs().max()))
+"""
+
+
+@pytest.mark.parametrize("flavour", ["musev", "musev_referencenet"])
+def test_unet_forward_through_the_simulated_library(sim_so, flavour):
+    """the WHOLE UNet3DConditionModel forward (small architecture, B = 1, T = 3, 8x8 latents) on the simulated kernels against
+    the oracle -- 25-30 minutes of simulation per flavour, so only with MUSEV_SIM_MODEL=1 (recorded results: DESIGN.md 7b)"""
+    if not os.environ.get("MUSEV_SIM_MODEL"):
+        pytest.skip("half an hour of simulation: set MUSEV_SIM_MODEL=1")
+    r = subprocess.run([sys.executable, "-c", _UNET.format(root=sim_lib.ROOT, here=HERE, so=sim_so, flavour=flavour)], capture_output=True,
+                       text=True, timeout=3 * 3600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    err = float([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1].split()[1])
+    assert err < 1e-2, err
