@@ -333,7 +333,7 @@ def main():
         names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
         agg = {}
         fam_bytes = 0.0
-        for mode, M, N, K, geglu, e0, e1, nbytes in prof:
+        for mode, M, N, K, geglu, e0, e1, nbytes in (r[:8] for r in prof):
             ms = e0.elapsed_time(e1)
             a = agg.setdefault(names[mode], [0.0, 0.0, 0])
             a[0] += 2.0 * M * N * K

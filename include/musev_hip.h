@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 2
+#define MV_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -71,28 +71,33 @@ typedef struct mv_gemm_desc {
     int32_t act;           /* MV_ACT_*                                                                 */
     int32_t geglu;         /* 1: w rows are [value | gate] interleaved per 16; out[m, n] for n < N/2 = */
                            /*    value * gelu(gate) (N is the full 2x width, ldc counts N/2 columns)   */
+    int32_t cfg;           /* tile configuration: -1 = measured per-shape table, then rules (default); */
+                           /*    -2 = rules only; >= 0 = this catalogue id wherever it applies          */
+    int32_t splitk;        /* K slices: 0 = library's choice, >= 1 = this many (clamped, see below)     */
+    void* workspace;       /* split-K scratch (fp32 slabs), 16-byte aligned; may be NULL when           */
+    int64_t workspace_bytes; /*  mv_gemm_workspace_bytes(d) == 0                                        */
 } mv_gemm_desc;
 
+/* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K
+ * choice (small-M, long-K problems) writes fp32 partial slabs [slices][M][N] into d->workspace and reduces them in fixed
+ * slice order (bit-reproducible); no allocation happens inside the library. */
 int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
-/* tuning knob (A/B runs): 0 = v1 register-staged copies, 1 = v1 LDS-DMA, 2 = v2 buffer-descriptor LDS-DMA (default),
- * 3 = v2 + 8-wave 256x160 tiles, 4 = persistent tile loop, 5 = 8-wave tiles on a three-stage counted-wait LDS ring,
- * 6 = BK-32 four-stage ring, 7 = 256x320 tiles wherever they fit, 8 = 2 + 256x256 tiles for the GEGLU GEMM */
-int mv_set_gemm_variant(int variant);
+/* bytes of workspace mv_gemm_f16 needs for this descriptor (0 = none; -1 = invalid descriptor, see mv_last_error) */
+int64_t mv_gemm_workspace_bytes(const mv_gemm_desc* d);
+/* the (tile configuration id, K slices) mv_gemm_f16 would use for this descriptor: introspection for tuners and tests */
+int mv_gemm_choice(const mv_gemm_desc* d, int32_t* cfg, int32_t* nsplit);
 
 /* tile-configuration catalogue of the implicit-GEMM kernel (block tile, waves, K depth, LDS stages), for the per-shape
- * tuner (tools/gpu_gemm_tune.py -> musev_amd/csrc/gemm_tuned.h) and A/B runs.  mv_set_gemm_force: cfg >= 0 uses that
- * configuration wherever it applies (the GEGLU epilogue needs an even number of 16-column tiles per wave), -1 = tuned table +
- * rules (default), -2 = rules only.  mv_gemm_config_desc fills {block rows, block columns, waves, BK, LDS stages}. */
-int mv_set_gemm_force(int cfg);
+ * tuner (tools/gpu_gemm_tune.py -> musev_amd/csrc/gemm_tuned.h).  mv_gemm_config_desc fills {block rows, block columns,
+ * waves, BK, LDS stages}. */
 int mv_gemm_num_configs(void);
 int mv_gemm_config_desc(int cfg, int32_t* desc5);
 
 /* workgroup -> output-tile order of the implicit-GEMM kernel: logical ids (contiguous per XCD) walk groups of `group`
  * m-tiles m-fastest when the grid is more than `group` n-tiles wide, so that the ~64 blocks resident on one XCD cover
- * ~8 x 8 tiles (what its L2 must fetch per window) instead of 1-3 m-tiles x the whole weight matrix.  Default 8;
- * 0 = plain m-major (A/B knob).  Results are independent of the order. */
-int mv_set_gemm_tile_group(int group);
-/* host-side evaluation of that map (launches nothing): tile_m[b], tile_n[b] of workgroup b, for b < tiles_m*tiles_n */
+ * ~8 x 8 tiles (what its L2 must fetch per window) instead of 1-3 m-tiles x the whole weight matrix (the kernel uses
+ * group 8).  Results are independent of the order.
+ * Host-side evaluation of that map (launches nothing): tile_m[b], tile_n[b] of workgroup b, for b < tiles_m*tiles_n */
 int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int32_t* tile_n);
 
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
@@ -149,15 +154,6 @@ typedef struct mv_attn_desc {
 } mv_attn_desc;
 
 int mv_attention_f16(const mv_attn_desc* d, void* stream);
-/* tuning knob (A/B runs): bits 0-1: 1 = single-buffered K/V tiles (default), 2 = double-buffered tiles for d <= 80,
- * 3 = variant 1 with the reduced softmax VALU work (row sums through a ones column in the P.V MFMA at d = 40);
- * +4 = temporal attention v1 (per-lane global K/V fetch) instead of v2 (K/V staged in LDS, default);
- * +8 = round-toward-zero packing of the probabilities (d = 40); +16 = K/V tiles fetched through buffer descriptors
- * (scalar tile advance, out-of-range offsets for the rows past a segment's end) instead of per-lane pointers (d = 40 / 80);
- * +32 = K tile row stride DP + 16 halfs instead of DP + 8 (which of the two is free of LDS bank conflicts depends on how the
- * hardware groups the lanes of a ds_read_b128; d = 40 / 80); +64 = V tile rows unpadded (the conflict-free stride of the
- * transpose read if it is served 32 lanes at a time) */
-int mv_set_attn_variant(int variant);
 
 /* ---- temporal self-attention over T <= 32 frames per pixel (K6c) -------------------------------------
  * rows are ordered (b, t, p): sequence of pixel (b, p) = rows (b*T + t)*HW + p, t = 0..T-1.

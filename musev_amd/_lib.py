@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmusev_hip.so")
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 2
+MV_ABI_VERSION = 3
 
 
 class MuseVHipError(RuntimeError):
@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("hin", C.c_int32), ("win", C.c_int32), ("hout", C.c_int32), ("wout", C.c_int32),
         ("t", C.c_int32), ("hw", C.c_int32),
         ("rows_per_group", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
+        ("cfg", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -60,9 +61,8 @@ SIGNATURES = {
     "mv_abi_version": (_i32, []),
     "mv_last_error": (C.c_char_p, []),
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
-    "mv_set_gemm_variant": (_i32, [_i32]),
-    "mv_set_gemm_tile_group": (_i32, [_i32]),
-    "mv_set_gemm_force": (_i32, [_i32]),
+    "mv_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
+    "mv_gemm_choice": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
     "mv_gemm_num_configs": (_i32, []),
     "mv_gemm_config_desc": (_i32, [_i32, _vp]),
     "mv_gemm_tile_order": (_i32, [_i32, _i32, _i32, _vp, _vp]),
@@ -72,7 +72,6 @@ SIGNATURES = {
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),
     "mv_attention_f16": (_i32, [C.POINTER(AttnDesc), _vp]),
-    "mv_set_attn_variant": (_i32, [_i32]),
     "mv_temporal_attention_f16": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _f32, _vp]),
     "mv_geglu_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
@@ -113,18 +112,6 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.mv_abi_version() != MV_ABI_VERSION:
         raise MuseVHipError(f"ABI mismatch: library {lib.mv_abi_version()} vs binding {MV_ABI_VERSION}")
-    variant = os.environ.get("MUSEV_GEMM_VARIANT")  # tuning knob for A/B runs (see mv_set_gemm_variant)
-    if variant is not None:
-        lib.mv_set_gemm_variant(int(variant))
-    force = os.environ.get("MUSEV_GEMM_FORCE")  # tile configuration id (see mv_set_gemm_force); -2 = ignore the tuned table
-    if force is not None:
-        lib.mv_set_gemm_force(int(force))
-    group = os.environ.get("MUSEV_GEMM_TILE_GROUP")  # 0 = plain m-major tile order (see mv_set_gemm_tile_group)
-    if group is not None:
-        lib.mv_set_gemm_tile_group(int(group))
-    variant = os.environ.get("MUSEV_ATTN_VARIANT")
-    if variant is not None:
-        lib.mv_set_attn_variant(int(variant))
     _lib = lib
     return lib
 

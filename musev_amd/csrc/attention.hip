@@ -416,265 +416,6 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
     }
 }
 
-// ---- v2 of the fused attention for d = 40 / 80: double-buffered K/V tiles (ONE barrier per 64-key tile instead of two),
-// a prefetch cursor that runs one tile ahead across segment boundaries (no exposed global round trip at a segment
-// start), exact skipping of the O rescale when no row maximum moved (alpha == 1), raised wave priority inside the MFMA
-// clusters.  Math, fragment layouts and masking are those of attn_kernel.
-struct AttnCursor {
-    int seg, base, len;
-    long ldk, ldv;
-    const half_t* kb;
-    const half_t* vb;
-};
-
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnArgs p) {
-    using C = AttnCfg<D>;
-    constexpr int TILE = C::LDS_HALFS;  // halfs per (K, V) buffer
-    __shared__ __attribute__((aligned(16))) half_t lds[2 * TILE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y;
-    const int n = blockIdx.z;
-    const int q0 = blockIdx.x * C::QB + wave * (16 * C::QT);
-
-    // zero both K tiles once: the padded contraction columns [D, DP) must read as 0 forever
-    for (int b = 0; b < 2; ++b)
-        for (int i = tid; i < C::KV * C::KRS / 8; i += 256) reinterpret_cast<uint4*>(lds + b * TILE)[i] = uint4{0, 0, 0, 0};
-
-    half8v qf[C::QT][C::NC];
-#pragma unroll
-    for (int qt = 0; qt < C::QT; ++qt) {
-        const int qr = q0 + 16 * qt + l15;
-#pragma unroll
-        for (int c = 0; c < C::NC; ++c) {
-            const int dcol = 32 * c + 8 * g;
-            half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qr < p.lq && dcol < D)
-                v = *reinterpret_cast<const half8v*>(p.q + ((long)n * p.lq + qr) * p.ldq + h * D + dcol);
-            qf[qt][c] = v;
-        }
-    }
-    float4v acc_o[C::QT][C::NDT];
-#pragma unroll
-    for (int qt = 0; qt < C::QT; ++qt)
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
-    float m_run[C::QT], l_run[C::QT];
-#pragma unroll
-    for (int qt = 0; qt < C::QT; ++qt) {
-        m_run[qt] = -INFINITY;
-        l_run[qt] = 0.f;
-    }
-
-    const half_t* zero = reinterpret_cast<const half_t*>(g_attn_zero);
-    u32x4 pf[C::PF];
-    AttnStage<D> stg;   // per-thread chunk geometry, segment independent part
-#pragma unroll
-    for (int i = 0; i < C::PF; ++i) {
-        const int idx = tid + 256 * i;
-        const bool isv = idx >= C::CHUNKS;
-        const int cidx = isv ? idx - C::CHUNKS : idx;
-        const int row = cidx / C::DCH, ch = cidx - row * C::DCH;
-        stg.isv[i] = isv;
-        stg.row[i] = (idx < 2 * C::CHUNKS) ? row : (1 << 20);
-        stg.loff[i] = isv ? C::KV * C::KRS + row * C::VRS + ch * 8 : row * C::KRS + ch * 8;
-        stg.goff[i] = ch * 8;
-    }
-    AttnStage<D> st = stg;  // with the current prefetch segment's row strides folded in
-
-    auto make_cur = [&](int seg) __attribute__((always_inline)) -> AttnCursor {
-        AttnCursor c;
-        c.seg = seg;
-        c.base = 0;
-        c.len = 0;
-        c.ldk = c.ldv = 0;
-        c.kb = c.vb = zero;
-        if (seg < p.nseg) {
-            c.len = ATTN_SEG_FIELD(p, seg, len);
-            c.ldk = ATTN_SEG_FIELD(p, seg, ldk);
-            c.ldv = ATTN_SEG_FIELD(p, seg, ldv);
-            const int sdiv = ATTN_SEG_FIELD(p, seg, div), smul = ATTN_SEG_FIELD(p, seg, mul), sadd = ATTN_SEG_FIELD(p, seg, add);
-            const long kvb = (long)(n / sdiv) * smul + sadd;
-            c.kb = ATTN_SEG_FIELD(p, seg, k) + kvb * c.len * c.ldk + h * D;
-            c.vb = ATTN_SEG_FIELD(p, seg, v) + kvb * c.len * c.ldv + h * D;
-        }
-        return c;
-    };
-    auto next_cur = [&](AttnCursor c) __attribute__((always_inline)) -> AttnCursor {
-        c.base += C::KV;
-        if (c.base >= c.len) return make_cur(c.seg + 1);
-        return c;
-    };
-    auto fold_strides = [&](const AttnCursor& c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < C::PF; ++i) {
-            const int r = stg.row[i] < C::KV ? stg.row[i] : 0;
-            st.goff[i] = stg.goff[i] + (long)r * (stg.isv[i] ? c.ldv : c.ldk);
-        }
-    };
-
-    AttnCursor pc = make_cur(0);  // prefetch cursor (runs ahead)
-    AttnCursor cc = pc;           // compute cursor
-    int st_seg = 0;
-    fold_strides(pc);
-    // tile 0 -> registers -> buffer 0 ; tile 1 -> registers
-    attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
-    pc = next_cur(pc);
-    __syncthreads();  // orders the zero fill before the first commit
-    attn_commit<D>(pf, st, lds);
-    bool pf_valid = pc.seg < p.nseg;
-    if (pf_valid) {
-        if (pc.seg != st_seg) {
-            fold_strides(pc);
-            st_seg = pc.seg;
-        }
-        attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
-        pc = next_cur(pc);
-    }
-    __syncthreads();
-
-    for (int t = 0; cc.seg < p.nseg; ++t) {
-        half_t* cur = lds + (t & 1) * TILE;
-        half_t* nxt = lds + ((t + 1) & 1) * TILE;
-        const half_t* sK = cur;
-        const half_t* sV = cur + C::KV * C::KRS;
-        // tile t+1: registers -> the other buffer (last read in iteration t-1, which every wave has left);
-        // tile t+2: global -> registers, a whole tile of MFMAs ahead of its commit
-        if (pf_valid) attn_commit<D>(pf, st, nxt);
-        pf_valid = pc.seg < p.nseg;
-        if (pf_valid) {
-            if (pc.seg != st_seg) {
-                fold_strides(pc);
-                st_seg = pc.seg;
-            }
-            attn_prefetch<D>(pf, st, pc.kb, pc.vb, pc.ldk, pc.ldv, pc.base, pc.len, zero);
-            pc = next_cur(pc);
-        }
-
-        // ---- S^T = K Q^T ----
-        float4v acc_s[C::QT][4];
-#pragma unroll
-        for (int qt = 0; qt < C::QT; ++qt)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc_s[qt][s4] = float4v{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int c = 0; c < C::NC; ++c) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                half8v kf = *reinterpret_cast<const half8v*>(sK + (16 * s4 + l15) * C::KRS + 32 * c + 8 * g);
-#pragma unroll
-                for (int qt = 0; qt < C::QT; ++qt)
-                    acc_s[qt][s4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][c], acc_s[qt][s4], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (cc.base + C::KV > cc.len) {  // tail of the segment
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (cc.base + 16 * s4 + 4 * g + r >= cc.len) {
-#pragma unroll
-                        for (int qt = 0; qt < C::QT; ++qt) acc_s[qt][s4][r] = -INFINITY;
-                    }
-                }
-        }
-        // ---- online softmax ----
-        half8v pfrag[C::QT][2];
-#pragma unroll
-        for (int qt = 0; qt < C::QT; ++qt) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[qt][s4][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx * p.scale_log2e);
-            // alpha == exp2(0) == 1 exactly when no row maximum of this wave moved: skipping the rescale is bit-exact
-            if (__any(m_new != m_run[qt])) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-                l_run[qt] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
-                m_run[qt] = m_new;
-            }
-            float ps = 0.f;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e = __builtin_amdgcn_exp2f(fmaf(acc_s[qt][s4][r], p.scale_log2e, -m_new));
-                    acc_s[qt][s4][r] = e;
-                    ps += e;
-                }
-            l_run[qt] += ps;
-#pragma unroll
-            for (int cc2 = 0; cc2 < 2; ++cc2) {
-                half8v f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f[r] = (half_t)acc_s[qt][2 * cc2][r];
-                    f[4 + r] = (half_t)acc_s[qt][2 * cc2 + 1][r];
-                }
-                pfrag[qt][cc2] = f;
-            }
-        }
-        // ---- O^T += V^T P^T ----
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int cc2 = 0; cc2 < 2; ++cc2) {
-#pragma unroll
-            for (int dt = 0; dt < C::NDT; ++dt) {
-                const half_t* b0p = sV + (32 * cc2 + 4 * g + (l15 >> 2)) * C::VRS + 16 * dt + (l15 & 3) * 4;
-                short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0p));
-                short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0p + 16 * C::VRS));
-                typedef short short8v __attribute__((ext_vector_type(8)));
-                short8v tv = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-                half8v vf = __builtin_bit_cast(half8v, tv);
-#pragma unroll
-                for (int qt = 0; qt < C::QT; ++qt)
-                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfrag[qt][cc2], acc_o[qt][dt], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        cc = next_cur(cc);
-        __syncthreads();  // tile t consumed by every wave; tile t+1 (committed above) visible
-    }
-
-#pragma unroll
-    for (int qt = 0; qt < C::QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        const int qr = q0 + 16 * qt + l15;
-        if (qr >= p.lq) continue;
-        half_t* orow = p.out + ((long)n * p.lq + qr) * p.ldo + h * D;
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) {
-            const int dcol = 16 * dt + 4 * g;
-            if (dcol >= D) continue;
-            float4v o = acc_o[qt][dt] * inv;
-            if (p.accumulate) {
-                half4v prev = *reinterpret_cast<const half4v*>(orow + dcol);
-                o = float4v{(float)prev[0], (float)prev[1], (float)prev[2], (float)prev[3]} + o * p.out_scale;
-            }
-            half4v w = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-            *reinterpret_cast<half4v*>(orow + dcol) = w;
-        }
-    }
-}
-
-int g_attn_pkrtz = 0;    // +8 on mv_set_attn_variant: round-toward-zero packing of P (variant 3, d = 40)
-int g_attn_buf = 0;      // +16: K/V tiles fetched through buffer descriptors (attn_kernel<D, 3>, d = 40 / 80)
-int g_attn_kpad16 = 0;   // +32: K tile row stride DP + 16 instead of DP + 8 (variant 3, d = 40 / 80)
-int g_attn_vpad0 = 0;    // +64: V tile rows without padding (variant 3, d = 40 / 80)
-int g_attn_variant = 3;  // tuning knob (mv_set_attn_variant): 1 = attn_kernel, 2 = attn2_kernel for d <= 80
-
 // ------------------------------------------------------------------------------------------------------
 struct TAttnArgs {
     const half_t* q;
@@ -886,22 +627,7 @@ __global__ __launch_bounds__(16 * IPB) void tattn2_kernel(const TAttnArgs a) {
     }
 }
 
-int g_tattn_variant = 2;  // 1 = tattn_kernel, 2 = tattn2_kernel where it applies (T <= 16, d in {40, 80, 160})
-
 }  // namespace
-
-extern "C" int mv_set_attn_variant(int v) {
-    // bits 0-1: spatial attention kernel (1 | 2 | 3); +4: temporal attention v1 instead of v2; +8: pkrtz; +16: buffer-descriptor K/V
-    // fetch; +32: K tile row stride DP + 16; +64: V tile rows unpadded
-    MV_REQUIRE((v & 3) >= 1, "mv_set_attn_variant: variant %d", v);
-    g_attn_variant = v & 3;
-    g_tattn_variant = (v & 4) ? 1 : 2;
-    g_attn_pkrtz = (v & 8) ? 1 : 0;
-    g_attn_buf = (v & 16) ? 1 : 0;
-    g_attn_kpad16 = (v & 32) ? 1 : 0;
-    g_attn_vpad0 = (v & 64) ? 1 : 0;
-    return MV_OK;
-}
 
 extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     MV_REQUIRE(d && d->q && d->out, "mv_attention_f16: null pointer");
@@ -928,27 +654,11 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     const int qb = d->d > 80 ? 64 : 128;  // AttnCfg<D>::QB
     dim3 grid((unsigned)((d->lq + qb - 1) / qb), (unsigned)d->heads, (unsigned)d->nb);
     hipStream_t s = (hipStream_t)stream;
-    if (d->d == 40 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<40>, grid, dim3(256), 0, s, a);
-    else if (d->d == 80 && g_attn_variant == 2) hipLaunchKernelGGL(attn2_kernel<80>, grid, dim3(256), 0, s, a);
-    else if (g_attn_variant == 3 && (d->d == 40 || d->d == 80)) {
-        // the variant-3 family: OPT 1 (register-staged K/V prefetch) | 2 (+ pkrtz, d = 40) | 3 (buffer-descriptor fetch), K row pad
-        // 8 | 16, V row pad 8 | 0 -- every combination instantiated for the A/B (tools/gpu_gemm_ab.py); default 1 / 8 / 8
-        const int opt = g_attn_buf ? 3 : ((g_attn_pkrtz && d->d == 40 && !g_attn_kpad16 && !g_attn_vpad0) ? 2 : 1);
-        const int kp = g_attn_kpad16 ? 16 : 8, vp = g_attn_vpad0 ? 0 : 8;
-        bool launched = false;
-#define MV_ATTN_TRY(D_, OPT_, KP_, VP_)                                                              \
-    if (!launched && d->d == D_ && opt == OPT_ && kp == KP_ && vp == VP_) {                           \
-        hipLaunchKernelGGL((attn_kernel<D_, OPT_, KP_, VP_>), grid, dim3(256), 0, s, a);             \
-        launched = true;                                                                             \
-    }
-#define MV_ATTN_PADS(D_, OPT_) MV_ATTN_TRY(D_, OPT_, 8, 8) MV_ATTN_TRY(D_, OPT_, 16, 8) MV_ATTN_TRY(D_, OPT_, 8, 0) MV_ATTN_TRY(D_, OPT_, 16, 0)
-        MV_ATTN_PADS(40, 1) MV_ATTN_PADS(40, 3) MV_ATTN_PADS(80, 1) MV_ATTN_PADS(80, 3) MV_ATTN_TRY(40, 2, 8, 8)
-#undef MV_ATTN_PADS
-#undef MV_ATTN_TRY
-        MV_REQUIRE(launched, "mv_attention_f16: no kernel for variant bits (d=%d opt=%d kpad=%d vpad=%d)", d->d, opt, kp, vp);
-    }
-    else if (d->d == 40) hipLaunchKernelGGL((attn_kernel<40, 0>), grid, dim3(256), 0, s, a);
-    else if (d->d == 80) hipLaunchKernelGGL((attn_kernel<80, 0>), grid, dim3(256), 0, s, a);
+    // d = 40 / 80: OPT 1 (row sums out of the P.V MFMA, 3-input maxima, exact rescale skip); the round-1 / round-2 A/B of the
+    // other variants (double-buffered tiles, pkrtz packing, buffer-descriptor K/V fetch, K / V row strides) measured within
+    // +-3 % of it at d = 40 and -20..-30 % at d = 80 (profiles/r02a_attn_variant_ab.log): removed from the library
+    if (d->d == 40) hipLaunchKernelGGL((attn_kernel<40, 1>), grid, dim3(256), 0, s, a);
+    else if (d->d == 80) hipLaunchKernelGGL((attn_kernel<80, 1>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<160, 0>), grid, dim3(256), 0, s, a);
     MV_CHECK_LAUNCH("mv_attention_f16");
     return MV_OK;
@@ -968,7 +678,7 @@ extern "C" int mv_temporal_attention_f16(const void* q, const void* k, const voi
     hipStream_t s = (hipStream_t)stream;
     // v2 pays where the item count is large (level 0: 65 536 items of d = 40: 141 -> 98 us); at d = 80 / 160 its small
     // blocks under-fill the CUs (measured 94 vs 80 us and 132 vs 44 us, profiles/r01f) and v1 stays
-    if (g_tattn_variant == 2 && t <= 16 && d == 40) {
+    if (t <= 16 && d == 40) {
         const size_t smem = (size_t)2 * 640 * t * sizeof(half_t);  // IPB * D == 640 in every configuration (<= 40 KB)
         if (d == 40) hipLaunchKernelGGL((tattn2_kernel<40, 16>), dim3((unsigned)((a.items + 15) / 16)), dim3(256), smem, s, a);
         else if (d == 80) hipLaunchKernelGGL((tattn2_kernel<80, 8>), dim3((unsigned)((a.items + 7) / 8)), dim3(128), smem, s, a);

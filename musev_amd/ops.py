@@ -11,6 +11,7 @@ QKV projection are passed without copies).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -36,8 +37,24 @@ def _stream() -> int:
 GEMM_PROFILE: Optional[list] = None
 
 
+# Tile configuration / split-K factor forced on every implicit-GEMM launch of this process (tuner and A/B runs; the C library
+# itself keeps no such state -- the choice travels in each call's descriptor).  Read once at import:
+#   MUSEV_GEMM_CFG    -1 = measured per-shape table, then rules (default); -2 = rules only; >= 0 = that catalogue id
+#   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
+GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
+GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
+
+
 def _launch_gemm(d: GemmDesc, what: str) -> None:
     lib = _lib.load()
+    d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
+    need = lib.mv_gemm_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(1, what)
+    ws = None
+    if need > 0:  # split-K slabs: scratch from torch's caching allocator (inside a graph capture: the capture's private pool)
+        ws = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
     if GEMM_PROFILE is None:
         check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
         return

@@ -72,6 +72,8 @@ class ParallelDenoiser:
         # profiles/r01j): MUSEV_HALF_STREAMS=0 restores the single batch-2 forward (per-kernel profiling)
         self.half_streams = os.environ.get("MUSEV_HALF_STREAMS", "1") == "1"
         self._side = {}
+        self._t_bufs: Dict[str, torch.Tensor] = {}
+        self._warm: Dict[tuple, bool] = {}  # signatures whose lazily built caches (packed weights, K/V projections) are filled
         self.scheduler = scheduler or DDIMScheduler()
         self.context_frames, self.context_overlap = context_frames, context_overlap
         self.context_stride, self.context_schedule = context_stride, context_schedule
@@ -133,9 +135,16 @@ class ParallelDenoiser:
         guidance = [float(g) for g in generate_parameters_with_timesteps(start=guidance_scale, stop=guidance_scale_end,
                                                                         num=len(timesteps), method=guidance_scale_method)]
         wins = self.windows(T, num_inference_steps)
-        win_len = len(wins[0])
-        if any(len(wd) != win_len for wd in wins):
-            raise NotImplementedError("windows of unequal length")
+        # windows may differ in length: `uniform_v2` (the CLI default, scripts/inference/text2video.py:499-505) ends with a
+        # short window whenever (T - overlap) % (window - overlap) != 0, and the reference runs every window as its own UNet
+        # call of whatever length (pipeline_controlnet.py:1900-1946).  Exchange slots are sized by the longest window.
+        win_len = max(len(wd) for wd in wins)
+        for wd in wins:
+            if len(set(wd)) != len(wd):
+                # `uniform` with context_stride > 1 can wrap a window onto a frame it already holds; the reference's
+                # index-assign then keeps one of the two predictions while the coverage counter counts the frame once --
+                # an ill-defined case (and a write race for a parallel scatter), refused instead of silently differing
+                raise NotImplementedError(f"window {wd} visits a frame twice")
         idx_dev = [torch.tensor(wd, dtype=torch.int32, device=dev) for wd in wins]
         counter = torch.zeros(T, dtype=torch.float32, device=dev)
         for wd in wins:  # coverage count is the same at every step: computed once (:2078)
@@ -155,14 +164,19 @@ class ParallelDenoiser:
         recv = torch.empty((world * max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
 
         vis_idx = list(range(n_cond)) if n_cond else None  # host ints (vision_condition_latent_index, :1914-1920)
-        sub_idx = (torch.arange(win_len, dtype=torch.long, device=dev) + n_cond) if n_cond else None
-        t_dev = torch.zeros(1, dtype=torch.float32, device=dev)  # static timestep buffer (graph input)
+        # sub_latent_index_c = arange(len(window)) + n_cond (:1914-1920), one tensor per distinct window length
+        sub_idx_by_len = {n: ((torch.arange(n, dtype=torch.long, device=dev) + n_cond) if n_cond else None)
+                          for n in sorted({len(wd) for wd in wins})}
+        # static timestep buffer (graph input): one per device for the lifetime of this object, so that the captures of one
+        # call are reused by the next (multi-shot generation replays the same graphs)
+        t_dev = self._t_bufs.get(str(dev))
+        if t_dev is None:
+            t_dev = self._t_bufs[str(dev)] = torch.zeros(1, dtype=torch.float32, device=dev)
         embeds = prompt_embeds.to(dev)
         eps_acc = torch.empty((halves, c, T, hw), dtype=torch.float32, device=dev)
-        tw = n_cond + win_len
 
         # ---- ControlNet conditioning (optional) ----
-        cn_keep, ctrl_frames, ctrl_buf, text_rep = None, None, None, None
+        cn_keep, ctrl_frames, ctrl_bufs, text_rep_by_len = None, None, None, None
         if controlnet is not None:
             if control_image is None or control_image.ndim != 5 or control_image.shape[0] != 1 or control_image.shape[2] != n_cond + T:
                 raise ValueError("control_image must be [1, c, n_cond + T, H, W] (condition frames first)")
@@ -175,9 +189,10 @@ class ParallelDenoiser:
             for wd in wins:  # controlnet_context = condition indices + (window indices + n_cond)   (:1953-1961)
                 sel = torch.tensor(list(range(n_cond)) + [i + n_cond for i in wd], dtype=torch.long, device=dev)
                 ctrl_frames.append(frames_all.index_select(0, sel).to(torch.float16).contiguous())
-            ctrl_buf = torch.empty_like(ctrl_frames[0])  # static buffer: the captured graphs read the window's frames from here
+            # static buffers (one per window length): the captured graphs read the window's frames from here
+            ctrl_bufs = {n: torch.empty_like(next(f for f, wd in zip(ctrl_frames, wins) if len(wd) == n)) for n in sub_idx_by_len}
             # align_repeat_tensor_single_dim(prompt_embeds, (b t)) (:1242-1246): one row of text per frame, per CFG half
-            text_rep = embeds.repeat_interleave(tw, dim=0).contiguous()
+            text_rep_by_len = {n: embeds.repeat_interleave(n_cond + n, dim=0).contiguous() for n in sub_idx_by_len}
 
         for step, t in enumerate(timesteps):
             if max_steps is not None and step >= max_steps:
@@ -189,28 +204,32 @@ class ParallelDenoiser:
             in_scale = sched.input_scale(step)
             lat_in = lat if in_scale == 1.0 else lat * in_scale
             slot = 0
-            cn = None
+            cn, cn_on = None, False
             if controlnet is not None:
                 cond_scale = float(controlnet_conditioning_scale) * cn_keep[step]   # :1229-1236
-                if cond_scale != 0.0:  # a zero scale makes every residual zero: adding them is a no-op, skip the network
-                    cn = (controlnet, ctrl_buf, text_rep, cond_scale, bool(guess_mode))
+                cn_on = cond_scale != 0.0  # a zero scale makes every residual zero: adding them is a no-op, skip the network
             for wi, hs in my_groups:
+                wl = len(wins[wi])
+                tw = n_cond + wl
                 x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs))
-                if cn is not None:
-                    ctrl_buf.copy_(ctrl_frames[wi])
-                eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx, vis_idx, motion_speed, unet_kwargs, cn)
+                if controlnet is not None and cn_on:
+                    ctrl_bufs[wl].copy_(ctrl_frames[wi])
+                    cn = (controlnet, ctrl_bufs[wl], text_rep_by_len[wl], cond_scale, bool(guess_mode))
+                eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx_by_len[wl], vis_idx, motion_speed,
+                                      unet_kwargs, cn)
                 if world == 1:
                     for k, hf in enumerate(hs):
                         ops.window_scatter_add(eps[k * tw * hw:(k + 1) * tw * hw], idx_dev[wi], n_cond, 1, hf, eps_acc, counter, False)
                 else:
                     for k, hf in enumerate(hs):
-                        send[slot].copy_(eps[(k * tw + n_cond) * hw:(k + 1) * tw * hw])
+                        send[slot, :wl * hw].copy_(eps[(k * tw + n_cond) * hw:(k + 1) * tw * hw])
                         slot += 1
             if world > 1:
                 torch.distributed.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
                 for r in range(world):  # fixed accumulation order on every rank -> bit-identical replicas
                     for k, u in enumerate(shards[r]):
-                        ops.window_scatter_add(recv[r * max_units + k], idx_dev[u.window], 0, 1, u.half, eps_acc, counter, False)
+                        ops.window_scatter_add(recv[r * max_units + k, :len(wins[u.window]) * hw], idx_dev[u.window], 0, 1, u.half,
+                                               eps_acc, counter, False)
             sched.loop_update(lat, eps_acc, counter, guidance[step], step, t)
             sched.consume_step_noise((1, c, T, h, w), latents.dtype, dev, generator, noise_type, w_ind_noise)
             if callback is not None:
@@ -244,6 +263,10 @@ class ParallelDenoiser:
                                           vision_conditon_frames_sample_index=vis_idx, sample_frame_rate=motion_speed, **k)
 
         split_halves = len(hs) == 2 and cn is not None and cn[4]  # guess mode needs the halves apart
+        # identity of everything a forward of this call reads besides x
+        sig = (hs, tw, h, w, float(motion_speed), t_dev.data_ptr(), embeds.data_ptr(), tuple(vis_idx or ()),
+               tuple(sorted((k, _ident(v)) for k, v in kw.items())), tuple(x.shape),
+               None if cn is None else (id(cn[0]), cn[1].data_ptr(), cn[2].data_ptr(), cn[3], cn[4]))
 
         def eager(inp):
             if split_halves and not (self.half_streams and inp.is_cuda):
@@ -259,6 +282,17 @@ class ParallelDenoiser:
             main = torch.cuda.current_stream()
             side = self._side_stream(inp.device)
             kws = [{k: (self._slice_half(v, [i], halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()} for i in hs]
+            # The forward builds shared caches lazily (packed conv / QKV / GEGLU weights, batched embedding projections, K/V
+            # of the prompt): the FIRST forward of a signature -- and the first after any parameter / pack-epoch change --
+            # runs both halves on ONE stream, so no stream ever reads a cache another stream is still filling.
+            wkey = (sig, _pack_epoch(), _param_epoch(self.unet), None if cn is None else _param_epoch(cn[0]))
+            if wkey not in self._warm:
+                if len(self._warm) >= 64:
+                    self._warm.clear()
+                e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0])
+                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
+                self._warm[wkey] = True
+                return torch.cat([e0, e1], dim=0)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
@@ -269,21 +303,17 @@ class ParallelDenoiser:
 
         if not (self.use_graphs and x.is_cuda and hasattr(torch.cuda, "CUDAGraph")):
             return eager(x)
-        # a captured graph is only valid for the exact tensors it was recorded with: key on their identities
-        key = (hs, tw, h, w, float(motion_speed), t_dev.data_ptr(), embeds.data_ptr(), tuple(vis_idx or ()),
-               tuple(sorted((k, _ident(v)) for k, v in kw.items())), tuple(x.shape), _param_epoch(self.unet),
-               None if cn is None else (id(cn[0]), cn[1].data_ptr(), cn[2].data_ptr(), cn[3], cn[4], _param_epoch(cn[0])))
-        gf = self._graphs.get(key)
+        # a captured graph is only valid for the exact tensors it was recorded with: key on their identities, on the model's
+        # parameter epoch and on the process-wide pack epoch (a .to() / load_state_dict of ANY HipModule re-packs weights)
+        key = sig + (_pack_epoch(), _param_epoch(self.unet), None if cn is None else _param_epoch(cn[0]))
+        gf = self._graphs.pop(key, None)
         if gf is None:
-            if len(self._graphs) >= 8:  # stale captures (other prompts / sizes) would pin their activation pools
-                self._graphs.clear()
-            if self.half_streams and len(hs) == 2:
-                # fill the shared packed-weight caches on ONE stream before two streams start using them
-                one(x, len(hs), ehs, kw)
-                torch.cuda.synchronize()
-            gf = _GraphedForward(eager, x)
+            while len(self._graphs) >= 8:  # least recently used first: stale captures pin their activation pools
+                self._graphs.pop(next(iter(self._graphs)))
+            gf = _GraphedForward(eager, x)  # its eager warm-up call is the single-stream cache fill (see eager())
             self._graphs[key] = gf
             return gf.first_result
+        self._graphs[key] = gf  # re-insert: dict order = recency
         return gf(x)
 
     def _side_stream(self, dev):
@@ -311,6 +341,11 @@ def _ident(v) -> tuple:
     if isinstance(v, (list, tuple)):
         return tuple(_ident(e) for e in v)
     return (repr(v),)
+
+
+def _pack_epoch() -> int:
+    from ..models.layers import _PACK_EPOCH
+    return _PACK_EPOCH[0]
 
 
 def _param_epoch(unet) -> int:

@@ -198,8 +198,9 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                  scheduler_kwargs: Optional[dict] = None, guidance_scale_end: Optional[float] = None,
                  guidance_scale_method: str = "linear", controlnet_fn: Optional[Callable[..., tuple]] = None,
                  control_image: Optional[Tensor] = None, controlnet_conditioning_scale: float = 1.0,
-                 control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guess_mode: bool = False) -> Tensor:
-    """pipeline_controlnet.py:1832-2156.  ``max_steps`` (test helper, not in the reference): stop after the first
+                 control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guess_mode: bool = False,
+                 record_latents: Optional[list] = None) -> Tensor:
+    """pipeline_controlnet.py:1832-2156.  ``record`` / ``record_latents`` (test helpers): per-step guided noise prediction / latents.  ``max_steps`` (test helper, not in the reference): stop after the first
     max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
     vision_conditon_frames_sample_index=, sample_frame_rate=, **unet_kwargs) -> eps [2, c, n_cond + win, h, w].
@@ -272,6 +273,8 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
         if record is not None:
             record.append(noise_pred.clone())
         latents = sched.step(noise_pred, i if euler else int(t), latents)                     # :2112-2117
+        if record_latents is not None:
+            record_latents.append(latents.clone())
     if condition_latents is not None:
         out = torch.zeros((latents.shape[0], latents.shape[1], n_cond + T, *latents.shape[3:]), dtype=latents.dtype)
         out.index_copy_(2, vis_idx, condition_latents)

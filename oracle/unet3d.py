@@ -242,7 +242,7 @@ def init_state_dict(cfg: dict, seed: int = 3, gain: float = 1.0, residual_gain: 
 def timesteps_sincos(t: Tensor, dim: int) -> Tensor:
     """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     emb = t.float()[:, None] * torch.exp(exponent)[None, :]
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
@@ -279,8 +279,14 @@ def sdp_attention(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
     """softmax(q k^T * d^-0.5) v per head; what xformers.memory_efficient_attention / SDPA compute."""
     qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
     scale = qh.shape[-1] ** -0.5
-    s = torch.matmul(qh, kh.transpose(-1, -2)) * scale
-    o = torch.matmul(torch.softmax(s, dim=-1), vh)
+    # the same arithmetic per batch item; sliced over the batch so that the BASELINE-size cases (26 frames x 8 heads x
+    # 4096 x 8192 scores = 28 GB at once) fit the host memory
+    per = max(1, (1 << 28) // max(1, qh.shape[1] * qh.shape[2] * kh.shape[2]))
+    outs = []
+    for b0 in range(0, qh.shape[0], per):
+        s = torch.matmul(qh[b0:b0 + per], kh[b0:b0 + per].transpose(-1, -2)) * scale
+        outs.append(torch.matmul(torch.softmax(s, dim=-1), vh[b0:b0 + per]))
+    o = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
     b, h, l, d = o.shape
     return o.transpose(1, 2).reshape(b, l, h * d)
 
@@ -301,7 +307,7 @@ def align_repeat(src: Tensor, target_length: int, dim: int = 0) -> Tensor:
         assert target_length % n == 0
         return src.repeat_interleave(target_length // n, dim=dim)
     if target_length < n:
-        return src.index_select(dim, torch.arange(target_length))
+        return src.index_select(dim, torch.arange(target_length, device=src.device))
     return src
 
 
@@ -449,8 +455,9 @@ def unet3d_forward(
 
     # 1. time embedding (:887-906)
     t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
-    t = t.reshape(-1).expand(b)
-    emb = timestep_embedding_mlp(sd, "time_embedding", timesteps_sincos(t, ch[0]))
+    t = t.reshape(-1).expand(b).to(sample.device)
+    wdt = sd["conv_in.weight"].dtype  # the weights' dtype: fp32 (the oracle) or fp16 (the "fp16 torch" drift floor of the tests)
+    emb = timestep_embedding_mlp(sd, "time_embedding", timesteps_sincos(t, ch[0]).to(wdt))
     if cfg["use_anivv1_cfg"]:
         emb = F.silu(emb)
     emb = emb.repeat_interleave(num_frames, dim=0)
@@ -459,10 +466,10 @@ def unet3d_forward(
         emb[:, vis_idx, :] = 0
         emb = rearrange(emb, "b t d -> (b t) d")
     # frame embedding (:909-937); frame_index is window-local
-    frame_index = torch.arange(num_frames, dtype=torch.long)
+    frame_index = torch.arange(num_frames, dtype=torch.long, device=sample.device)
     if cfg["use_anivv1_cfg"]:
         frame_index = (frame_index * sample_frame_rate).to(dtype=torch.long)
-    femb = repeat(timesteps_sincos(frame_index, ch[0]), "t d -> b t d", b=b)
+    femb = repeat(timesteps_sincos(frame_index, ch[0]).to(wdt), "t d -> b t d", b=b)
     femb = timestep_embedding_mlp(sd, "frame_embedding", femb)
     if cfg["use_anivv1_cfg"]:
         femb = F.silu(femb)

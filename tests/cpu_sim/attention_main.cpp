@@ -42,7 +42,6 @@ int main(int argc, char** argv) {
     const long rows = (long)kv["rows"], ldo = (long)kv["ldo"];
     std::vector<char> out = slurp(dir + "/out0.bin");
     if (out.empty()) out.assign((size_t)rows * ldo * 2 + 256, 0);
-    if (mv_set_attn_variant((int)kv["variant"]) != 0) return 4;
     int rc;
     std::vector<std::vector<char>> keep;
     if (kv["temporal"] != 0) {

@@ -55,9 +55,21 @@ int main(int argc, char** argv) {
     d.rowbias = rowbias.empty() ? nullptr : rowbias.data();
     d.residual = residual.empty() ? nullptr : residual.data();
     d.alpha = alpha.empty() ? nullptr : (const float*)alpha.data();
-    if (mv_set_gemm_variant((int)kv["variant"]) != 0) return 4;
-    if (kv.count("tile_group")) mv_set_gemm_tile_group((int)kv["tile_group"]);
-    if (kv.count("force") && mv_set_gemm_force((int)kv["force"]) != 0) return 6;
+    d.cfg = kv.count("force") ? (int)kv["force"] : -1;   // tile configuration: travels in the descriptor
+    d.splitk = kv.count("splitk") ? (int)kv["splitk"] : 0;
+    const long need = mv_gemm_workspace_bytes(&d);
+    if (need < 0) {
+        fprintf(stderr, "mv_gemm_workspace_bytes failed: %s\n", g_err);
+        return 4;
+    }
+    std::vector<char> ws((size_t)need + 64);
+    if (need > 0) {
+        d.workspace = (void*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
+        d.workspace_bytes = need;
+    }
+    int32_t ch_cfg = -1, ch_split = 0;
+    if (mv_gemm_choice(&d, &ch_cfg, &ch_split) != 0) return 6;
+    fprintf(stderr, "choice cfg %d nsplit %d\n", ch_cfg, ch_split);
     const int rc = mv_gemm_f16(&d, nullptr);
     if (rc != 0) {
         fprintf(stderr, "mv_gemm_f16 failed (%d): %s\n", rc, g_err);

@@ -19,6 +19,8 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
   * reference_loop_utils.json / .npz  musev/utils/timesteps_util.py generate_parameters_with_timesteps (guidance schedule) and
                                 musev/utils/noise_util.py random_noise / video_fusion_noise (initial latents)
   * reference_poseguider_*.npz  musev/models/controlnet.py PoseGuider.forward (the pose conditioning of musev_referencenet_pose)
+  * reference_unet_musev_cfg2.npz / reference_unet_refnet_cfg3.npz  (``--at-size``) the same forward at the sizes of BASELINE.json
+                                configs 2 and 3: full SD-1.5 widths, B 2, T 13, 64x64 latents
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
 from __future__ import annotations
@@ -45,7 +47,7 @@ logging.disable(logging.CRITICAL)
 from oracle import unet3d  # noqa: E402
 
 # ---- the golden UNet cases (shared with the tests through golden_cases.py) ----
-from golden_cases import UNET_CASES, case_config, case_inputs, FLAVOUR_CTOR_KWARGS  # noqa: E402
+from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, case_config, case_inputs, FLAVOUR_CTOR_KWARGS  # noqa: E402
 
 
 def gen_context():
@@ -64,9 +66,11 @@ def gen_context():
     print("context:", len(table), "entries")
 
 
-def gen_unet():
+def gen_unet(cases=None):
+    import time
     from musev.models.unet_3d_condition import UNet3DConditionModel
-    for name, case in UNET_CASES.items():
+    for name, case in (UNET_CASES if cases is None else cases).items():
+        t_start = time.time()
         cfg = case_config(case)
         sd = unet3d.init_state_dict(cfg, case["weight_seed"])
         ctor = dict(FLAVOUR_CTOR_KWARGS[case["flavour"]])
@@ -83,7 +87,9 @@ def gen_unet():
                 out_cfg = model(x, t, encoder_hidden_states=ehs, return_dict=False, do_classifier_free_guidance=True, **kw)[0]
                 extra["cfg_flag_max_abs_diff"] = np.float32((out - out_cfg).abs().max().item())
         np.savez_compressed(os.path.join(HERE, f"reference_unet_{name}.npz"), out=out.numpy().astype(np.float32), **extra)
-        print("unet", name, tuple(out.shape), "absmax", out.abs().max().item(), {k: float(v) for k, v in extra.items()})
+        print("unet", name, tuple(out.shape), "absmax", out.abs().max().item(), {k: float(v) for k, v in extra.items()},
+              f"{time.time() - t_start:.0f} s", flush=True)
+        del model, sd
 
 
 def gen_ddim():
@@ -255,6 +261,9 @@ def gen_poseguider():
 
 
 if __name__ == "__main__":
+    if "--at-size" in sys.argv:  # the BASELINE-size UNet cases only (minutes of CPU, ~25 GB)
+        gen_unet(UNET_CASES_AT_SIZE)
+        sys.exit(0)
     gen_poseguider()
     gen_loop_utils()
     gen_context()

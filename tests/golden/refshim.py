@@ -542,10 +542,16 @@ def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
 def memory_efficient_attention(query, key, value, attn_bias=None, op=None, scale=None, p=0.0):
     """xformers.ops.memory_efficient_attention for the 3-D [batch*heads, tokens, dim] layout the reference uses."""
     scale = query.shape[-1] ** -0.5 if scale is None else scale
-    s = torch.bmm(query, key.transpose(1, 2)) * scale
-    if attn_bias is not None:
-        s = s + attn_bias
-    return torch.bmm(torch.softmax(s, dim=-1), value)
+    # same arithmetic per (batch*head) slice; sliced over the batch axis so that the BASELINE-size cases (208 x 4096 x 8192
+    # scores = 28 GB at once) fit the host memory
+    per = max(1, (1 << 28) // max(1, query.shape[1] * key.shape[1]))
+    outs = []
+    for b0 in range(0, query.shape[0], per):
+        s = torch.bmm(query[b0:b0 + per], key[b0:b0 + per].transpose(1, 2)) * scale
+        if attn_bias is not None:
+            s = s + (attn_bias[b0:b0 + per] if attn_bias.dim() == 3 and attn_bias.shape[0] == query.shape[0] else attn_bias)
+        outs.append(torch.bmm(torch.softmax(s, dim=-1), value[b0:b0 + per]))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
 
 def generate_sample_idxs(total, window_size, step, sample_rate=1, drop_last=False):

@@ -44,6 +44,16 @@ UNET_CASES = {
                                         input_seed=18, timestep=701, controlnet=True, pose=True),
 }
 
+# ---- BASELINE-size cases: the full SD-1.5-width model on the tensors of BASELINE.json configs 2 and 3 --
+# B = 2 (CFG), T = 13 (12 generated + 1 vision-condition frame), 64x64 latents (512x512 px).  One reference forward is
+# ~37 / ~41 TFLOP of fp32 CPU work (minutes) and needs ~25 GB, so these are generated once (make_reference_goldens.py
+# --at-size) and replayed (a) by the HIP model in `-m gpu` and (b) by the oracle only when MUSEV_GOLDEN_AT_SIZE=1.
+UNET_CASES_AT_SIZE = {
+    "musev_cfg2": dict(flavour="musev", arch={}, b=2, t=13, h=64, w=64, n_cond=1, weight_seed=8, input_seed=19, timestep=601),
+    "refnet_cfg3": dict(flavour="musev_referencenet", arch={}, b=2, t=13, h=64, w=64, n_cond=1, weight_seed=9, input_seed=20,
+                        timestep=401),
+}
+
 
 def case_config(case: dict) -> dict:
     from oracle import unet3d

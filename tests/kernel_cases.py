@@ -464,3 +464,61 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("layout_misc", case_layout_and_misc),
     ("window_loop", case_window_loop),
 ]
+
+
+# ---- BASELINE-size cases (`-m gpu` only): every (mode, M, N, K, epilogue) class of the config-2 forward at
+# its real size, so that each tile configuration the measured table / the rules select there -- the 256x320 / 256x256 8-wave
+# tiles, the 256x160 three-stage counted-wait ring of the M = 6656 level, the split-K path of the 8x8-latent level -- is checked
+# against torch on the exact grid shapes the benchmark launches; and the level-0 reference-only self-attention at Lq 4096 x
+# Lkv 8192, d = 40 (88 % of the attention FLOPs).
+def case_gemm_choice(M, N, K, mode=0):
+    """which (tile configuration, K slices) the library picks for a problem (introspection, launches nothing)"""
+    import ctypes as C
+    from musev_amd import _lib
+    d = _lib.GemmDesc()
+    d.a = d.w = d.c = 16
+    d.M, d.N, d.K, d.mode, d.cfg = M, N, K, mode, -1
+    taps = {0: 1, 1: 9, 2: 3}[mode]
+    d.c1 = d.lda = K // taps
+    d.ldc = N
+    d.stride, d.hin, d.win, d.hout, d.wout, d.t, d.hw = 1, 1, 1, 1, 1, 1, 1
+    cfg, ns = C.c_int32(), C.c_int32()
+    assert _lib.load().mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns)) == 0
+    return cfg.value, ns.value
+
+
+def case_attention_level0(frames=2):
+    """level-0 reference-only self-attention of config 2: Lq 4096, K/V = [own frame | vision-condition frame] = 8192 keys, d 40"""
+    return case_attention_self(d=40, b=1, t=frames, lq=4096, cond_idx=0, seed=64)
+
+
+AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
+    ("gemm_l0_out_res", lambda: case_gemm(M=106496, N=320, K=320, seed=200)),                    # to_out / proj_out + residual
+    ("gemm_l0_qkv", lambda: case_gemm(M=106496, N=960, K=320, epilogue=False, seed=201)),        # fused QKV
+    ("gemm_l0_ff2", lambda: case_gemm(M=106496, N=320, K=1280, seed=202)),
+    ("gemm_l0_geglu", lambda: case_gemm_geglu(M=106496, C=320)),                                 # N 2560 (packed), 256x256 tiles
+    ("gemm_l1_geglu", lambda: case_gemm_geglu(M=26624, C=640)),
+    ("gemm_l1_out_res", lambda: case_gemm(M=26624, N=640, K=640, seed=203)),
+    ("gemm_l2_out_res", lambda: case_gemm(M=6656, N=1280, K=1280, seed=204)),                    # 256x160 three-stage ring (26 x 8 blocks)
+    ("gemm_l2_qkv", lambda: case_gemm(M=6656, N=3840, K=1280, epilogue=False, seed=205)),
+    ("gemm_l2_half", lambda: case_gemm(M=3328, N=1280, K=1280, seed=206)),                       # one CFG half (two-stream default path)
+    ("gemm_l3_out_res", lambda: case_gemm(M=1664, N=1280, K=1280, seed=207)),                    # split-K rule
+    ("gemm_l3_ff2_half", lambda: case_gemm(M=832, N=1280, K=5120, seed=208)),
+    ("conv_l0", lambda: case_conv3x3(n=26, h=64, w=64, c1=320, cout=320, seed=210)),
+    ("conv_l0_two_src", lambda: case_conv3x3(n=26, h=64, w=64, c1=320, c2=320, cout=320, seed=211)),
+    ("conv_l1_down", lambda: case_conv3x3(n=26, h=64, w=64, c1=320, cout=320, stride=2, seed=212)),
+    ("conv_l1_two_src", lambda: case_conv3x3(n=26, h=32, w=32, c1=640, c2=640, cout=640, seed=213)),
+    ("conv_l1_up", lambda: case_conv3x3(n=26, h=16, w=16, c1=1280, cout=1280, upsample=True, seed=214)),
+    ("conv_l2", lambda: case_conv3x3(n=26, h=16, w=16, c1=1280, cout=1280, seed=215)),
+    ("conv_l3", lambda: case_conv3x3(n=26, h=8, w=8, c1=1280, cout=1280, seed=216)),             # M 1664, K 11520: split-K
+    ("conv_l3_half_two_src", lambda: case_conv3x3(n=13, h=8, w=8, c1=1280, c2=1280, cout=1280, seed=217)),  # M 832, K 23040
+    ("tconv_l0", lambda: case_tconv3(b=2, t=13, hw=4096, c=320, seed=220)),
+    ("tconv_l2", lambda: case_tconv3(b=2, t=13, hw=256, c=1280, seed=221)),
+    ("tconv_l3", lambda: case_tconv3(b=2, t=13, hw=64, c=1280, seed=222)),                       # M 1664, K 3840: split-K
+    ("tconv_l3_half", lambda: case_tconv3(b=1, t=13, hw=64, c=1280, seed=223)),
+    ("attention_level0", case_attention_level0),
+    ("groupnorm_l0", lambda: case_groupnorm(n=26, rows=4096, c1=320, seed=230)),
+    ("groupnorm_l0_tconv", lambda: case_groupnorm(n=2, rows=13 * 4096, c1=320, seed=231)),       # statistics over T*H*W
+    ("layernorm_l0", lambda: case_layernorm(rows=106496, c=320, seed=232)),
+    ("temporal_attention_l0", lambda: case_temporal_attention(b=2, t=13, hw=4096, d=40, seed=233)),
+]

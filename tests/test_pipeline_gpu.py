@@ -1,10 +1,11 @@
 """-m gpu: the sliding-window parallel-denoise loop on HIP kernels (musev_amd.pipelines.ParallelDenoiser) against the
 oracle loop (oracle/pipeline.py, restating pipeline_controlnet.py:1832-2156) on identical seeds.
 
-Tolerance: |delta latent|max < 1e-2 (north-star bound) over the first steps of the real 20-step DDIM schedule.  A whole
-20-step run amplifies the UNet's fp16-level prediction error (~3e-3, test_model_gpu.py) by CFG (x ~4) and by the DDIM
-recursion (L2 gain ~3.9), beyond 1e-2 for ANY fp16 implementation -- the per-step bound is the meaningful one, and the
-loop glue itself is exact (fp32; checked bit-level in kernel_cases.case_window_loop and the full-size properties below)."""
+Tolerance: |delta latent|max < 1e-2 (north-star bound): over the first steps of the real 20-step DDIM schedule on the small
+nets, over ALL steps of BASELINE config 1 (full-width model, 256x256, 4 frames, 4 DDIM steps, guidance 7.5), and -- measured,
+not asserted at 1e-2 -- over a whole 20-step run next to the drift of a plain torch-fp16 evaluation of the oracle UNet inside
+the same fp32 loop (the floor any fp16 implementation sits on).  The loop glue itself is exact (fp32; checked bit-level in
+kernel_cases.case_window_loop and the full-size properties below)."""
 import pytest
 import torch
 
@@ -92,3 +93,126 @@ def test_full_size_window_average_property():
     x = lat.clone()
     ops.cfg_ddim_step(x, acc2, cnt, 3.5, 0.5, 0.5)
     assert (x - lat).abs().max().item() < 1e-5
+
+
+def _drift(rec_a, rec_b):
+    return [(a.float().cpu() - b.float().cpu()).abs().max().item() for a, b in zip(rec_a, rec_b)]
+
+
+def test_config1_full_loop_all_steps():
+    """BASELINE.json config 1 end to end: `musev` at full SD-1.5 width, latents [1, 4, 4, 32, 32] (256x256 px, 4 frames, no
+    vision-condition frame), prompt embeddings [2, 77, 768], ALL 4 DDIM steps, guidance 7.5 -- HIP loop against
+    the oracle loop: |delta latent|max < 1e-2 after the last step, per-step drift printed."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import os
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg = unet3d.flavour_config("musev")
+    sd = unet3d.init_state_dict(cfg, 3)
+    latents = torch.randn(1, 4, 4, 32, 32, generator=torch.Generator().manual_seed(0))
+    prompt = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(1))
+    kw = dict(num_inference_steps=4, guidance_scale=7.5, motion_speed=8.0)
+    rec_o = []
+    with torch.no_grad():
+        want = opipe.denoise_loop(lambda x, t, ehs, **k: unet3d.unet3d_forward(sd, cfg, x, t, ehs, **k), latents, prompt,
+                                  record_latents=rec_o, **kw)
+    dev = torch.device("cuda", 0)
+    unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16).to(dev)
+    del sd
+    rec_h = []
+    den = ParallelDenoiser(unet)
+    got = den(latents.to(dev), prompt.to(dev), callback=lambda i, t, lat: rec_h.append(lat.clone().view(1, 4, 4, 32, 32)), **kw)
+    torch.cuda.synchronize()
+    drift = _drift(rec_h, rec_o)
+    print("config 1 per-step |delta latent|max:", ["%.2e" % d for d in drift], "| |latent|max", want.abs().max().item())
+    assert len(drift) == 4
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err < 1e-2, f"config 1: |delta latent|max = {err}, per step {drift}"
+
+
+def test_twenty_step_drift_against_fp16_torch_floor():
+    """A whole 20-step denoise (2 windows, vision-condition frame, guidance 3.5) on the 2-level SD-1.5-width net at 16x16 latents:
+    drift of the HIP loop from the fp32 oracle loop per step, next to the drift of the SAME oracle loop whose UNet is evaluated by
+    plain torch in fp16 on the GPU (weights and activations fp16: what the reference itself runs on a GPU).  The numbers replace
+    DESIGN.md section 4's former assertion; asserted: finite, and the HIP drift is not worse than 2x the torch-fp16 drift + 2e-3 at any step."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import json
+    import os
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    cfg = unet3d.flavour_config("musev", **ARCH)
+    sd = unet3d.init_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(7)
+    T, h, w = 10, 16, 16
+    latents = torch.randn(1, 4, T, h, w, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    kw = dict(num_inference_steps=20, guidance_scale=3.5, condition_latents=cond, context_frames=6, context_overlap=2, motion_speed=8.0)
+    rec32, rec16, rech = [], [], []
+    dev = torch.device("cuda", 0)
+    with torch.no_grad():
+        opipe.denoise_loop(lambda x, t, ehs, **k: unet3d.unet3d_forward(sd, cfg, x, t, ehs, **k), latents, prompt,
+                           record_latents=rec32, **kw)
+        sdh = {k: v.to(dev, torch.float16) for k, v in sd.items()}
+
+        def unet16(x, t, ehs, **k):
+            k = {n: (v.to(dev) if torch.is_tensor(v) else v) for n, v in k.items()}
+            return unet3d.unet3d_forward(sdh, cfg, x.to(dev, torch.float16), t, ehs.to(dev, torch.float16), **k).float().cpu()
+
+        opipe.denoise_loop(unet16, latents, prompt, record_latents=rec16, **kw)
+    unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+    den = ParallelDenoiser(unet, context_frames=6, context_overlap=2)
+    den(latents.to(dev), prompt.to(dev), num_inference_steps=20, guidance_scale=3.5, condition_latents=cond.to(dev), motion_speed=8.0,
+        callback=lambda i, t, lat: rech.append(lat.clone().view(1, 4, T, h, w)))
+    torch.cuda.synchronize()
+    d_hip, d_f16 = _drift(rech, rec32), _drift(rec16, rec32)
+    table = [{"step": i + 1, "hip_vs_fp32": a, "torch_fp16_vs_fp32": b} for i, (a, b) in enumerate(zip(d_hip, d_f16))]
+    print("20-step drift |delta latent|max (HIP loop | torch-fp16 UNet in the oracle loop):")
+    for r in table:
+        print("  step %2d  %.3e  %.3e" % (r["step"], r["hip_vs_fp32"], r["torch_fp16_vs_fp32"]))
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "drift_20_steps.json"), "w") as f:
+        json.dump({"net": "musev 2-level (320, 640), 16x16 latents, 10 frames, window 6 overlap 2, 20 DDIM steps, guidance 3.5",
+                   "latent_absmax": rec32[-1].abs().max().item(), "table": table}, f, indent=1)
+    assert len(d_hip) == 20 and all(map(lambda v: v == v and v < 1e3, d_hip))
+    for a, b in zip(d_hip, d_f16):
+        assert a <= 2.0 * b + 2e-3, (d_hip, d_f16)
+
+
+def test_uniform_v2_unequal_windows_on_the_gpu():
+    """`uniform_v2` (the CLI default schedule): T = 16, window 6, overlap 2 -> windows of 6, 6, 6 and a short last one; HIP loop
+    (one captured graph per window length) against the oracle loop over the first 2 steps"""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.context import prepare_global_context
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    T, win, ov = 15, 6, 2
+    wins = [c[0] for c in prepare_global_context("uniform_v2", 20, T, win, 1, ov, 1)]
+    assert len({len(x) for x in wins}) == 2, wins
+    cfg = unet3d.flavour_config("musev", **ARCH)
+    sd = unet3d.init_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(3)
+    latents = torch.randn(1, 4, T, 8, 8, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, 8, 8, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    kw = dict(num_inference_steps=20, max_steps=2, guidance_scale=3.5, motion_speed=8.0)
+    with torch.no_grad():
+        want = opipe.denoise_loop(lambda x, t, ehs, **k: unet3d.unet3d_forward(sd, cfg, x, t, ehs, **k), latents, prompt,
+                                  condition_latents=cond, context_frames=win, context_overlap=ov, context_schedule="uniform_v2", **kw)
+    dev = torch.device("cuda", 0)
+    unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+    den = ParallelDenoiser(unet, context_frames=win, context_overlap=ov, context_schedule="uniform_v2")
+    got = den(latents.to(dev), prompt.to(dev), condition_latents=cond.to(dev), **kw)
+    got2 = den(latents.to(dev), prompt.to(dev), condition_latents=cond.to(dev), **kw)   # replays the captured graphs
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2)
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err < 1e-2, f"|delta latent|max = {err}"

@@ -31,28 +31,19 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
     emu_ops.install(monkeypatch)
     monkeypatch.setattr(emu_ops, "STRICT_WIDTHS", True)
     lib = _lib.load()
-    state = {"force": -2}
-    real_force = lib.mv_set_gemm_force
 
-    class LibProxy:  # records the forced configuration, everything else is the real (host-side) library
-        def __getattr__(self, name):
-            return getattr(lib, name)
-
-        def mv_set_gemm_force(self, cfg):
-            state["force"] = cfg
-            return real_force(cfg)
-
-    monkeypatch.setattr(_lib, "load", lambda: LibProxy())
-
-    # synthetic timing model: rules = 1.0 ms; configuration 6 is 20 % faster on conv3x3 problems, configuration 21 is 10 % faster
-    # on linear problems with K <= 320, configuration 3 is 1 % faster everywhere (below the 3 % threshold: must NOT be picked)
+    # synthetic timing model: rules = 1.0 ms; configuration 6 is 20 % faster on conv3x3 problems (30 % with 4 K slices on
+    # configuration 1), configuration 13 is 10 % faster on linear problems with K <= 320, configuration 3 is 1 % faster everywhere
+    # (below the 3 % threshold: must NOT be picked)
     def fake_ms(mode, K):
-        cfg = state["force"]
+        cfg, split = ops.GEMM_CFG, ops.GEMM_SPLITK
+        if cfg == 1 and split == 4 and mode == 1:
+            return 0.7
         if cfg == 6 and mode == 1:
             return 0.8
-        if cfg == 21 and mode == 0 and K <= 320:
+        if cfg == 13 and mode == 0 and K <= 320:
             return 0.9
-        if cfg == 3:
+        if cfg == 3 and split <= 1:
             return 0.99
         return 1.0 if cfg == -2 else 1.05
 
@@ -97,14 +88,14 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
     monkeypatch.setattr(tune, "ROOT", str(tmp_path))
     monkeypatch.setattr(sys, "argv", ["gpu_gemm_tune.py", "dry", "--size", "64", "--reps", "1"])
     tune.main()
-    assert state["force"] == -1, "the tuner must leave the library on `table + rules`"
+    assert (ops.GEMM_CFG, ops.GEMM_SPLITK) == (-1, 0), "the tuner must leave the process on `table + rules`"
 
     hdr = open(tmp_path / "gpurun_out" / "dry_gemm_tuned.h").read()
-    entries = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", hdr)]
+    entries = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", hdr)]
     n_decl = int(re.search(r"kNumGemmTuned = (\d+);", hdr).group(1))
     assert n_decl == len(entries) > 0
-    assert all(c == 6 for mode, M, N, K, g, c in entries if mode == 1) and any(mode == 1 for mode, *_ in entries)
-    assert all(c == 21 for mode, M, N, K, g, c in entries if mode == 0) and all(K <= 320 for mode, M, N, K, g, c in entries if mode == 0)
+    assert all((c, sp) == (1, 4) for mode, M, N, K, g, c, sp in entries if mode == 1) and any(mode == 1 for mode, *_ in entries)
+    assert all((c, sp) == (13, 1) for mode, M, N, K, g, c, sp in entries if mode == 0) and all(K <= 320 for mode, M, N, K, g, c, sp in entries if mode == 0)
     assert not any(mode == 2 for mode, *_ in entries), "a 1 % gain is below the threshold"
     import json
     rep = json.load(open(tmp_path / "gpurun_out" / "dry_gemm_tune.json"))

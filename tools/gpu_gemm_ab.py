@@ -1,4 +1,5 @@
-"""A/B of the GEMM kernel variants on the GPU box: parity of every implicit-GEMM case per variant, then micro-benchmarks
+"""A/B of tile configurations of the implicit-GEMM kernel on the GPU box (a "variant" is a catalogue id forced through
+mv_gemm_desc.cfg; -1 = measured table + rules, -2 = rules only): parity of every implicit-GEMM case per variant, then micro-benchmarks
 at the config-2 shapes WITH the epilogues the model uses.  Prints one table; writes gpurun_out/<tag>_gemm_ab.json.
 Usage: python tools/gpu_gemm_ab.py <tag> [variants...]"""
 import json
@@ -69,14 +70,15 @@ def shapes():
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "ab"
-    variants = [int(v) for v in sys.argv[2:]] or [1, 2, 3]
+    variants = [int(v) for v in sys.argv[2:]] or [-1, -2]
     from musev_amd import _lib
     from kernel_cases import ALL_CASES
     lib = _lib.load()
     report = {"device": torch.cuda.get_device_name(0), "variants": {}}
     sh = shapes()
-    for v in variants:
-        assert lib.mv_set_gemm_variant(v) == 0
+    from musev_amd import ops as _ops
+    for v in variants:   # a "variant" is a forced catalogue id (-1 = measured table + rules, -2 = rules only)
+        _ops.GEMM_CFG = v
         rep = {"cases": {}, "bench": {}}
         for name, fn in ALL_CASES:
             if not name.startswith(("gemm", "conv3x3", "tconv3")):
@@ -96,42 +98,7 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 rep["bench"][name] = {"error": repr(ex)}
         report["variants"][str(v)] = rep
-    # ---- attention kernel variants: parity of every attention case + the reference-only self-attention shapes ----
-    from musev_amd import ops
-    report["attn"] = {}
-    # 3: default; +8: pkrtz packing of P; +16: buffer-descriptor K/V fetch; +32: K row stride DP + 16; +64: V rows unpadded
-    ATTN_VARIANTS = (3, 11, 19, 35, 67, 99, 51, 83, 115)
-    for av in ATTN_VARIANTS:
-        assert lib.mv_set_attn_variant(av) == 0
-        rep = {"cases": {}, "bench": {}}
-        for name, fn in ALL_CASES:
-            if not name.startswith("attention"):
-                continue
-            try:
-                res = fn()
-                torch.cuda.synchronize()
-            except Exception as ex:  # noqa: BLE001
-                res = {"ok": False, "error": repr(ex)}
-            rep["cases"][name] = {"ok": bool(res.get("ok")), "max_abs_err": res.get("max_abs_err"), "error": res.get("error")}
-            print(f"attn variant {av} {'PASS' if res.get('ok') else 'FAIL'} {name} err={res.get('max_abs_err')} {res.get('error', '')}", flush=True)
-        rep["all_ok"] = all(c["ok"] for c in rep["cases"].values())
-        for (lq, d) in [(4096, 40), (1024, 80)]:
-            nb, t, heads = 26, 13, 8
-            c = heads * d
-            qkv = (torch.randn(nb * lq, 3 * c, device="cuda")).half()
-            q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
-            ms = timeit(lambda: ops.attention(q, [(k, v, lq, 1, 1, 0), (k, v, lq, t, t, 0)], nb, lq, heads, d, d ** -0.5), iters=5)
-            rep["bench"][f"attn_self lq{lq} d{d}"] = {"ms": ms, "tflops": 4.0 * nb * lq * 2 * lq * c / ms / 1e9}
-            kt = torch.randn(2 * 77, 2 * c, device="cuda").half()
-            ms = timeit(lambda: ops.attention(q, [(kt[:, :c], kt[:, c:], 77, t, 1, 0)], nb, lq, heads, d, d ** -0.5), iters=5)
-            rep["bench"][f"attn_cross lq{lq} d{d}"] = {"ms": ms, "tflops": 4.0 * nb * lq * 77 * c / ms / 1e9}
-        report["attn"][str(av)] = rep
-        print(f"attn variant {av}: ok={rep['all_ok']} " + " ".join(f"{k}: {b['ms']:.3f} ms {b['tflops']:.0f} TF" for k, b in rep["bench"].items()), flush=True)
-    def _attn_ms(v):
-        return sum(b["ms"] for b in report["attn"][str(v)]["bench"].values())
-    best_attn = min((v for v in ATTN_VARIANTS if report["attn"][str(v)]["all_ok"]), key=_attn_ms, default=3)
-    report["best_attn"] = best_attn
-    lib.mv_set_attn_variant(best_attn)
+    _ops.GEMM_CFG = -1
     print(f"{'shape':44s}" + "".join(f"  v{v:>1d} TF/s   ms   " for v in variants))
     for name, _, _ in sh:
         line = f"{name:44s}"

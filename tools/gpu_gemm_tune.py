@@ -5,7 +5,7 @@
 
 Times every launch of ONE window forward of the benchmark model (config 2: B = 2, T = 13, 64x64 latents) in situ -- HIP
 events around each mv_gemm_f16 launch on the launch stream (musev_amd.ops.GEMM_PROFILE), eager launches, one stream -- once per
-catalogue configuration (mv_set_gemm_force), plus once under the built-in rules.  For every distinct problem
+catalogue configuration / split-K factor (ops.GEMM_CFG, ops.GEMM_SPLITK -> mv_gemm_desc.cfg / .splitk), plus once under the built-in rules.  For every distinct problem
 (mode, M, N, K, geglu) it keeps the fastest configuration if that beats the rules by more than --min-gain, and writes
 
     gpurun_out/<tag>_gemm_tuned.h      -> copy to musev_amd/csrc/gemm_tuned.h, rebuild (exact-match table in front of the rules)
@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--flavour", default="musev")
+    ap.add_argument("--no-split", action="store_true", help="skip the forced split-K sweeps")
     args = ap.parse_args()
     import bench
     from musev_amd import _lib, ops
@@ -70,50 +71,62 @@ def main():
         lib.mv_gemm_config_desc(i, d)
         descs.append(list(d))
     names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
-    table = {}   # key -> {"n": launches, "ms": {cfg: mean ms per launch}}
+    # (cfg, splitk) combinations: the rules (incl. the split-K rule), every catalogue entry unsplit, and 2 / 4 / 8 K slices on the
+    # tiles that make sense for the small-M, long-K problems (a forced split is clamped by the library's workspace cap, so on the
+    # large problems these runs repeat the unsplit kernel)
+    split_cfgs = [c for c in range(n_cfg) if descs[c][0] <= 128 and descs[c][1] in (128, 160) and descs[c][2] >= 4]
+    combos = [(-2, 0)] + [(c, 1) for c in range(n_cfg)] + [(c, s) for c in split_cfgs for s in (2, 4, 8)]
+    if args.no_split:
+        combos = [cs for cs in combos if cs[1] <= 1]
+    table = {}   # key -> {"n": launches, "ms": {(cfg, splitk): mean ms per launch}}
     ref_out = None
-    for cfg in [-2] + list(range(n_cfg)):
-        assert lib.mv_set_gemm_force(cfg) == 0
+    for cfg, splitk in combos:
+        ops.GEMM_CFG, ops.GEMM_SPLITK = cfg, splitk   # the choice travels in every call's descriptor (the library keeps no state)
         out = forward()   # warm-up (packed weights, caches, code objects)
         torch.cuda.synchronize()
         if ref_out is None:
             ref_out = out.clone()
-        elif not torch.equal(out, ref_out):   # every configuration reduces in the same order: results must not move
-            print(f"WARNING: configuration {cfg} changed the forward's output by {(out - ref_out).abs().max().item():.3e}", flush=True)
+        elif splitk <= 1 and not torch.equal(out, ref_out) and cfg != -2:
+            # unsplit configurations reduce over K in the same order: results must not move (a split changes the fp32 order)
+            print(f"NOTE: configuration {cfg} changed the forward's output by {(out - ref_out).abs().max().item():.3e} vs the rules "
+                  f"(expected only where the rules split K)", flush=True)
         ops.GEMM_PROFILE = []
         for _ in range(args.reps):
             forward()
         torch.cuda.synchronize()
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         acc = {}
-        for mode, M, N, K, geglu, e0, e1, _ in prof:
+        for rec in prof:
+            mode, M, N, K, geglu, e0, e1 = rec[:7]
             key = (mode, M, N, K, geglu)
             a = acc.setdefault(key, [0.0, 0])
             a[0] += e0.elapsed_time(e1)
             a[1] += 1
         for key, (ms, n) in acc.items():
             ent = table.setdefault(key, {"n": n // args.reps, "ms": {}})
-            ent["ms"][cfg] = ms / n
+            ent["ms"][(cfg, splitk)] = ms / n
         tot = sum(ms for ms, _ in acc.values()) / args.reps
-        label = "rules" if cfg == -2 else f"cfg {cfg:2d} {descs[cfg][0]}x{descs[cfg][1]} {descs[cfg][2]}w BK{descs[cfg][3]}x{descs[cfg][4]}"
-        print(f"{label:34s} GEMM family {tot:7.2f} ms / forward", flush=True)
-    lib.mv_set_gemm_force(-1)
+        label = "rules" if cfg == -2 else f"cfg {cfg:2d} {descs[cfg][0]}x{descs[cfg][1]} {descs[cfg][2]}w x{descs[cfg][4]} splitk {splitk}"
+        print(f"{label:40s} GEMM family {tot:7.2f} ms / forward", flush=True)
+    ops.GEMM_CFG, ops.GEMM_SPLITK = -1, 0
 
     rules_total = tuned_total = 0.0
     entries, report = [], []
-    for key, ent in sorted(table.items(), key=lambda kv: -kv[1]["ms"].get(-2, 0.0) * kv[1]["n"]):
-        base = ent["ms"][-2]
-        best = min((c for c in ent["ms"] if c >= 0), key=lambda c: ent["ms"][c])
+    for key, ent in sorted(table.items(), key=lambda kv: -kv[1]["ms"].get((-2, 0), 0.0) * kv[1]["n"]):
+        base = ent["ms"][(-2, 0)]
+        # ties (a clamped split repeats the unsplit kernel) go to the smaller split factor
+        best = min((c for c in ent["ms"] if c[0] >= 0), key=lambda c: (ent["ms"][c], c[1]))
         pick = best if ent["ms"][best] < (1.0 - args.min_gain) * base else None
         rules_total += base * ent["n"]
         tuned_total += (ent["ms"][pick] if pick is not None else base) * ent["n"]
         mode, M, N, K, geglu = key
         flops = 2.0 * M * N * K
         report.append({"mode": names[mode], "M": M, "N": N, "K": K, "geglu": geglu, "launches": ent["n"], "rules_ms": base,
-                       "rules_tflops": flops / base / 1e9, "best_cfg": best, "best_ms": ent["ms"][best],
-                       "best_tflops": flops / ent["ms"][best] / 1e9, "picked": pick, "ms": {str(c): v for c, v in ent["ms"].items()}})
+                       "rules_tflops": flops / base / 1e9, "best_cfg": best[0], "best_splitk": best[1], "best_ms": ent["ms"][best],
+                       "best_tflops": flops / ent["ms"][best] / 1e9, "picked": list(pick) if pick else None,
+                       "ms": {f"{c}/{s}": v for (c, s), v in ent["ms"].items()}})
         if pick is not None:
-            entries.append((mode, M, N, K, geglu, pick, base, ent["ms"][pick]))
+            entries.append((mode, M, N, K, geglu, pick[0], pick[1], base, ent["ms"][pick]))
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"{args.tag}_gemm_tune.json"), "w") as f:
@@ -123,16 +136,17 @@ def main():
              "// GENERATED by tools/gpu_gemm_tune.py (do not edit by hand); ids refer to MV_GEMM_CFGS in gemm.hip.",
              f"// {torch.cuda.get_device_name(0)}; {args.flavour}, {args.size}x{args.size}, T = 13, one batch-1 + one batch-2 forward; rules "
              f"{rules_total:.2f} ms -> table {tuned_total:.2f} ms of GEMM time.",
-             "// {mode, M, N, K, geglu, cfg}", "static const GemmTuned kGemmTuned[] = {"]
-    for mode, M, N, K, geglu, pick, base, best in entries:
-        lines.append(f"    {{{mode}, {M}, {N}, {K}, {geglu}, {pick}}},  // {names[mode]}: {base * 1e3:.0f} -> {best * 1e3:.0f} us")
-    lines += ["    {-1, 0, 0, 0, 0, -1},  // sentinel (never matches)", "};", f"static const int kNumGemmTuned = {len(entries)};", ""]
+             "// {mode, M, N, K, geglu, cfg, nsplit}   nsplit: K slices (clamped by the workspace cap); 0 = split-K rule",
+             "static const GemmTuned kGemmTuned[] = {"]
+    for mode, M, N, K, geglu, pick, split, base, best in entries:
+        lines.append(f"    {{{mode}, {M}, {N}, {K}, {geglu}, {pick}, {split}}},  // {names[mode]}: {base * 1e3:.0f} -> {best * 1e3:.0f} us")
+    lines += ["    {-1, 0, 0, 0, 0, -1, 0},  // sentinel (never matches)", "};", f"static const int kNumGemmTuned = {len(entries)};", ""]
     with open(os.path.join(out_dir, f"{args.tag}_gemm_tuned.h"), "w") as f:
         f.write("\n".join(lines))
     print(f"rules {rules_total:.2f} ms -> tuned {tuned_total:.2f} ms per forward over {len(table)} problems, {len(entries)} table entries")
-    for r in report[:16]:
+    for r in report[:24]:
         print(f"{r['mode']:8s} M{r['M']:<7d} N{r['N']:<6d} K{r['K']:<6d} g{r['geglu']} x{r['launches']:<3d} rules {r['rules_ms'] * 1e3:6.0f} us "
-              f"{r['rules_tflops']:5.0f} TF | best cfg {r['best_cfg']:2d} {r['best_ms'] * 1e3:6.0f} us {r['best_tflops']:5.0f} TF")
+              f"{r['rules_tflops']:5.0f} TF | best cfg {r['best_cfg']:2d}/{r['best_splitk']} {r['best_ms'] * 1e3:6.0f} us {r['best_tflops']:5.0f} TF")
 
 
 if __name__ == "__main__":
