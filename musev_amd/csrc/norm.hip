@@ -1,14 +1,16 @@
 // norm.hip -- GroupNorm(32)(+SiLU) over channels-last tensors and LayerNorm over the channel dim (gfx950).
 //
 // Both are HBM-bound streaming kernels: 16-byte (8 x fp16) vector loads, fp32 statistics, 64-lane
-// shuffle reductions.  GroupNorm runs as three launches on one stream:
-//   1. gn_stats    : per (item, row-split) per-CHANNEL partial sum / sum-of-squares (fp32).  Per-channel, not
-//                    per-group, because on the up path the input is the channel concat of two tensors and
-//                    groups of 30 / 60 channels straddle both the 8-channel vectors and the concat seam.
-//   2. gn_finalize : per (item, group): fold splits and the group's channels (double), emit per-channel
-//                    scale = rstd*gamma and shift = beta - mean*rstd*gamma.
-//   3. gn_apply    : y = silu?(x*scale + shift), writing the concatenated [rows][c1+c2] tensor (this is the only
-//                    place the up-path concat is ever materialised, already normalised).
+// shuffle reductions.  GroupNorm runs as two launches on one stream:
+//   1. gn_stats : per (item, row-split): per-CHANNEL sum / sum-of-squares (fp32; per-channel first because on the up path the
+//                 input is the channel concat of two tensors and groups of 30 / 60 channels straddle both the 8-channel vectors
+//                 and the concat seam), folded to per-GROUP partials [item][split][group][2] inside the block.  The block that
+//                 arrives LAST for its item (ticket counter, agent-scope release / acquire as cdna_hip_programming.md G16) folds
+//                 the item's splits in split order, in double -- the result does not depend on which block is last -- and emits
+//                 mean / rstd per (item, group).  (Round 1 ran this fold as a third launch: 166 launches and 1.4 ms per step,
+//                 most of it strided reads of per-channel partials.)
+//   2. gn_apply : y = silu?((x - mean) * rstd * gamma + beta), writing the concatenated [rows][c1+c2] tensor (this is the only
+//                 place the up-path concat is ever materialised, already normalised).
 // For TemporalConvLayer / TransformerTemporalModel the statistics span (T, H, W): the caller passes
 // n_items = B and rows = T*H*W, which is contiguous in the [B,T,H,W,C] layout.
 #include "common.h"
@@ -23,8 +25,9 @@ struct GnArgs {
     int nsplit;
     int oc;  // (c1+c2)/8 channel octets
     int rl;  // row lanes per block
-    float* partial;      // [item][split][2][C]
-    float* scale_shift;  // [item][2][C]
+    float* partial;      // [item][split][group][2]
+    float* stat;         // [item][group][2] = mean, rstd
+    int* counter;        // [item] arrival tickets: zero on entry, zero on exit
     const half_t* gamma;
     const half_t* beta;
     half_t* y;
@@ -86,8 +89,8 @@ __global__ void gn_stats_kernel(const GnArgs a) {
         mine[2 * j + 1] = ss[j];
     }
     __syncthreads();
+    // per-channel totals of this block (row lanes folded in lane order), parked in row lane 0's slots
     if (rl == 0) {
-        float* out = a.partial + (item * a.nsplit + blockIdx.x) * 2 * C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float ts = 0.f, tss = 0.f;
@@ -96,59 +99,67 @@ __global__ void gn_stats_kernel(const GnArgs a) {
                 ts += q[0];
                 tss += q[1];
             }
-            out[o * 8 + j] = ts;
-            out[C + o * 8 + j] = tss;
+            red[(o * 8 + j) * 2] = ts;   // the k = 0 slot of this very thread: read above, written only here
+            red[(o * 8 + j) * 2 + 1] = tss;
         }
     }
-}
-
-// one block per (item, group): fold the row-split partials of the group's channels (fixed order -> deterministic),
-// reduce across the block in double, emit scale/shift for the group's channels.  (A single block per item folding
-// nsplit x C partials serially was 24 % of the whole UNet step: 1024 splits x 2 items at the temporal layers.)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a) {
-    __shared__ double red[2][4];
-    __shared__ float stat[2];
-    const int C = a.oc * 8;
-    const long item = blockIdx.y;
-    const int gI = blockIdx.x;
+    __syncthreads();
+    // per-group partials of this (item, split): channels of a group in ascending order
     const int cpg = C / a.groups;
-    const int c0 = gI * cpg;
-    const float* pp = a.partial + item * a.nsplit * 2 * C;
-    double ts = 0.0, tss = 0.0;
-    const int total = a.nsplit * cpg;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int k = i / cpg, c = c0 + (i - k * cpg);
-        ts += (double)pp[(long)k * 2 * C + c];
-        tss += (double)pp[(long)k * 2 * C + C + c];
+    float* gp = a.partial + (item * a.nsplit + blockIdx.x) * a.groups * 2;
+    for (int gI = threadIdx.x; gI < a.groups; gI += blockDim.x) {
+        float ts = 0.f, tss = 0.f;
+        for (int c = gI * cpg; c < (gI + 1) * cpg; ++c) {
+            ts += red[c * 2];
+            tss += red[c * 2 + 1];
+        }
+        gp[gI * 2] = ts;
+        gp[gI * 2 + 1] = tss;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ts += __shfl_xor(ts, o, 64);
-        tss += __shfl_xor(tss, o, 64);
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        red[0][wave] = ts;
-        red[1][wave] = tss;
-    }
+    // ---- last-arriver fold (cdna_hip_programming.md Guideline 16, counter form): every storing wave drains its stores, one
+    // lane releases at agent scope and takes a ticket; the block that draws nsplit - 1 acquires and folds ----
+    int* flag = reinterpret_cast<int*>(red + (long)a.rl * C * 2);  // one word behind the fold area (same LDS object)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        const double s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(a.counter + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == a.nsplit - 1);
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // fold the item's splits: thread (part, g) sums splits part, part + P, ... in double; parts are then added in part order
+    double* dred = reinterpret_cast<double*>(red);  // [P][groups][2] doubles: P * groups <= blockDim threads, 16 B each <= the fold area
+    const int P = blockDim.x / a.groups;            // >= 1 (checked on the host)
+    const int gI = threadIdx.x % a.groups, part = threadIdx.x / a.groups;
+    if (part < P) {
+        double ts = 0.0, tss = 0.0;
+        const float* pp = a.partial + item * a.nsplit * a.groups * 2 + gI * 2;
+        for (int k = part; k < a.nsplit; k += P) {
+            ts += (double)pp[(long)k * a.groups * 2];
+            tss += (double)pp[(long)k * a.groups * 2 + 1];
+        }
+        dred[(part * a.groups + gI) * 2] = ts;
+        dred[(part * a.groups + gI) * 2 + 1] = tss;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.groups) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < P; ++k) {
+            s1 += dred[(k * a.groups + threadIdx.x) * 2];
+            s2 += dred[(k * a.groups + threadIdx.x) * 2 + 1];
+        }
         const double n = (double)cpg * (double)a.rows;
         const double mean = s1 / n;
         double var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        stat[0] = (float)mean;
-        stat[1] = (float)(1.0 / sqrt(var + (double)a.eps));
+        a.stat[(item * a.groups + threadIdx.x) * 2] = (float)mean;
+        a.stat[(item * a.groups + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
-    __syncthreads();
-    const float mean = stat[0], rstd = stat[1];
-    for (int c = c0 + threadIdx.x; c < c0 + cpg; c += 256) {
-        const float sc = rstd * (float)a.gamma[c];
-        a.scale_shift[item * 2 * C + c] = sc;
-        a.scale_shift[item * 2 * C + C + c] = (float)a.beta[c] - mean * sc;
-    }
+    if (threadIdx.x == 0) a.counter[item] = 0;  // the next call on this stream finds it zero
 }
 
 __global__ void gn_apply_kernel(const GnArgs a) {
@@ -159,11 +170,16 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     const long r0 = (long)blockIdx.x * per;
     const long r1 = (r0 + per < a.rows) ? r0 + per : a.rows;
     float sc[8], sh[8];
-    const float* ssp = a.scale_shift + item * 2 * C + o * 8;
+    {
+        const int cpg = C / a.groups;
+        const half8v gm = *reinterpret_cast<const half8v*>(a.gamma + o * 8);
+        const half8v bt = *reinterpret_cast<const half8v*>(a.beta + o * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sc[j] = ssp[j];
-        sh[j] = ssp[C + j];
+        for (int j = 0; j < 8; ++j) {
+            const float* st = a.stat + (item * a.groups + (o * 8 + j) / cpg) * 2;  // groups of 30 / 60 channels straddle octets
+            sc[j] = st[1] * (float)gm[j];
+            sh[j] = (float)bt[j] - st[0] * sc[j];
+        }
     }
     auto norm = [&](const half8v& v) __attribute__((always_inline)) {
         half8v w;
@@ -267,36 +283,40 @@ extern "C" int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, in
     return (int32_t)want;
 }
 
-extern "C" int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t c, int32_t nsplit) {
-    return n_items * (int64_t)nsplit * 2 * c;
+extern "C" int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_groups, int32_t nsplit) {
+    return n_items * (int64_t)nsplit * 2 * num_groups;
 }
 
 extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                                 int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
                                 const void* beta, int32_t silu, void* y, int32_t ldy, float* partial, int32_t nsplit,
-                                float* scale_shift, void* stream) {
-    MV_REQUIRE(x1 && y && gamma && beta && partial && scale_shift, "mv_groupnorm_f16: null pointer");
+                                float* stat, int32_t* counters, void* stream) {
+    MV_REQUIRE(x1 && y && gamma && beta && partial && stat && counters, "mv_groupnorm_f16: null pointer");
     if (!x2) c2 = 0;
     const int C = c1 + c2;
     MV_REQUIRE(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "mv_groupnorm_f16: channels must be multiples of 8 (c1=%d c2=%d)", c1, c2);
     MV_REQUIRE(num_groups > 0 && C % num_groups == 0, "mv_groupnorm_f16: C=%d not divisible by groups=%d", C, num_groups);
     MV_REQUIRE(ld1 % 8 == 0 && (c2 == 0 || ld2 % 8 == 0) && ldy % 8 == 0, "mv_groupnorm_f16: leading dims must be multiples of 8");
     MV_REQUIRE(n_items > 0 && rows > 0 && nsplit > 0 && nsplit <= 65535 && n_items <= 65535, "mv_groupnorm_f16: bad sizes");
+    MV_REQUIRE((reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0,
+               "mv_groupnorm_f16: gamma / beta must be 16-byte aligned");
     const int oc = C / 8;
     MV_REQUIRE(oc <= 1024, "mv_groupnorm_f16: C=%d too large", C);
     int rl = 256 / oc;
     if (rl < 1) rl = 1;
+    const int bs = oc * rl;
+    MV_REQUIRE(bs >= num_groups, "mv_groupnorm_f16: C=%d too small for %d groups", C, num_groups);
     GnArgs a;
     a.x1 = (const half_t*)x1; a.x2 = (const half_t*)x2; a.c1 = c1; a.c2 = c2; a.ld1 = ld1; a.ld2 = ld2;
-    a.rows = rows; a.nsplit = nsplit; a.oc = oc; a.rl = rl; a.partial = partial; a.scale_shift = scale_shift;
+    a.rows = rows; a.nsplit = nsplit; a.oc = oc; a.rl = rl; a.partial = partial; a.stat = stat; a.counter = counters;
     a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta; a.y = (half_t*)y; a.ldy = ldy; a.silu = silu;
     a.groups = num_groups; a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
-    const int bs = oc * rl;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), (size_t)bs * 16 * sizeof(float), s, a);
+    // LDS: [rl][C][2] floats = 16 bytes per thread for the row-lane fold (reused as [P][groups][2] doubles by the last
+    // arriver: P * groups <= bs threads x 16 bytes) + the "I am last" word behind it (ONE LDS object, G16 / section 5 trap (a))
+    const size_t lds = (size_t)bs * 16 * sizeof(float) + 16;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), lds, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(stats)");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)num_groups, (unsigned)n_items), dim3(256), 0, s, a);
-    MV_CHECK_LAUNCH("mv_groupnorm_f16(finalize)");
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(apply)");
     return MV_OK;

