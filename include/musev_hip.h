@@ -106,16 +106,14 @@ int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int
  *   TemporalConvLayer conv*[0] (resnet.py:57-75; statistics span T*H*W: pass rows = T*H*W, groups_n = B),
  *   conv_norm_out (unet_3d_condition.py:562-568).
  * x: [n_items][rows][c1] (+ optional second source [n_items][rows][c2], channel-concatenated),
- * y: [n_items][rows][c1+c2].  Two launches: statistics (per-split group partials + a last-arriver fold), apply.
- * partial: fp32 scratch [n_items][nsplit][num_groups][2]; stat: fp32 scratch [n_items][num_groups][2] (mean, rstd);
- * counters: int32 [n_items] arrival tickets -- ZERO on entry, left zero on exit; calls that may run concurrently (different
- * streams) need distinct counter arrays.  gamma / beta 16-byte aligned.
+ * y: [n_items][rows][c1+c2].  Three launches: statistics (per-split group partials), fold, apply.
+ * partial: fp32 scratch [n_items][nsplit][num_groups][2]; stat: fp32 scratch [n_items][num_groups][2] (mean, rstd).
+ * gamma / beta 16-byte aligned.
  */
 int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                      int64_t n_items, int64_t rows, int32_t num_groups, float eps,
                      const void* gamma, const void* beta, int32_t silu,
-                     void* y, int32_t ldy, float* partial, int32_t nsplit, float* stat, int32_t* counters,
-                     void* stream);
+                     void* y, int32_t ldy, float* partial, int32_t nsplit, float* stat, void* stream);
 /* scratch size (in floats) of `partial` for the call above */
 int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_groups, int32_t nsplit);
 int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c);

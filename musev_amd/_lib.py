@@ -67,7 +67,7 @@ SIGNATURES = {
     "mv_gemm_config_desc": (_i32, [_i32, _vp]),
     "mv_gemm_tile_order": (_i32, [_i32, _i32, _i32, _vp, _vp]),
     "mv_groupnorm_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
-                                _vp, _i32, _vp, _vp, _vp]),
+                                _vp, _i32, _vp, _vp]),
     "mv_groupnorm_partial_floats": (_i64, [_i64, _i32, _i32]),
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),

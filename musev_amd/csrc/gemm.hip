@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     constexpr int AI = (CA + NW - 1) / NW, BI = (CB + NW - 1) / NW;
     const GemmArgs& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NST = (SCHED == 3) ? 3 : 2;  // LDS stages
+    constexpr int NST = (SCHED == 3) ? 3 : 2;  // LDS stages (SCHED 8 / 9: the two-tile ring of the ping-pong schedule)
     half_t* sA = reinterpret_cast<half_t*>(smem);  // [NST][BM*BK]
     half_t* sB = sA + NST * BM * BK;                // [NST][BN*BK]
 
@@ -471,6 +471,75 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             mma_stage(cur);
             cur = (cur == NST - 1) ? 0 : cur + 1;
         }
+    } else if constexpr (SCHED == 8 || SCHED == 9) {
+        // PING-PONG schedule for the one-block-per-CU 8-wave tiles (WGM == 2): the two wave groups (wm = 0 / 1; every SIMD
+        // hosts one wave of each) run the same slot sequence one slot apart, so that in every slot one group is in a pure-MFMA
+        // "C" slot (operands in registers, s_setprio 1) while the other is in an "L" slot (ds_read_b128 of its next 32-deep
+        // fragment set, LDS-DMA issue, address arithmetic): the SIMD's matrix pipe always has a wave to run
+        // (cdna_hip_programming.md T3 / T5: phase-split waves + priority).  Per K tile and wave: L0 C0 L1 C1, one raw s_barrier
+        // per slot; the lockstep schedules above stall every wave at once on their fragment reads and on the barrier drain.
+        //   slot 4t   : A L0(t)               slot 4t+1 : A C0(t)  B L0(t)
+        //   slot 4t+2 : A L1(t)  B C0(t)      slot 4t+3 : A C1(t)  B L1(t)         slot 4t+4 : A L0(t+1)  B C1(t)
+        // LDS ring of two K tiles: tile t+1 goes into the buffer tile t-1 left; its last readers are B's L1(t-1) in slot 4t-1,
+        // so both groups issue their LDS-DMA pieces at the head of their L0(t) (slots 4t / 4t+1).  Tile t+1 is first read in
+        // slot 4t+4: every wave waits for its own pieces before the barrier that ends slot 4t+3 -- the end of C1(t) for group A,
+        // the end of L1(t) for group B (2.5 - 3.5 slots after the issue: nothing younger is in flight, so vmcnt(0) is the
+        // counted wait).  A ds_read must have EXECUTED before the barrier that hands its buffer on: lgkmcnt(0) closes every L slot.
+        static_assert(WGM == 2 && NST == 2, "ping-pong needs two wave groups and the two-tile ring");
+        const int grp = wm;
+        half8v af[TM], wf[TN];
+        auto read_frags = [&](int st, int kk) __attribute__((always_inline)) {
+            const half_t* cA = sA + st * (BM * BK);
+            const half_t* cB = sB + st * (BN * BK);
+            const int slot_off = (((kk * 4 + g) ^ swz) << 3);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
+        };
+        auto mma_frags = [&]() __attribute__((always_inline)) {
+            if (SCHED == 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            if (SCHED == 8) __builtin_amdgcn_s_setprio(0);
+        };
+        auto end_slot = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        prepare();
+        issue(0, kt0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        end_slot();                   // tile kt0 is visible to every wave
+        if (grp == 1) end_slot();     // the trailing group runs one slot behind
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            const bool more = kt + 1 < nk;
+            // ---- L0 ----
+            if (more) {
+                prepare();
+                issue(cur ^ 1, kt + 1);
+            }
+            read_frags(cur, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            end_slot();
+            // ---- C0 ----
+            mma_frags();
+            end_slot();
+            // ---- L1 ----
+            read_frags(cur, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grp == 1 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            end_slot();
+            // ---- C1 ----
+            mma_frags();
+            if (grp == 0 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            end_slot();
+        }
+        if (grp == 0) end_slot();     // pairs with the trailing group's last slot (barrier counts must match)
     } else {
         prepare();
         issue(0, kt0);
@@ -614,8 +683,10 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     X(12, 2, 5, 4, 2, 3) /* 128x160, 8 waves, 3 stages  */ X(13, 2, 5, 2, 1, 0)  /* 64x80, 2 waves (small grids) */    \
     X(14, 2, 5, 1, 2, 0) /* 32x160, 2 waves             */ X(15, 2, 5, 4, 2, 0)  /* 128x160, 8 waves of 32x80  */      \
     X(16, 2, 4, 4, 2, 0) /* 128x128, 8 waves of 32x64   */ X(17, 2, 5, 2, 2, 3)  /* 64x160, 4 waves, 3 stages  */      \
-    X(18, 4, 5, 2, 2, 3) /* 128x160, 4 waves, 3 stages  */
-constexpr int kNumGemmCfgs = 19;
+    X(18, 4, 5, 2, 2, 3) /* 128x160, 4 waves, 3 stages  */ X(19, 8, 4, 2, 4, 8)  /* 256x256, 8 waves, ping-pong */     \
+    X(20, 8, 5, 2, 4, 8) /* 256x320, 8 waves, ping-pong */ X(21, 8, 4, 2, 4, 9)  /* 256x256 ping-pong, no setprio (A/B) */ \
+    X(22, 8, 5, 2, 4, 9) /* 256x320 ping-pong, no setprio (A/B) */
+constexpr int kNumGemmCfgs = 23;
 struct GemmCfgDesc { int tm, tn, wgm, wgn, sched; };
 constexpr GemmCfgDesc kGemmCfgs[kNumGemmCfgs] = {
 #define MV_X(id, tm, tn, wgm, wgn, sched) {tm, tn, wgm, wgn, sched},

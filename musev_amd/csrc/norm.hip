@@ -1,16 +1,13 @@
 // norm.hip -- GroupNorm(32)(+SiLU) over channels-last tensors and LayerNorm over the channel dim (gfx950).
 //
 // Both are HBM-bound streaming kernels: 16-byte (8 x fp16) vector loads, fp32 statistics, 64-lane
-// shuffle reductions.  GroupNorm runs as two launches on one stream:
-//   1. gn_stats : per (item, row-split): per-CHANNEL sum / sum-of-squares (fp32; per-channel first because on the up path the
-//                 input is the channel concat of two tensors and groups of 30 / 60 channels straddle both the 8-channel vectors
-//                 and the concat seam), folded to per-GROUP partials [item][split][group][2] inside the block.  The block that
-//                 arrives LAST for its item (ticket counter, agent-scope release / acquire as cdna_hip_programming.md G16) folds
-//                 the item's splits in split order, in double -- the result does not depend on which block is last -- and emits
-//                 mean / rstd per (item, group).  (Round 1 ran this fold as a third launch: 166 launches and 1.4 ms per step,
-//                 most of it strided reads of per-channel partials.)
-//   2. gn_apply : y = silu?((x - mean) * rstd * gamma + beta), writing the concatenated [rows][c1+c2] tensor (this is the only
-//                 place the up-path concat is ever materialised, already normalised).
+// shuffle reductions.  GroupNorm runs as three launches on one stream:
+//   1. gn_stats    : per (item, row-split): per-CHANNEL sum / sum-of-squares (fp32; per-channel first because on the up path the
+//                    input is the channel concat of two tensors and groups of 30 / 60 channels straddle both the 8-channel
+//                    vectors and the concat seam), folded to per-GROUP partials [item][split][group][2] inside the block.
+//   2. gn_finalize : one wave per (item, group): fold the splits (double, fixed order), emit mean / rstd.
+//   3. gn_apply    : y = silu?((x - mean) * rstd * gamma + beta), writing the concatenated [rows][c1+c2] tensor (this is the
+//                    only place the up-path concat is ever materialised, already normalised).
 // For TemporalConvLayer / TransformerTemporalModel the statistics span (T, H, W): the caller passes
 // n_items = B and rows = T*H*W, which is contiguous in the [B,T,H,W,C] layout.
 #include "common.h"
@@ -27,7 +24,7 @@ struct GnArgs {
     int rl;  // row lanes per block
     float* partial;      // [item][split][group][2]
     float* stat;         // [item][group][2] = mean, rstd
-    int* counter;        // [item] arrival tickets: zero on entry, zero on exit
+    long n_items;
     const half_t* gamma;
     const half_t* beta;
     half_t* y;
@@ -116,50 +113,41 @@ __global__ void gn_stats_kernel(const GnArgs a) {
         gp[gI * 2] = ts;
         gp[gI * 2 + 1] = tss;
     }
-    // ---- last-arriver fold (cdna_hip_programming.md Guideline 16, counter form): every storing wave drains its stores, one
-    // lane releases at agent scope and takes a ticket; the block that draws nsplit - 1 acquires and folds ----
-    int* flag = reinterpret_cast<int*>(red + (long)a.rl * C * 2);  // one word behind the fold area (same LDS object)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = __hip_atomic_fetch_add(a.counter + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == a.nsplit - 1);
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *flag = last;
+}
+
+// one wave per (item, group): fold the splits' group partials in split order (lanes take splits lane, lane + 64, ...; the lane
+// totals are then added by a fixed xor tree), in double; emit mean / rstd.  Contiguous 8-byte reads of [split][group][2] -- the
+// round-1 form folded per-CHANNEL partials (strided 4-byte reads of a 40x larger array) and cost 8-10 us per launch.
+// (A last-arriving-block fold inside gn_stats was measured in round 2: the agent-scope release each block needs writes back
+// its XCD's dirty L2 lines -- the previous kernels' activations -- and doubled the statistics kernel: 11.4 -> 25.4 us.)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (item, group) of this wave
+    const long total = (long)a.groups * a.n_items;
+    if (pair >= total) return;
+    const long item = pair / a.groups;
+    const int gI = (int)(pair - item * a.groups);
+    const float* pp = a.partial + item * a.nsplit * a.groups * 2 + gI * 2;
+    double ts = 0.0, tss = 0.0;
+    for (int k = lane; k < a.nsplit; k += 64) {
+        const float* v = pp + (long)k * a.groups * 2;
+        ts += (double)v[0];
+        tss += (double)v[1];
     }
-    __syncthreads();
-    if (!*flag) return;
-    // fold the item's splits: thread (part, g) sums splits part, part + P, ... in double; parts are then added in part order
-    double* dred = reinterpret_cast<double*>(red);  // [P][groups][2] doubles: P * groups <= blockDim threads, 16 B each <= the fold area
-    const int P = blockDim.x / a.groups;            // >= 1 (checked on the host)
-    const int gI = threadIdx.x % a.groups, part = threadIdx.x / a.groups;
-    if (part < P) {
-        double ts = 0.0, tss = 0.0;
-        const float* pp = a.partial + item * a.nsplit * a.groups * 2 + gI * 2;
-        for (int k = part; k < a.nsplit; k += P) {
-            ts += (double)pp[(long)k * a.groups * 2];
-            tss += (double)pp[(long)k * a.groups * 2 + 1];
-        }
-        dred[(part * a.groups + gI) * 2] = ts;
-        dred[(part * a.groups + gI) * 2 + 1] = tss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ts += __shfl_xor(ts, o, 64);
+        tss += __shfl_xor(tss, o, 64);
     }
-    __syncthreads();
-    if ((int)threadIdx.x < a.groups) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < P; ++k) {
-            s1 += dred[(k * a.groups + threadIdx.x) * 2];
-            s2 += dred[(k * a.groups + threadIdx.x) * 2 + 1];
-        }
+    if (lane == 0) {
+        const int cpg = a.oc * 8 / a.groups;
         const double n = (double)cpg * (double)a.rows;
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
+        const double mean = ts / n;
+        double var = tss / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        a.stat[(item * a.groups + threadIdx.x) * 2] = (float)mean;
-        a.stat[(item * a.groups + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+        a.stat[(item * a.groups + gI) * 2] = (float)mean;
+        a.stat[(item * a.groups + gI) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
-    if (threadIdx.x == 0) a.counter[item] = 0;  // the next call on this stream finds it zero
 }
 
 __global__ void gn_apply_kernel(const GnArgs a) {
@@ -290,8 +278,8 @@ extern "C" int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_grou
 extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                                 int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
                                 const void* beta, int32_t silu, void* y, int32_t ldy, float* partial, int32_t nsplit,
-                                float* stat, int32_t* counters, void* stream) {
-    MV_REQUIRE(x1 && y && gamma && beta && partial && stat && counters, "mv_groupnorm_f16: null pointer");
+                                float* stat, void* stream) {
+    MV_REQUIRE(x1 && y && gamma && beta && partial && stat, "mv_groupnorm_f16: null pointer");
     if (!x2) c2 = 0;
     const int C = c1 + c2;
     MV_REQUIRE(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "mv_groupnorm_f16: channels must be multiples of 8 (c1=%d c2=%d)", c1, c2);
@@ -308,15 +296,16 @@ extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int3
     MV_REQUIRE(bs >= num_groups, "mv_groupnorm_f16: C=%d too small for %d groups", C, num_groups);
     GnArgs a;
     a.x1 = (const half_t*)x1; a.x2 = (const half_t*)x2; a.c1 = c1; a.c2 = c2; a.ld1 = ld1; a.ld2 = ld2;
-    a.rows = rows; a.nsplit = nsplit; a.oc = oc; a.rl = rl; a.partial = partial; a.stat = stat; a.counter = counters;
+    a.rows = rows; a.nsplit = nsplit; a.oc = oc; a.rl = rl; a.partial = partial; a.stat = stat; a.n_items = n_items;
     a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta; a.y = (half_t*)y; a.ldy = ldy; a.silu = silu;
     a.groups = num_groups; a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
-    // LDS: [rl][C][2] floats = 16 bytes per thread for the row-lane fold (reused as [P][groups][2] doubles by the last
-    // arriver: P * groups <= bs threads x 16 bytes) + the "I am last" word behind it (ONE LDS object, G16 / section 5 trap (a))
-    const size_t lds = (size_t)bs * 16 * sizeof(float) + 16;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), lds, s, a);
+    // LDS: [rl][C][2] floats = 64 bytes per thread for the row-lane fold
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), (size_t)bs * 16 * sizeof(float), s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(stats)");
+    const long pairs = (long)num_groups * n_items;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a);
+    MV_CHECK_LAUNCH("mv_groupnorm_f16(finalize)");
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(apply)");
     return MV_OK;

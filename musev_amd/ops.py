@@ -244,23 +244,8 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
     o = _out(out, n_items * rows, c, x)
     check(lib.mv_groupnorm_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
                                n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
-                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _gn_counters(x.device, n_items),
-                               _stream()), "mv_groupnorm_f16")
+                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _stream()), "mv_groupnorm_f16")
     return o
-
-
-# arrival-ticket counters of the GroupNorm statistics kernel: zero on entry, left zero by the kernel.  One persistent array per
-# (device, stream): launches on one stream are ordered, launches on different streams (the two CFG halves) must not share it.
-_GN_COUNTERS: dict = {}
-
-
-def _gn_counters(device: torch.device, n_items: int) -> int:
-    key = (device.index, _stream())
-    buf = _GN_COUNTERS.get(key)
-    if buf is None or buf.numel() < n_items:
-        buf = torch.zeros(max(4096, n_items), dtype=torch.int32, device=device)
-        _GN_COUNTERS[key] = buf
-    return buf.data_ptr()
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

@@ -22,6 +22,7 @@ def transform(text: str) -> str:
     text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(CSRC, "common.h"))
     text = text.replace('#include "gemm_tuned.h"', '#include "%s"' % os.path.join(CSRC, "gemm_tuned.h"))
     text = re.sub(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)" ::: "memory"\)', r"sim_waitcnt_vm(\1)", text)
+    text = text.replace('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")', "((void)0)")  # LDS reads are synchronous in the simulator
     text = re.sub(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) (\w+) (\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(sim_smem_buf);", text)
     assert "extern __shared__" not in text
     return text

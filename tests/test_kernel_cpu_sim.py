@@ -238,7 +238,7 @@ def test_gemm_tile_order_on_the_host(gemm_sim):
     _close(got, a.float() @ w.float().t())
 
 
-@pytest.mark.parametrize("kind", ["conv_slices3_ring", "conv_two_src_slices4", "tconv_slices2", "linear_ragged_slices3", "rule"])
+@pytest.mark.parametrize("kind", ["conv_slices3_ring", "conv_two_src_slices4", "tconv_slices2", "linear_ragged_slices3", "rule", "conv_slices3_pingpong"])
 def test_gemm_split_k_on_the_host(gemm_sim, kind):
     """split-K: blockIdx.y owns a contiguous range of K tiles starting in the MIDDLE of the (tap, channel) walk; raw fp32 slabs
     + fixed-order reduce with the full epilogue.  Slices that start inside a tap, at a tap boundary and at the source switch of
@@ -259,7 +259,7 @@ def test_gemm_split_k_on_the_host(gemm_sim, kind):
             tensors["a2"] = xl[:, c1:].contiguous()
         # K = 9 * 128 = 18 K tiles: 3 slices of 6 (tap boundaries), 4 slices of 5 / 5 / 5 / 3 (inside a tap, at the source switch)
         ints = dict(_BASE, M=n * ho * wo, N=cout, K=9 * cin, lda=c1, lda2=c2, ldc=cout, ldr=cout, ldrb=cout, c1=c1, c2=c2, mode=1,
-                    hin=h, win=w_, hout=ho, wout=wo, rows_per_group=ho * wo, splitk=(4 if two else 3), force=(1 if two else 17))
+                    hin=h, win=w_, hout=ho, wout=wo, rows_per_group=ho * wo, splitk=(4 if two else 3), force=(1 if two else (20 if "pingpong" in kind else 17)))
         got = _run_gemm_job(work, exe, kind, tensors, ints, 1, trace=trace)
         assert f"nsplit {4 if two else 3}" in trace[0], trace[0]
         _close(got, ref, atol=6e-3)
@@ -459,18 +459,18 @@ def _catalogue():
 
 def test_gemm_catalogue_is_consistent():
     cat = _catalogue()
-    assert len(set(cat)) == len(cat) == 19, "configurations must be distinct"
+    assert len(cat) == 23 and len(set(cat)) == 19  # 19-22: the 256x256 / 256x320 tiles again, on the ping-pong schedule (with / without s_setprio), "configurations must be distinct"
     for rows, cols, waves, bk, stages in cat:
         assert rows in (32, 64, 128, 256) and cols in (80, 128, 160, 256, 320) and waves in (2, 4, 8) and (bk, stages) in ((64, 2), (64, 3))
         assert stages * (rows + cols) * bk * 2 <= 160 * 1024, "operand stages must fit the 160 KB LDS"
 
 
-@pytest.mark.parametrize("cfg", list(range(19)))
+@pytest.mark.parametrize("cfg", list(range(23)))
 def test_gemm_every_configuration_on_the_host(gemm_sim, cfg):
     """linear GEMM with the full epilogue, forced onto each catalogue entry: ragged M (300) and N = 320 (ragged for the 128- and
     256-wide tiles), K = 192 = three 64-deep or six 32-deep K steps (every ring wraps), LATEST legal LDS-DMA landing; the GEGLU
     epilogue on the even-TN configurations"""
-    if not _FULL and cfg not in (0, 6, 12, 13, 15, 17, 18):
+    if not _FULL and cfg not in (0, 6, 12, 13, 15, 17, 18, 19, 20):
         pytest.skip("covered by MUSEV_SIM_FULL=1 (every configuration was run when it was added)")
     work, exe = gemm_sim
     rows, cols, waves, bk, stages = _catalogue()[cfg]
@@ -493,10 +493,10 @@ def test_gemm_every_configuration_on_the_host(gemm_sim, cfg):
         _close(gotg, hfull[:, :8 * C] * F.gelu(hfull[:, 8 * C:]))
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_gemm_new_configurations_conv_on_the_host(gemm_sim, cfg):
     """the configurations added for the tuner, on the two-source 3x3 convolution with stride 2 (halo + tap walk + concat)"""
-    _subset(cfg in (12, 18))
+    _subset(cfg in (12, 18, 19, 20))
     work, exe = gemm_sim
     n, h, w, c1, c2, cout = 2, 9, 12, 64, 64, 320
     cin = c1 + c2
