@@ -12,12 +12,15 @@ all ranks (the time is the MAX over ranks of K timed steps bracketed by barrier 
 
 Workloads (BASELINE.json configs; synthetic N(0,1) latents / prompt embeddings, seeded random fp16 weights of the
 real SD-1.5 MuseV architecture, 1.42 B parameters -- no checkpoints or datasets exist in this environment):
-  N = 1  : config 2 -- text2video `musev`, 512x512 (latent 64x64), 12 frames + 1 vision-condition frame, CFG batch 2.
-  N > 1  : the same per-GPU work (one 12-frame window x 2 CFG halves per rank): 8*N frames, window 12, overlap 4,
-           `uniform` closed-loop schedule => exactly N windows ("scaling": "weak").  Overlapping windows recompute 4
-           of every 12 frames, so the unique-frame rate of a perfectly parallel run is 8N/12 of N x the 1-GPU rate.
-  --workload config4 : 96 frames = 12 windows = 24 units, strong scaling over the ranks (north-star config 4).
+  N = 1  : config 2 -- text2video `musev`, 512x512 (latent 64x64), 12 frames + 1 vision-condition frame, CFG batch 2 (the
+           configuration the metric is quoted on).  The same line carries `config4_n1`: a short 1-GPU run of config 4, the
+           denominator of the strong-scaling curve the N > 1 runs belong to.
+  N > 1  : config 4 -- 96 frames = 12 windows (window 12, overlap 4, `uniform`, incl. the wrap-around window) x 2 CFG halves =
+           24 units sharded over the ranks ("scaling": "strong"; 3 units per rank at N = 8 -> ideal 8x the 1-GPU config-4 rate).
+  --workload weak    : one window x 2 halves per rank (8*N frames): fixed per-GPU work.
   --workload config3 : `musev_referencenet` + IP-Adapter (+13 ReferEmbFuse attentions), single window.
+  --workload config5 : `musev_referencenet_pose` (== `musev_referencenet` architecture, unet_loader.py:243-268) at 768x768, 48
+                       frames = 6 windows, synthetic ControlNet residuals on the 12 skips + mid block.
 
 Extra JSON objects (tier contract):
   roofline      the dominant kernel (the implicit-GEMM family, MFMA-bound): algorithmic FLOPs per launch / launch
@@ -118,17 +121,37 @@ def unet_flops(H, W, T, B, model="musev", n_vis=1, n_ip_tokens=4, text_tokens=77
     return 2 * tot
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources the library is built from (musev_amd/csrc/*.hip, *.h, include/musev_hip.h): ties a PMC
+    measurement to the code it was taken on"""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "musev_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "musev_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "musev_hip.h")])
+    for f in files:
+        hsh.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def measured_traffic(workload: str):
     """HBM bytes per GEMM launch from the PMC counters: collected offline by tools/gpu_profile.sh (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command, gfx950 read correction x2 applied by
     tools/pmc_summary.py) and committed as profiles/hbm_traffic.json -- a counter pass cannot run inside the timed
-    process.  None when no measurement of this workload is on file."""
+    process.  The file records the hash of the kernel sources it was measured on: a measurement of OTHER code is not
+    reported (None), so `traffic` is reproducible from profiles/ or absent."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
-        fam = rec.get(workload, {}).get("gemm")
-        return (None, None) if fam is None else (fam["hbm_bytes_per_launch"], rec[workload].get("source"))
+        ent = rec.get(workload, {})
+        fam = ent.get("gemm")
+        if fam is None or ent.get("kernel_source_hash") != kernel_source_hash():
+            return None, (f"profiles/hbm_traffic.json holds no PMC measurement of this build (kernel sources {kernel_source_hash()}, "
+                          f"file: {ent.get('kernel_source_hash')})")
+        return fam["hbm_bytes_per_launch"], ent.get("source")
     except (OSError, ValueError, KeyError):
         return None, None
 
@@ -214,12 +237,13 @@ def build_unet(flavour: str, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config3", "config4", "weak"])
+    ap.add_argument("--steps", type=int, default=40)   # ~2.5 s of timed GPU work at config 2 (activity samplers see it)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config3", "config4", "config5", "weak"])
+    ap.add_argument("--no-config4", action="store_true", help="N = 1 default run: skip the short config-4 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--size", type=int, default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,23 +268,24 @@ def main():
 
     workload = args.workload
     if workload == "auto":
-        workload = "config2" if world == 1 else "weak"
-    flavour = "musev_referencenet" if workload == "config3" else "musev"
+        workload = "config2" if world == 1 else "config4"
+    flavour = "musev_referencenet" if workload in ("config3", "config5") else "musev"
     n_cond, win = 1, 12
-    if workload in ("config2", "config3"):
-        T = 12
-    elif workload == "config4":
-        T = 96
-    else:
-        T = 12 if world == 1 else 8 * world
+    if args.size is None:
+        args.size = 768 if workload == "config5" else 512
+    T = {"config2": 12, "config3": 12, "config4": 96, "config5": 48}.get(workload, 12 if world == 1 else 8 * world)
     h = w = args.size // 8
 
     unet = build_unet(flavour, dev)
 
     g = torch.Generator().manual_seed(0)
-    latents = torch.randn(1, 4, T, h, w, generator=g).to(dev)
     prompt = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(1)).to(dev)
     cond = (0.18215 * torch.randn(1, 4, n_cond, h, w, generator=torch.Generator().manual_seed(2))).to(dev)
+
+    def make_latents(frames):
+        return torch.randn(1, 4, frames, h, w, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    latents = make_latents(T)
     unet_kwargs = {}
     if flavour == "musev_referencenet":
         shapes, mid = refer_shapes(h, w)
@@ -269,8 +294,19 @@ def main():
         unet_kwargs["mid_block_refer_emb"] = torch.randn(1, mid[0], 1, mid[1], mid[2], generator=g4).repeat(2, 1, 1, 1, 1).to(dev)
         unet_kwargs["vision_clip_emb"] = torch.randn(2, 4, 768, generator=torch.Generator().manual_seed(5)).to(dev)
         unet_kwargs["ip_adapter_scale"] = 1.0
+    if workload == "config5":
+        # ControlNet residuals of one window ([(b t), C, h, w] on every skip + the mid block, N(0, 0.1), seed 6: SURVEY 8d row 5);
+        # the ControlNet itself is a side model (section 8f), its outputs are inputs of the path.  The same tensors serve every
+        # window (timing does not depend on their values).
+        shapes, mid = refer_shapes(h, w)
+        g6 = torch.Generator().manual_seed(6)
+        n_rows = 2 * (win + n_cond)
+        unet_kwargs["down_block_additional_residuals"] = [(0.1 * torch.randn(n_rows, c, a, b_, generator=g6)).to(dev, torch.float16) for c, a, b_ in shapes]
+        unet_kwargs["mid_block_additional_residual"] = (0.1 * torch.randn(n_rows, mid[0], mid[1], mid[2], generator=g6)).to(dev, torch.float16)
 
     den = ParallelDenoiser(unet, context_frames=win, context_overlap=4, context_stride=1, context_schedule="uniform")
+    if workload == "config5":
+        den.half_streams = False  # the (b t)-shaped residual tensors cover both CFG halves of a window: one batch-2 forward
     n_windows = len(den.windows(T, DENOISE_STEPS))
     total = args.warmup + args.steps
 
@@ -290,9 +326,9 @@ def main():
                 marks["t0"] = time.perf_counter()
         return cb
 
-    def run_steps(n_steps, cb=None):
+    def run_steps(n_steps, cb=None, lat=None):
         # a DDIM schedule with n_steps entries: every step does identical work, which is all the timing needs
-        return den(latents, prompt, num_inference_steps=n_steps, guidance_scale=3.5, condition_latents=cond,
+        return den(latents if lat is None else lat, prompt, num_inference_steps=n_steps, guidance_scale=3.5, condition_latents=cond,
                    motion_speed=8.0, unet_kwargs=unet_kwargs, group=group, callback=cb)
 
     if args.warmup == 0:
@@ -308,6 +344,23 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = T / (DENOISE_STEPS * ms_per_step / 1e3)
     finite = bool(torch.isfinite(out).all())
+
+    # ---- N = 1 default run: the 1-GPU point of the config-4 strong-scaling curve (12 windows per step), a few steps ----
+    config4_n1 = None
+    if world == 1 and args.workload == "auto" and not args.no_config4:
+        lat96 = make_latents(96)
+        k4, w4 = 3, 1
+        marks4 = {}
+
+        def cb4(step, t, lat):
+            if step + 1 == w4:
+                sync_all()
+                marks4["t0"] = time.perf_counter()
+        run_steps(w4 + k4, cb4, lat96)
+        sync_all()
+        ms4 = (time.perf_counter() - marks4["t0"]) * 1e3 / k4
+        config4_n1 = {"workload": "config4: musev, 512x512, 96 frames, window 12 overlap 4 -> 12 windows x 2 CFG halves on 1 GPU",
+                      "value": 96 / (DENOISE_STEPS * ms4 / 1e3), "unit": "frames/s", "ms_per_step": ms4, "steps": k4, "warmup": w4}
 
     # ---- whole-step algorithmic FLOPs (what each rank executes per step, summed over ranks) ----
     halves = 2
@@ -383,7 +436,7 @@ def main():
             "metric": "denoised frames/sec @512x512, 12-frame window, 20 DDIM steps",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if workload == "config4" else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong" if workload in ("config4", "config5") else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{workload}: {flavour}, {args.size}x{args.size}, {T} frames (+{n_cond} vision-condition frame per window), "
                                    f"window {win} overlap 4 -> {n_windows} window(s) x 2 CFG halves = {n_windows * 2} units over {world} GPU(s), "
                                    f"{DENOISE_STEPS} DDIM steps, guidance 3.5",
@@ -393,9 +446,11 @@ def main():
                        # PERFECTLY parallel run is 8N/12 of N x the single-window rate -- the algorithm's overlap, not a loss
                        "window_frames_per_s": n_windows * win / (DENOISE_STEPS * ms_per_step / 1e3),
                        "ideal_value_vs_n1": (T / 12.0) if workload == "weak" else None,
+                       # strong-scaling workloads: the speed-up this rank count can reach at best = total units / the largest shard
+                       "ideal_speedup_vs_1gpu_same_workload": (n_windows * 2) / max(len(s_) for s_ in shards),
                        "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
                        "output_finite": finite},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -219,6 +219,13 @@ int mv_window_gather(const float* latents, const float* cond, const int32_t* idx
 int mv_window_scatter_add(const void* eps_win, int32_t eps_is_f32, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
                           int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset,
                           float* eps_acc, float* counter, int32_t add_counter, void* stream);
+/* mv_window_units_reduce: the multi-rank form of the accumulation (reference :2076-2078 after the RCCL all-gather of SURVEY 8e):
+ * eps_acc[half][C][T_total][HW] = sum, in table order, of units[slot][j*HW + p][C] (fp32 channels-last rows of one window's
+ * generated frames; slot = rank * max_units + k in the gathered buffer, unit_stride elements apart).  table: int32
+ * [halves][T_total][maxc][2] = (slot, j) pairs covering (half, frame), -1 terminated.  Overwrites eps_acc (no zero fill needed);
+ * the order of the sum is the table's, identical on every rank. */
+int mv_window_units_reduce(const float* units, int64_t unit_stride, const int32_t* table, int32_t maxc, int32_t c,
+                           int32_t t_total, int32_t hw, int32_t halves, float* eps_acc, void* stream);
 /* mv_cfg_ddim_step: eps = acc / counter; eps = eps_u + g (eps_t - eps_u); DDIM (eta = 0, epsilon prediction):
  *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps   (in place on latents)
  * replaces: pipeline_controlnet.py:2079,2101-2117 + musev/schedulers/scheduling_ddim.py:198-264. */

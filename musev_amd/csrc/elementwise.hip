@@ -285,6 +285,31 @@ __global__ void window_scatter_add_kernel(const EpsT* eps_win, const int* idx, i
     if (add_counter && blockIdx.x == 0 && threadIdx.x < win) counter[idx[threadIdx.x]] += 1.0f;
 }
 
+// Multi-rank update of one denoise step: eps_acc[h][ci][f][p] = sum over the units that cover frame f (window order) of the
+// gathered predictions  units[slot][j * hw + p][ci]  (fp32, channels-last rows; slot = rank * max_units + k).  A GATHER over a host
+// table (up to `maxc` (slot, j) pairs per (half, frame), -1 = none) instead of world x max_units scatter-add launches: one launch,
+// no read-modify-write on eps_acc (no zero fill either), and a summation order fixed by the table -> bit-identical on every rank.
+__global__ void window_units_reduce_kernel(const float* units, long unit_stride, const int* tab, int maxc, int c, int t_total, int hw,
+                                           int halves, float* eps_acc) {
+    const long total = (long)halves * t_total * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % hw);
+        const long r = i / hw;
+        const int f = (int)(r % t_total);
+        const int h = (int)(r / t_total);
+        const int* e = tab + ((long)h * t_total + f) * maxc * 2;
+        for (int ci = 0; ci < c; ++ci) {
+            float acc = 0.f;
+            for (int k = 0; k < maxc; ++k) {
+                const int slot = e[2 * k];
+                if (slot < 0) break;
+                acc += units[(long)slot * unit_stride + ((long)e[2 * k + 1] * hw + p) * c + ci];
+            }
+            eps_acc[(((long)h * c + ci) * t_total + f) * hw + p] = acc;
+        }
+    }
+}
+
 __global__ void cfg_ddim_step_kernel(float* latents, const float* eps_acc, const float* counter, int c, int t_total, int hw,
                                      int halves, float guidance, float sqrt_at, float sqrt_1mat, float sqrt_ap,
                                      float sqrt_1map) {
@@ -557,6 +582,16 @@ extern "C" int mv_window_scatter_add(const void* eps_win, int32_t eps_is_f32, co
         hipLaunchKernelGGL(window_scatter_add_kernel<half_t>, g, dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)eps_win, idx, win,
                            n_cond, c, t_total, hw, halves, half_offset, eps_acc, counter, add_counter);
     MV_CHECK_LAUNCH("mv_window_scatter_add");
+    return MV_OK;
+}
+
+extern "C" int mv_window_units_reduce(const float* units, int64_t unit_stride, const int32_t* table, int32_t maxc, int32_t c,
+                                      int32_t t_total, int32_t hw, int32_t halves, float* eps_acc, void* stream) {
+    MV_REQUIRE(units && table && eps_acc && maxc > 0 && c > 0 && t_total > 0 && hw > 0 && (halves == 1 || halves == 2) && unit_stride > 0,
+               "mv_window_units_reduce: bad args");
+    hipLaunchKernelGGL(window_units_reduce_kernel, dim3(grid_for((long)halves * t_total * hw)), dim3(kBlock), 0, (hipStream_t)stream, units,
+                       (long)unit_stride, table, maxc, c, t_total, hw, halves, eps_acc);
+    MV_CHECK_LAUNCH("mv_window_units_reduce");
     return MV_OK;
 }
 

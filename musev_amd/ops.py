@@ -23,7 +23,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
 __all__ = [
     "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
     "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
-    "window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
+    "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
 
 
@@ -457,6 +457,18 @@ def window_scatter_add(eps_win: torch.Tensor, idx: torch.Tensor, n_cond: int, ha
                                             n_cond, c, t_total, hw, halves,
                                             half_offset, eps_acc.data_ptr(), counter.data_ptr(), int(add_counter),
                                             _stream()), "mv_window_scatter_add")
+
+
+def window_units_reduce(units: torch.Tensor, table: torch.Tensor, eps_acc: torch.Tensor) -> None:
+    """units fp32 [slots, win_max*HW, C] (the all-gathered predictions); table int32 [halves, T_total, maxc, 2] of (slot, j) pairs,
+    -1 terminated; eps_acc fp32 [halves, C, T_total, HW] is OVERWRITTEN with the table-ordered sums."""
+    halves, c, t_total, hw = eps_acc.shape
+    if units.dtype != torch.float32 or not units.is_contiguous() or units.dim() != 3 or units.shape[2] != c:
+        raise ValueError("window_units_reduce: units must be contiguous fp32 [slots, rows, C]")
+    if table.dtype != torch.int32 or not table.is_contiguous() or table.shape[:2] != (halves, t_total) or table.shape[3] != 2:
+        raise ValueError("window_units_reduce: table must be contiguous int32 [halves, T_total, maxc, 2]")
+    check(_lib.load().mv_window_units_reduce(units.data_ptr(), units.stride(0), table.data_ptr(), table.shape[2], c, t_total, hw, halves,
+                                             eps_acc.data_ptr(), _stream()), "mv_window_units_reduce")
 
 
 def cfg_ddim_step(latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.Tensor, guidance: float, alpha_t: float,

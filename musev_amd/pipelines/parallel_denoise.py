@@ -10,9 +10,11 @@ Here
   * the window input is built directly in the UNet's channels-last layout by one kernel (mv_window_gather),
   * every (window, CFG half) pair is an independent *unit* of work: a rank owns a contiguous slice of the unit list,
     runs the UNet on its units (both halves of a window batched when it owns both) and contributes the predictions
-    to ONE all_gather_into_tensor per step (RCCL; fp32 predictions, <= 786 KB per unit) -- there is no other collective,
-  * every rank then performs the identical, order-fixed scatter-add / average / CFG / DDIM update
-    (mv_window_scatter_add + mv_cfg_ddim_step), so the replicated latents stay bit-identical across ranks.
+    to the step's exchange (RCCL all-gather of the fp32 predictions, <= 786 KB per unit, one collective per exchange slot issued
+    as soon as the slot is filled so that it runs under the next window's forward) -- there is no other collective,
+  * every rank then performs the identical, order-fixed accumulation / average / CFG / DDIM update
+    (mv_window_units_reduce -- one table-driven gather-reduce launch -- + mv_cfg_ddim_step), so the replicated latents stay
+    bit-identical across ranks.
 Latents are kept in fp32 [C, T, HW]; the reference keeps them in the model dtype (fp16 on GPU)."""
 from __future__ import annotations
 
@@ -161,7 +163,24 @@ class ParallelDenoiser:
         max_units = max(len(s) for s in shards)
         unit_elems = win_len * hw * c
         send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
-        recv = torch.empty((world * max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
+        recv = torch.empty((max_units, world, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None  # [slot][rank]
+        cover = None
+        if world > 1:
+            # (slot, position-in-window) pairs covering every (half, frame), in unit order (= window order: the shards are
+            # contiguous slices of the window-major unit list): ONE gather-reduce launch per step replaces world x max_units
+            # scatter-adds, and its summation order is the same on every rank (bit-identical replicas)
+            pairs = [[[] for _ in range(T)] for _ in range(halves)]
+            for r in range(world):
+                for k, u in enumerate(shards[r]):
+                    for j, f in enumerate(wins[u.window]):
+                        pairs[u.half][f].append((k * world + r, j))
+            maxc = max(len(e) for hp in pairs for e in hp)
+            tab = torch.full((halves, T, maxc, 2), -1, dtype=torch.int32)
+            for hf in range(halves):
+                for f in range(T):
+                    for q, (slot_, j) in enumerate(pairs[hf][f]):
+                        tab[hf, f, q, 0], tab[hf, f, q, 1] = slot_, j
+            cover = tab.to(dev)
 
         vis_idx = list(range(n_cond)) if n_cond else None  # host ints (vision_condition_latent_index, :1914-1920)
         # sub_latent_index_c = arange(len(window)) + n_cond (:1914-1920), one tensor per distinct window length
@@ -197,13 +216,15 @@ class ParallelDenoiser:
         for step, t in enumerate(timesteps):
             if max_steps is not None and step >= max_steps:
                 break
-            eps_acc.zero_()
+            if world == 1:
+                eps_acc.zero_()  # (the multi-rank gather-reduce overwrites it)
             t_dev.fill_(float(t))
             # scheduler.scale_model_input (:1911): identity for DDIM, 1/sqrt(sigma^2+1) for Euler; the vision-condition
             # latents are concatenated AFTER the scaling in the reference (:1922-1946) and stay unscaled
             in_scale = sched.input_scale(step)
             lat_in = lat if in_scale == 1.0 else lat * in_scale
             slot = 0
+            works = []
             cn, cn_on = None, False
             if controlnet is not None:
                 cond_scale = float(controlnet_conditioning_scale) * cn_keep[step]   # :1229-1236
@@ -223,13 +244,18 @@ class ParallelDenoiser:
                 else:
                     for k, hf in enumerate(hs):
                         send[slot, :wl * hw].copy_(eps[(k * tw + n_cond) * hw:(k + 1) * tw * hw])
+                        # one all-gather per exchange slot, issued as soon as the slot is filled: RCCL runs it on the process
+                        # group's own stream, under the next group's forward; only the last slot's exchange is exposed
+                        works.append(torch.distributed.all_gather_into_tensor(recv[slot].view(-1), send[slot].view(-1), group=group,
+                                                                              async_op=True))
                         slot += 1
             if world > 1:
-                torch.distributed.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-                for r in range(world):  # fixed accumulation order on every rank -> bit-identical replicas
-                    for k, u in enumerate(shards[r]):
-                        ops.window_scatter_add(recv[r * max_units + k, :len(wins[u.window]) * hw], idx_dev[u.window], 0, 1, u.half,
-                                               eps_acc, counter, False)
+                for k in range(slot, max_units):  # a rank with fewer units still takes part in every slot's collective
+                    works.append(torch.distributed.all_gather_into_tensor(recv[k].view(-1), send[k].view(-1), group=group, async_op=True))
+                for wk in works:
+                    wk.wait()  # stream dependency for RCCL (no host block)
+                works.clear()
+                ops.window_units_reduce(recv.view(max_units * world, win_len * hw, c), cover, eps_acc)  # table order -> bit-identical replicas
             sched.loop_update(lat, eps_acc, counter, guidance[step], step, t)
             sched.consume_step_noise((1, c, T, h, w), latents.dtype, dev, generator, noise_type, w_ind_noise)
             if callback is not None:

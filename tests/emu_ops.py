@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 
-from fake_ops import cfg_affine_step, cfg_ddim_step, window_gather, window_scatter_add  # noqa: F401  (loop glue)
+from fake_ops import cfg_affine_step, cfg_ddim_step, window_gather, window_scatter_add, window_units_reduce  # noqa: F401  (loop glue)
 
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 
@@ -351,7 +351,7 @@ def pack_geglu(w, bias):
 
 EMULATED = ["gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
-            "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step",
+            "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
             "pack_conv_weight", "pack_geglu"]
 
 

@@ -25,6 +25,18 @@ def window_scatter_add(eps_win, idx, n_cond, halves, half_offset, eps_acc, count
         counter[idx.long()] += 1
 
 
+def window_units_reduce(units, table, eps_acc):
+    halves, c, t_total, hw = eps_acc.shape
+    for h in range(halves):
+        for f in range(t_total):
+            acc = torch.zeros(hw, c)
+            for slot, j in table[h, f].tolist():
+                if slot < 0:
+                    break
+                acc = acc + units[slot, j * hw:(j + 1) * hw]
+            eps_acc[h, :, f] = acc.t()
+
+
 def cfg_ddim_step(latents, eps_acc, counter, guidance, a_t, a_prev):
     eps = eps_acc / counter[None, None, :, None]
     e = eps[0] + guidance * (eps[1] - eps[0]) if eps.shape[0] == 2 else eps[0]

@@ -399,6 +399,36 @@ def case_window_loop():
             "parts": {p["name"]: p["ok"] for p in parts}}
 
 
+def case_window_units_reduce():
+    """the multi-rank accumulation (mv_window_units_reduce) against the scatter-add formulation: config-4-like table (3 ranks x 3
+    slots, one unused; windows of 6 and a short one of 3 frames; a wrap-around window), exact in fp32"""
+    from musev_amd import ops
+    c, t_total, hw, halves, win_max = 4, 14, 40, 2, 6
+    wins = [[0, 1, 2, 3, 4, 5], [4, 5, 6, 7, 8, 9], [8, 9, 10, 11, 12, 13], [12, 13, 0]]
+    units = [(wi, hf) for wi in range(len(wins)) for hf in range(halves)]           # 8 units over 3 ranks: 3 + 3 + 2
+    world, max_units = 3, 3
+    shards = [units[0:3], units[3:6], units[6:8]]
+    g = torch.Generator().manual_seed(140)
+    recv = torch.randn((world * max_units, win_max * hw, c), generator=g).to(DEV)
+    pairs = [[[] for _ in range(t_total)] for _ in range(halves)]
+    ref = torch.zeros((halves, c, t_total, hw), device=DEV)
+    for r in range(world):
+        for k, (wi, hf) in enumerate(shards[r]):
+            slot = r * max_units + k
+            for j, f in enumerate(wins[wi]):
+                pairs[hf][f].append((slot, j))
+                ref[hf, :, f] += recv[slot, j * hw:(j + 1) * hw].t()
+    maxc = max(len(e) for hp in pairs for e in hp)
+    tab = torch.full((halves, t_total, maxc, 2), -1, dtype=torch.int32)
+    for hf in range(halves):
+        for f in range(t_total):
+            for q, (slot, j) in enumerate(pairs[hf][f]):
+                tab[hf, f, q, 0], tab[hf, f, q, 1] = slot, j
+    acc = torch.full((halves, c, t_total, hw), 123.0, device=DEV)  # must be overwritten, not accumulated into
+    ops.window_units_reduce(recv, tab.to(DEV), acc)
+    return _cmp("window_units_reduce", acc, ref, atol=0.0, rtol=0.0)
+
+
 def case_cfg_affine_step():
     """mv_cfg_affine_step against the Euler-discrete step (scheduling_euler_discrete.py:146-162 with gamma = 0):
     x + (sigma_next - sigma) * CFG(acc / counter)."""
@@ -463,6 +493,7 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("timestep_embedding", case_timestep_embedding),
     ("layout_misc", case_layout_and_misc),
     ("window_loop", case_window_loop),
+    ("window_units_reduce", case_window_units_reduce),
 ]
 
 

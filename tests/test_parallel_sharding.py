@@ -32,14 +32,14 @@ def test_shard_units_invariants():
 
 def _patch(monkeypatch_like):
     from musev_amd import ops
-    for name in ("window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step"):
+    for name in ("window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step"):
         monkeypatch_like(ops, name, getattr(fake_ops, name))
 
 
 def _run_loop(group=None, scheduler=None, frames=20, schedule="uniform", window=8, overlap=2, **loop_kw):
     from musev_amd import ops
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
-    saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "cfg_ddim_step", "cfg_affine_step")}
+    saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step")}
     try:
         _patch(setattr)
         ParallelDenoiser._device_check = False
@@ -186,3 +186,37 @@ def test_window_visiting_a_frame_twice_is_refused():
             den(torch.randn(1, 4, 20, 4, 4, generator=g), torch.randn(2, 7, 16, generator=g), num_inference_steps=2, guidance_scale=3.5)
         finally:
             ParallelDenoiser._device_check = True
+
+
+# ---- side models on one rank + one broadcast -----------------------------------------------------------------------
+def _side_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from musev_amd.pipelines.conditioning import get_referencenet_emb_sharded
+    calls = []
+
+    def fake_refnet(sample, timestep, encoder_hidden_states, num_frames, return_ndim):
+        calls.append(1)
+        g = torch.Generator().manual_seed(5)
+        down = [torch.randn(2, c, 1, s_, s_, generator=g).half() for c, s_ in ((320, 8), (320, 8), (640, 4), (1280, 2))]
+        return down, torch.randn(2, 1280, 1, 2, 2, generator=g).half(), None
+
+    lat = torch.zeros(2, 4, 8, 8)
+    tok = torch.zeros(2, 4, 768)
+    down, mid, sa = get_referencenet_emb_sharded(fake_refnet if rank == 1 else None, lat if rank == 1 else None, 1, tok, None,
+                                                 group=dist.group.WORLD, src=1, device=torch.device("cpu"))
+    ret[rank] = ([d.clone() for d in down], mid.clone(), len(calls))
+    dist.destroy_process_group()
+
+
+def test_side_model_outputs_are_computed_on_one_rank_and_broadcast():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_side_worker, args=(3, port, ret), nprocs=3, join=True)
+    assert [ret[r][2] for r in range(3)] == [0, 1, 0], "the side model must run on the source rank only"
+    for r in (0, 2):
+        assert all(torch.equal(a, b) for a, b in zip(ret[r][0], ret[1][0])) and torch.equal(ret[r][1], ret[1][1])
+    assert [tuple(d.shape) for d in ret[0][0]] == [(2, 320, 1, 8, 8), (2, 320, 1, 8, 8), (2, 640, 1, 4, 4), (2, 1280, 1, 2, 2)]

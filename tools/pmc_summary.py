@@ -32,6 +32,9 @@ for fam in out.get("FETCH_SIZE", {}):
     n = max(f["launches"], 1)
     res[fam] = {"launches": f["launches"], "fetch_kb_per_launch_raw": f["avg_kb"], "write_kb_per_launch": w["avg_kb"],
                 "hbm_bytes_per_launch": (2.0 * f["avg_kb"] + w["avg_kb"]) * 1024.0}
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+res["kernel_source_hash"] = bench.kernel_source_hash()
 print(json.dumps(res, indent=1))
 with open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_summary.json"), "w") as fh:
     json.dump(res, fh, indent=1)
