@@ -219,6 +219,12 @@ int mv_window_gather(const float* latents, const float* cond, const int32_t* idx
 int mv_window_scatter_add(const void* eps_win, int32_t eps_is_f32, const int32_t* idx, int32_t win, int32_t n_cond, int32_t c,
                           int32_t t_total, int32_t hw, int32_t halves, int32_t half_offset,
                           float* eps_acc, float* counter, int32_t add_counter, void* stream);
+/* ---- row softmax (side model: VAE decoder mid-block attention, single head of d = 512, run as GEMM -> softmax -> GEMM) ------
+ * replaces: the softmax inside diffusers' Attention processor of AutoencoderKL.decoder.mid_block.attentions[0] (un-vendored);
+ * call site in the reference: StableDiffusionPipeline.decode_latents via musev/pipelines/pipeline_controlnet.py:233-238.
+ * x: fp16 [rows][ldx], softmax over the first `cols` entries of every row, in place (fp32 arithmetic). */
+int mv_softmax_rows_f16(void* x, int64_t ldx, int64_t rows, int32_t cols, void* stream);
+
 /* mv_window_units_reduce: the multi-rank form of the accumulation (reference :2076-2078 after the RCCL all-gather of SURVEY 8e):
  * eps_acc[half][C][T_total][HW] = sum, in table order, of units[slot][j*HW + p][C] (fp32 channels-last rows of one window's
  * generated frames; slot = rank * max_units + k in the gathered buffer, unit_stride elements apart).  table: int32

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mv_bthwc_to_bcthw_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mv_window_gather": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mv_window_scatter_add": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mv_softmax_rows_f16": (_i32, [_vp, _i64, _i64, _i32, _vp]),
     "mv_window_units_reduce": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mv_cfg_ddim_step": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
     "mv_cfg_affine_step": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),

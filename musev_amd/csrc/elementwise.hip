@@ -285,6 +285,58 @@ __global__ void window_scatter_add_kernel(const EpsT* eps_win, const int* idx, i
     if (add_counter && blockIdx.x == 0 && threadIdx.x < win) counter[idx[threadIdx.x]] += 1.0f;
 }
 
+// Row softmax in place over fp16 rows (the single-head, d = 512 mid-block attention of the VAE decoder is run as GEMM -> this ->
+// GEMM: once per decoded frame, outside the denoise loop).  One 256-thread block per row, the row held in registers (cols <= 16384),
+// fp32 maximum / sum, exp2 with the log2(e) factor folded.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* x, long ld, int cols) {
+    __shared__ float red[8];
+    half_t* row = x + (long)blockIdx.x * ld;
+    const int oc = cols >> 3;
+    constexpr int MAXV = 8;  // 8 octets per thread x 256 threads x 8 = 16384 columns
+    half8v v[MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int o = threadIdx.x + 256 * k;
+        if (o < oc) {
+            v[k] = *reinterpret_cast<const half8v*>(row + o * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[k][j]);
+        }
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float e[MAXV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int o = threadIdx.x + 256 * k;
+        if (o < oc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                e[k][j] = __builtin_amdgcn_exp2f(((float)v[k][j] - mx) * 1.4426950408889634f);
+                sum += e[k][j];
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int o = threadIdx.x + 256 * k;
+        if (o < oc) {
+            half8v w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (half_t)(e[k][j] * inv);
+            *reinterpret_cast<half8v*>(row + o * 8) = w;
+        }
+    }
+}
+
 // Multi-rank update of one denoise step: eps_acc[h][ci][f][p] = sum over the units that cover frame f (window order) of the
 // gathered predictions  units[slot][j * hw + p][ci]  (fp32, channels-last rows; slot = rank * max_units + k).  A GATHER over a host
 // table (up to `maxc` (slot, j) pairs per (half, frame), -1 = none) instead of world x max_units scatter-add launches: one launch,
@@ -592,6 +644,14 @@ extern "C" int mv_window_units_reduce(const float* units, int64_t unit_stride, c
     hipLaunchKernelGGL(window_units_reduce_kernel, dim3(grid_for((long)halves * t_total * hw)), dim3(kBlock), 0, (hipStream_t)stream, units,
                        (long)unit_stride, table, maxc, c, t_total, hw, halves, eps_acc);
     MV_CHECK_LAUNCH("mv_window_units_reduce");
+    return MV_OK;
+}
+
+extern "C" int mv_softmax_rows_f16(void* x, int64_t ldx, int64_t rows, int32_t cols, void* stream) {
+    MV_REQUIRE(x && rows > 0 && rows < (1L << 31) && cols > 0 && cols % 8 == 0 && cols <= 16384 && ldx % 8 == 0 && ldx >= cols,
+               "mv_softmax_rows_f16: need cols %% 8 == 0, cols <= 16384, ldx %% 8 == 0 (rows=%ld cols=%d ldx=%ld)", (long)rows, cols, (long)ldx);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, (long)ldx, cols);
+    MV_CHECK_LAUNCH("mv_softmax_rows_f16");
     return MV_OK;
 }
 

@@ -21,7 +21,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
                    check)
 
 __all__ = [
-    "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
+    "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
     "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
     "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
@@ -310,6 +310,13 @@ def geglu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     o = _out(out, M, half, x)
     check(_lib.load().mv_geglu_f16(x.data_ptr(), x.stride(0), o.data_ptr(), o.stride(0), M, half, _stream()), "mv_geglu_f16")
     return o
+
+
+def softmax_rows_(x: torch.Tensor) -> torch.Tensor:
+    """in-place softmax over the columns of an fp16 [rows, cols] matrix (unit inner stride, any row stride % 8)"""
+    x = _mat(x, "x")
+    check(_lib.load().mv_softmax_rows_f16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "mv_softmax_rows_f16")
+    return x
 
 
 def silu(x: torch.Tensor) -> torch.Tensor:

@@ -281,3 +281,20 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
         out.index_copy_(2, latent_index, latents)
         latents = out
     return latents
+
+
+def multi_shot_loop(unet_fn: Callable[..., Tensor], noises: List[Tensor], prompt_embeds: Tensor, condition_latents: Optional[Tensor],
+                    n_vision_condition: int = 1, fix_condition_images: bool = False, **loop_kwargs) -> Tensor:
+    """musev/pipelines/pipeline_controlnet_predictor.py:643-745 (``run_pipe_text2video``'s shot loop) over ``denoise_loop``: shot i
+    starts from ``noises[i]``; from shot 1 on the condition latents are the last ``n_vision_condition`` frames of the previous
+    shot's output (``out_latents_batch[:, :, -n_vision_condition:]``, :656-659) and the first ``n_vision_condition`` output frames
+    (``result_overlap``, :662) are dropped before the shots are concatenated along t."""
+    parts = []
+    cond = condition_latents
+    for i, noise in enumerate(noises):
+        out = denoise_loop(unet_fn, noise, prompt_embeds, condition_latents=cond, **loop_kwargs)
+        overlap = 0 if i == 0 else (n_vision_condition if cond is not None else 0)
+        parts.append(out[:, :, overlap:])
+        if cond is not None and n_vision_condition > 0 and not fix_condition_images:
+            cond = out[:, :, -n_vision_condition:]
+    return torch.cat(parts, dim=2)

@@ -256,6 +256,13 @@ def geglu(x, out=None):
     return _store(x.float()[:, :half] * F.gelu(x.float()[:, half:]), out)
 
 
+def softmax_rows_(x):
+    _mat(x, "x")
+    _req(x.shape[1] % 8 == 0 and x.shape[1] <= 16384 and x.stride(0) % 8 == 0, "softmax_rows_: cols % 8, cols <= 16384, ld % 8")
+    x.copy_(torch.softmax(x.float(), dim=-1).to(torch.float16))
+    return x
+
+
 def silu(x):
     _req(x.is_contiguous() and x.dtype == torch.float16 and x.numel() % 8 == 0 and x.numel() > 0, "silu: contiguous fp16, n % 8")
     return F.silu(x.float()).to(torch.float16)
@@ -349,7 +356,7 @@ def pack_geglu(w, bias):
     return w.index_select(0, perm).contiguous(), (bias.index_select(0, perm).contiguous() if bias is not None else None)
 
 
-EMULATED = ["gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add",
+EMULATED = ["gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
             "pack_conv_weight", "pack_geglu"]

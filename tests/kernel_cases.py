@@ -429,6 +429,18 @@ def case_window_units_reduce():
     return _cmp("window_units_reduce", acc, ref, atol=0.0, rtol=0.0)
 
 
+def case_softmax_rows(rows=300, cols=1024, seed=150):
+    """row softmax in place (VAE mid-block attention): strided rows, large-magnitude scores"""
+    from musev_amd import ops
+    buf = _rand((rows, cols + 64), seed, 6.0)
+    x = buf[:, :cols]
+    ref = torch.softmax(x.float(), dim=-1)
+    ops.softmax_rows_(x)
+    r = _cmp(f"softmax_rows {rows}x{cols}", x, ref, atol=2e-4)
+    r["ok"] = r["ok"] and bool((buf[:, cols:].float().abs() > 0).any())  # the tail of the strided rows is untouched noise
+    return r
+
+
 def case_cfg_affine_step():
     """mv_cfg_affine_step against the Euler-discrete step (scheduling_euler_discrete.py:146-162 with gamma = 0):
     x + (sigma_next - sigma) * CFG(acc / counter)."""
@@ -494,6 +506,8 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("layout_misc", case_layout_and_misc),
     ("window_loop", case_window_loop),
     ("window_units_reduce", case_window_units_reduce),
+    ("softmax_rows", case_softmax_rows),
+    ("softmax_rows_4096", lambda: case_softmax_rows(rows=64, cols=4096, seed=151)),
 ]
 
 
