@@ -416,6 +416,284 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
     }
 }
 
+// =====================================================================================================================
+// attn3_kernel (d = 40 / 80): the same math and fragment layouts as attn_kernel, with the per-tile instruction count cut to a
+// third.  attn_kernel<40, 1> issues ~530 instructions per 64-key tile and wave for 28 MFMAs (static count of its loop: ~290 of
+// them are the register-staged K/V prefetch -- per-chunk 64-bit pointer selects, tail predicates, ds_write commits -- and 64
+// are the scale / subtract fma + exp pairs) and runs at ~1 instruction per 4 cycles per SIMD: it is instruction-issue-bound
+// (MFMA pipe ~30 % busy).  Here:
+//   * K / V tiles travel global -> LDS by LDS-DMA through buffer descriptors (scalar tile advance, rows past the segment end
+//     carry an out-of-range offset and read as zero): no staging registers, no ds_write, no per-tile address arithmetic; dense
+//     rows of D halfs (a whole number of 1-KiB pieces per tile); a three-stage ring with counted waits keeps two tiles in
+//     flight behind one raw s_barrier per tile.
+//   * the score MFMA starts from the accumulator -m instead of 0 and the query fragment is pre-multiplied by scale * log2(e):
+//     S' = q.k * scale * log2(e) - m leaves the matrix pipe ready for exp2 with NO per-score VALU work.
+//   * m is a lazily updated reference, not the exact running maximum (softmax is invariant to the reference as long as
+//     numerators and row sums use the same one): a tile rescales only when some score exceeds the reference by more than kThr
+//     (P <= 2^kThr in fp16) or on the first tile; then O, the row sums and the tile's scores shift by the same amount.
+//   * the row sums come out of the matrix pipe as well: one extra MFMA per 32 keys against a constant fragment whose row 0 is
+//     all ones (fp32 accumulation of exactly the fp16-rounded probabilities the P.V MFMA sees).
+// Contraction columns past D (the 32-deep chunks cover 64 / 96) read the next LDS row: finite data (the LDS is zero-filled
+// once, DMA data is finite) times the zero tail of the query fragment.
+// Per tile and wave at d = 40: 32 MFMA + 32 exp + 16 packed converts + 16 max3 + 1 compare + 20 LDS reads + 2-3 DMA issues.
+template <int D>
+struct Attn3Cfg {
+    static constexpr int CH = D / 8;                   // 16-byte chunks per row
+    static constexpr int NC = (D + 31) / 32;           // 32-deep contraction chunks
+    static constexpr int NDT = (D + 15) / 16;          // O^T d-tiles
+    static constexpr int KV = 64, QT = 2, QB = 128, NST = 3;
+    static constexpr int TILE = KV * D;                // halfs per K (or V) tile = CH pieces of 1 KiB
+    static constexpr int PIECES = 2 * CH;              // LDS-DMA pieces per (K, V) tile pair: 10 / 20, dealt round-robin to the 4 waves
+    static constexpr int PPW = (PIECES + 3) / 4;       // ... at most per wave: 3 / 5
+    static constexpr int LDS_HALFS = NST * 2 * TILE + 64;  // slack: a 32-deep fragment read of the last row runs past it
+};
+
+template <int D>
+__global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnArgs p) {
+    using C = Attn3Cfg<D>;
+    static_assert(D % 8 == 0 && (64 * C::CH) % 64 == 0, "a tile must be a whole number of 1-KiB pieces");
+    constexpr float kThr = 6.0f;  // scores may exceed the reference by 2^6: P <= 64 in fp16, sums in fp32
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const int n = blockIdx.z;
+    const int q0 = blockIdx.x * C::QB + wave * (16 * C::QT);
+    const int npw = (C::PIECES - wave + 3) / 4;  // pieces this wave issues per tile pair (wave-uniform): 3,3,2,2 / 5,5,5,5
+
+    for (int i = tid; i < C::LDS_HALFS / 8; i += 256) reinterpret_cast<uint4*>(lds)[i] = uint4{0, 0, 0, 0};
+    typedef __attribute__((address_space(3))) half_t lds_half_t;
+    const lds_half_t* lds3 = (const lds_half_t*)lds;                           // the LDS image in its own address space (one cast)
+    const int v_lane_off = (4 * g + (l15 >> 2)) * D + (l15 & 3) * 4;           // this lane's place inside a [4 kv][16 d] block of V
+
+    // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale * log2(e); zero past column D ----
+    half8v qf[C::QT][C::NC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int qr = q0 + 16 * qt + l15;
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+            const int dcol = 32 * c + 8 * g;
+            half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qr < p.lq && dcol < D) {
+                const half8v raw = *reinterpret_cast<const half8v*>(p.q + ((long)n * p.lq + qr) * p.ldq + h * D + dcol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)raw[e] * p.scale_log2e);
+            }
+            qf[qt][c] = v;
+        }
+    }
+    // constant A fragment of the row-sum MFMA: row 0 (lanes with l15 == 0) all ones
+    half8v ones_f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones_f[e] = (half_t)(l15 == 0 ? 1.0f : 0.0f);
+
+    float4v acc_o[C::QT][C::NDT], acc_l[C::QT];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        acc_l[qt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+    float m_ref[C::QT] = {0.f, 0.f};  // reference of the exponents (log2 domain)
+
+    __syncthreads();  // the zero fill is complete before the first DMA may land
+    bool first = true;    // no tile processed yet (the first tile sets the reference unconditionally)
+    // ---- walk the key/value segments; per segment a three-stage LDS ring with two tiles in flight (the ring drains at a segment
+    // boundary: a segment is 64 tiles at level 0, and everything that selects it -- base pointers, strides, descriptors, the
+    // lanes' chunk offsets -- is computed here once instead of per tile) ----
+#pragma unroll 1
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        const int len = ATTN_SEG_FIELD(p, seg, len);
+        const int ldk = ATTN_SEG_FIELD(p, seg, ldk), ldv = ATTN_SEG_FIELD(p, seg, ldv);
+        const int sdiv = ATTN_SEG_FIELD(p, seg, div), smul = ATTN_SEG_FIELD(p, seg, mul), sadd = ATTN_SEG_FIELD(p, seg, add);
+        const long kvb = (long)(n / sdiv) * smul + sadd;
+        const half_t* kb = ATTN_SEG_FIELD(p, seg, k) + kvb * len * ldk + h * D;
+        const half_t* vb = ATTN_SEG_FIELD(p, seg, v) + kvb * len * ldv + h * D;
+        // descriptors over the rows [0, len) of this (frame, head)
+        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (unsigned)(((len - 1) * ldk + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(((len - 1) * ldv + D) * 2), 0x00020000);
+        unsigned voff[C::PPW];   // byte offset of this lane's chunk inside a tile, per piece
+        int prow[C::PPW];        // its tile row (tail predicate of the partial last tile)
+#pragma unroll
+        for (int j = 0; j < C::PPW; ++j) {
+            const int q = wave + 4 * j;
+            const int ci = (q % C::CH) * 64 + lane;
+            prow[j] = ci / C::CH;
+            voff[j] = (unsigned)((prow[j] * (q >= C::CH ? ldv : ldk) + (ci - prow[j] * C::CH) * 8) * 2);
+        }
+        const int total = (len + C::KV - 1) / C::KV;
+        const int tile_k = C::KV * ldk * 2, tile_v = C::KV * ldv * 2;  // scalar byte advance per tile
+
+        auto issue = [&](int tile) {  // tile `tile` of this segment -> stage tile % NST
+            half_t* base = lds + (tile % C::NST) * (2 * C::TILE);
+            const int row0 = tile * C::KV;
+            const bool partial = len - row0 < C::KV;  // wave-uniform: rows past the end read as zero
+#pragma unroll
+            for (int j = 0; j < C::PPW; ++j) {
+                const int q = wave + 4 * j;
+                if (q >= C::PIECES) break;  // wave-uniform
+                const bool isv = q >= C::CH;
+                unsigned vo = voff[j];
+                if (partial) vo = (row0 + prow[j] < len) ? vo : 0x80000000u;  // out of range for every descriptor
+                half_t* dst = base + (isv ? C::TILE : 0) + (q % C::CH) * 512;
+                if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, tile * tile_v, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, tile * tile_k, 0, 0);
+            }
+        };
+
+        // every wave has left the previous segment's last tile before its stages are refilled
+        if (seg > 0) __builtin_amdgcn_s_barrier();
+        issue(0);
+        if (total > 1) issue(1);
+
+      for (int t = 0; t < total; ++t) {
+        const int stage = t % C::NST;
+        // this wave's pieces of tile t have landed when at most its pieces of tile t+1 are still in flight
+        if (t + 1 < total) {
+            if (npw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (npw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t are visible; every wave has left tile t-1 (its stage is free)
+        asm volatile("" ::: "memory");
+        if (t + 2 < total) issue(t + 2);
+        const int rows = len - t * C::KV < C::KV ? len - t * C::KV : C::KV;
+        const half_t* sK = lds + stage * (2 * C::TILE);
+        // V^T fragments: ONE per-lane LDS address per tile (stage base + this lane's row / column inside a [4 kv][16 d] block);
+        // the 4 * NDT transpose reads of the tile use immediate offsets from it.  (Casting a generic pointer to the LDS address
+        // space per read costs a v_subrev + v_add3 each: 24 of the ~150 VALU instructions per tile before this.)
+        const lds_half_t* vrd = lds3 + (stage * (2 * C::TILE) + C::TILE + v_lane_off);
+        MV_KEEP_ONE_REGISTER(vrd);  // opaque: ONE address register + immediates (LLVM otherwise hoists 12 addresses and re-adds the stage per read)
+
+        // ---- S'^T = K Q^T - m : acc_s[qt][st][r] = S'[q = l15][kv = 16 st + 4 g + r] ----
+        float4v acc_s[C::QT][4];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const float m0 = -m_ref[qt];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc_s[qt][st] = float4v{m0, m0, m0, m0};
+        }
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const half8v kf = *reinterpret_cast<const half8v*>(sK + (16 * st + l15) * D + 32 * c + 8 * g);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_s[qt][st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][c], acc_s[qt][st], 0, 0, 0);
+            }
+        }
+        if (rows < C::KV) {  // wave-uniform: the partial last tile of a segment masks its missing keys
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * st + 4 * g + r >= rows) {
+#pragma unroll
+                        for (int qt = 0; qt < C::QT; ++qt) acc_s[qt][st][r] = -INFINITY;
+                    }
+        }
+        // ---- softmax numerators ----
+        // per-lane maxima of the 16 scores each lane holds per query tile (3-input maxima on the raw MFMA results); whether ANY
+        // score of the wave exceeds the reference by more than kThr needs no cross-lane traffic -- the per-query maximum (two
+        // cross-lane steps through the LDS crossbar) is only formed on the rare rescale path
+        float lmx[C::QT];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const float4v &s0 = acc_s[qt][0], &s1 = acc_s[qt][1], &s2 = acc_s[qt][2], &s3 = acc_s[qt][3];
+            const float t0 = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
+            const float t1 = fmaxf(fmaxf(s0[3], s1[0]), s1[1]);
+            const float t2 = fmaxf(fmaxf(s1[2], s1[3]), s2[0]);
+            const float t3 = fmaxf(fmaxf(s2[1], s2[2]), s2[3]);
+            const float t4 = fmaxf(fmaxf(s3[0], s3[1]), s3[2]);
+            lmx[qt] = fmaxf(fmaxf(fmaxf(t0, t1), t2), fmaxf(fmaxf(t3, t4), s3[3]));
+        }
+        if (first || __any(fmaxf(lmx[0], lmx[1]) > kThr)) {  // wave-uniform; rare after the first tiles of a row
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) {
+                float mx = lmx[qt];
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // maximum of this query's 64 scores, relative to its reference
+                // move the reference up to the new maximum (on the first tile: to the first estimate, whatever its sign)
+                const float delta = first ? mx : fmaxf(mx, 0.f);  // every tile holds >= 1 real key: mx is finite
+                m_ref[qt] += delta;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                acc_l[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] *= alpha;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) acc_s[qt][st] -= delta;
+            }
+        }
+        half8v pfrag[C::QT][2];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_s[qt][st][r] = __builtin_amdgcn_exp2f(acc_s[qt][st][r]);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                half8v f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (half_t)acc_s[qt][2 * cc][r];
+                    f[4 + r] = (half_t)acc_s[qt][2 * cc + 1][r];
+                }
+                pfrag[qt][cc] = f;
+            }
+        }
+        // ---- O^T += V^T P^T; row sums += 1^T P^T ----
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt)
+                acc_l[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones_f, pfrag[qt][cc], acc_l[qt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt) {
+                const lds_half_t* b0 = vrd + (32 * cc * D + 16 * dt);  // compile-time offset (the loops are fully unrolled)
+                short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0));
+                short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0 + 16 * D));
+                typedef short short8v __attribute__((ext_vector_type(8)));
+                short8v tv = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                half8v vf = __builtin_bit_cast(half8v, tv);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfrag[qt][cc], acc_o[qt][dt], 0, 0, 0);
+            }
+        }
+        first = false;
+      }
+    }
+
+    // ---- epilogue: O^T[d = 16 dt + 4 g + r][q = l15] / row sum ----
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const float l = __shfl(acc_l[qt][0], l15, 64);  // row 0 of the row-sum tile: lane group g = 0, register 0
+        const float inv = 1.0f / l;
+        const int qr = q0 + 16 * qt + l15;
+        if (qr >= p.lq) continue;
+        half_t* orow = p.out + ((long)n * p.lq + qr) * p.ldo + h * D;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+            const int dcol = 16 * dt + 4 * g;
+            if (dcol >= D) continue;
+            float4v o = acc_o[qt][dt] * inv;
+            if (p.accumulate) {
+                half4v prev = *reinterpret_cast<const half4v*>(orow + dcol);
+                o = float4v{(float)prev[0], (float)prev[1], (float)prev[2], (float)prev[3]} + o * p.out_scale;
+            }
+            half4v w = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *reinterpret_cast<half4v*>(orow + dcol) = w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 struct TAttnArgs {
     const half_t* q;
@@ -657,9 +935,27 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
     // d = 40 / 80: OPT 1 (row sums out of the P.V MFMA, 3-input maxima, exact rescale skip); the round-1 / round-2 A/B of the
     // other variants (double-buffered tiles, pkrtz packing, buffer-descriptor K/V fetch, K / V row strides) measured within
     // +-3 % of it at d = 40 and -20..-30 % at d = 80 (profiles/r02a_attn_variant_ab.log): removed from the library
-    if (d->d == 40) hipLaunchKernelGGL((attn_kernel<40, 1>), grid, dim3(256), 0, s, a);
-    else if (d->d == 80) hipLaunchKernelGGL((attn_kernel<80, 1>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<160, 0>), grid, dim3(256), 0, s, a);
+    if (d->d == 40 || d->d == 80) {
+        // LDS-DMA kernel: every K / V source must span < 2 GiB from its (frame, head) base (32-bit descriptor offsets)
+        for (int sg = 0; sg < d->nseg; ++sg)
+            MV_REQUIRE((long)d->seg[sg].len * d->seg[sg].ldk * 2 < 0x7fffffffL && (long)d->seg[sg].len * d->seg[sg].ldv * 2 < 0x7fffffffL,
+                       "mv_attention_f16: segment %d spans 2 GiB or more per key batch", sg);
+        if (d->d == 40) {
+            constexpr int smem = Attn3Cfg<40>::LDS_HALFS * 2;
+            hipLaunchKernelGGL((attn3_kernel<40>), grid, dim3(256), smem, s, a);
+        } else {
+            constexpr int smem = Attn3Cfg<80>::LDS_HALFS * 2;
+            static bool attr_done = false;  // idempotent one-time attribute of this instantiation (72 KB of dynamic LDS)
+            if (!attr_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_kernel<80>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((attn3_kernel<80>), grid, dim3(256), smem, s, a);
+        }
+    } else {
+        hipLaunchKernelGGL((attn_kernel<160, 0>), grid, dim3(256), 0, s, a);
+    }
     MV_CHECK_LAUNCH("mv_attention_f16");
     return MV_OK;
 }

@@ -17,6 +17,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define MV_WAVE 64
 
+// makes a VGPR value opaque to the optimiser at this point (an empty asm that "modifies" it): used to keep a per-tile LDS address
+// in ONE register with immediate offsets.  The host simulator of tests/ defines it away before including this header.
+#ifndef MV_KEEP_ONE_REGISTER
+#define MV_KEEP_ONE_REGISTER(x) asm volatile("" : "+v"(x))
+#endif
+
 // host-side error plumbing ---------------------------------------------------------------------------
 void mv_set_error(const char* fmt, ...);
 

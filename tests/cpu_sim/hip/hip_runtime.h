@@ -78,6 +78,7 @@ static inline void sim_wave_barrier() { pthread_barrier_wait(&sim_wave_bar[threa
 #define __builtin_amdgcn_s_barrier sim_s_barrier
 #define __builtin_amdgcn_wave_barrier sim_wave_barrier
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define MV_KEEP_ONE_REGISTER(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 template <class T> static inline T sim_atomic_fetch_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __hip_atomic_fetch_add(p, v, order, scope) sim_atomic_fetch_add((p), (v))

@@ -195,7 +195,9 @@ def case_attention_self(d=40, b=2, t=3, lq=200, cond_idx=0, seed=60, qscale=1.0)
     ks = torch.cat([k3, k3[cond]], dim=1)
     vs = torch.cat([v3, v3[cond]], dim=1)
     ref = _attn_ref(q.reshape(nb, lq, c), ks, vs, heads, d, scale)
-    return _cmp(f"attention self+cond d{d} nb{nb} lq{lq} qscale{qscale}", got, ref, atol=3e-3)
+    # d = 40 / 80 fold scale * log2(e) into the fp16 query fragment (one more fp16 rounding on the score path, the size of the
+    # rounding the QKV projection already left in q): the absolute bound scales with |v| (= qscale) and with the score spread
+    return _cmp(f"attention self+cond d{d} nb{nb} lq{lq} qscale{qscale}", got, ref, atol=3e-3 * qscale * qscale)
 
 
 def case_attention_cross(d=80, nb=6, t=3, lq=130, lk=77, seed=70, with_ip=True):
