@@ -17,8 +17,9 @@
 // d-tiles of 16.
 //
 // mv_temporal_attention_f16: the temporal transformer's sequences are 13 tokens long (12 frames + 1 condition
-// frame), one sequence per pixel and head -- far too small for MFMA tiles.  One 16/32-lane group per (pixel, head),
-// lane = query frame, fp32 VALU dot products; rows stay in (b, t, p) order so no permute copy is needed.
+// frame), one sequence per pixel and head; rows stay in (b, t, p) order so no permute copy is needed.  T <= 16 at the
+// UNet's head widths: one wave per (pixel, head), one 16x16 MFMA tile per product (tattn3_kernel).  Other shapes
+// (T <= 32, any d % 8 == 0): one 16/32-lane group per item, lane = query frame, fp32 VALU dot products (tattn_kernel).
 #include "common.h"
 
 namespace {
@@ -794,120 +795,133 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs a) {
     }
 }
 
-// ---- v2 of the temporal attention (T <= 16): the K/V rows of the block's (pixel, head) items are staged ONCE in LDS
-// with coalesced 16-byte loads (the 8 heads of a pixel are one contiguous row), and the 16 lanes of an item read them
-// back as LDS broadcasts.  tattn_kernel has every lane fetch all T key and value rows of its item from global memory
-// itself (135 16-byte loads per lane at d = 40; TA-bound at ~2.2 TB/s), this one 13.
-template <int D, int IPB>  // IPB items of 16 lanes per block
-__global__ __launch_bounds__(16 * IPB) void tattn2_kernel(const TAttnArgs a) {
-    constexpr int DCH = D / 8;
-    extern __shared__ __attribute__((aligned(16))) half_t tsm[];  // K rows [IPB][t][D], then V rows [IPB][t][D]
-    half_t* sk = tsm;
-    half_t* sv = tsm + IPB * a.t * D;
-    const int tid = threadIdx.x;
-    const long item0 = (long)blockIdx.x * IPB;
-    // ---- stage K and V: chunk index fastest, then item, then frame.  All of a thread's global loads (its K / V chunks and
-    // its query row) are issued before the first LDS store: t * DCH <= 16 * DCH chunks per item -> at most DCH rounds ----
-    const int nchunk = IPB * a.t * DCH;
-    u32x4 kreg[DCH], vreg[DCH];
-#pragma unroll
-    for (int it = 0; it < DCH; ++it) {
-        const int idx = tid + it * 16 * IPB;
-        // branch-free: a chunk that does not exist loads element 0 of K / V (always mapped) and is zeroed afterwards, so the
-        // loads of all rounds sit in one basic block and go out back to back
-        const int ch = idx % DCH;
-        const int rest = idx / DCH;
-        const int il = rest % IPB, j = rest / IPB;
-        const long item = item0 + il;
-        const bool ok = idx < nchunk && item < a.items;
-        const int h = (int)(item % a.heads);
-        const long bp = item / a.heads;
-        const int pix = (int)(bp % a.hw);
-        const int b = (int)(bp / a.hw);
-        const long row = ((long)b * a.t + j) * a.hw + pix;
-        const long ko = ok ? row * a.ldk + h * D + ch * 8 : 0;
-        const long vo = ok ? row * a.ldv + h * D + ch * 8 : 0;
-        kreg[it] = *reinterpret_cast<const u32x4*>(a.k + ko);
-        vreg[it] = *reinterpret_cast<const u32x4*>(a.v + vo);
-        if (!ok) {
-            kreg[it] = u32x4{0, 0, 0, 0};
-            vreg[it] = u32x4{0, 0, 0, 0};
-        }
-    }
-    const int il = tid >> 4, gl = tid & 15;
-    const long item = item0 + il;
-    const bool live = item < a.items;
-    const bool active = live && gl < a.t;
-    const int h = live ? (int)(item % a.heads) : 0;
-    const long bp = live ? item / a.heads : 0;
-    const int pix = (int)(bp % a.hw);
-    const int b = (int)(bp / a.hw);
-    const int tq = active ? gl : 0;
-    const long qrow = ((long)b * a.t + tq) * a.hw + pix;
-    half8v qv[DCH];
-#pragma unroll
-    for (int ch = 0; ch < DCH; ++ch) qv[ch] = *reinterpret_cast<const half8v*>(a.q + qrow * a.ldq + h * D + ch * 8);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < DCH; ++it) {
-        const int idx = tid + it * 16 * IPB;
-        if (idx < nchunk) {
-            const int ch = idx % DCH;
-            const int rest = idx / DCH;
-            const int il2 = rest % IPB, j = rest / IPB;
-            *reinterpret_cast<u32x4*>(sk + (il2 * a.t + j) * D + ch * 8) = kreg[it];
-            *reinterpret_cast<u32x4*>(sv + (il2 * a.t + j) * D + ch * 8) = vreg[it];
-        }
-    }
-    __syncthreads();
+// ---- temporal attention on the matrix cores (T <= 16, d = 40 / 80 / 160): one wave per (pixel, head) item ----------------------
+// tattn_kernel spends ~1200 VALU/LDS instructions per item on 13 x 13 x d scalar FMAs and is instruction-issue bound (level 0:
+// 107 us for 272 MB of q/k/v/out, profiles/r02e).  Here an item is two small MFMA products:
+//   S^T[key][query] = K Q^T   16x16x32 steps over d; A = K rows, B = Q rows, both loaded straight from global memory in fragment
+//                             shape (lane (l15 = frame, g) holds 8 halfs at d = 32c + 8g; frames >= T re-read frame T-1 and are masked)
+//   softmax over keys         a lane holds keys 4g..4g+3 of query l15: 4 registers + two xor-shuffles (16, 32)
+//   O^T[d][query]   = V^T P^T 16x16x16 steps; B = P^T is the S^T accumulator layout as it stands (keys 4g+r), A = V^T comes from the
+//                             wave's private LDS image of V ([key][DP] row-major) through ds_read_b64_tr_b16
+// The accumulator of O^T holds 4 consecutive d of one query per lane: 8-byte stores.  A wave walks `ipw` items (stride 4 inside its
+// block, so the block covers 4 * ipw consecutive (pixel, head) items = whole 128-byte lines of the [.., heads * d] rows) and loads
+// the next item's fragments before it computes the current one.  LDS rows are padded to an odd multiple of 32 bytes: the
+// ds_write_b128 of 8 keys and the transposed reads of 8 keys x 32 bytes are conflict-free.
+template <int D> struct TAttn3Cfg {
+    static constexpr int NCH = (D + 31) / 32;  // 32-wide d chunks of the S^T product
+    static constexpr int NJ = (D + 15) / 16;   // 16-wide d blocks of the O^T product
+    static constexpr int DP = D == 40 ? 48 : (D == 80 ? 80 : 176);
+    static_assert(DP >= 16 * NJ && (DP * 2 / 32) % 2 == 1, "LDS row: >= the columns read, odd multiple of 32 bytes");
+};
 
-    const half_t* kb = sk + il * a.t * D;
-    const half_t* vb = sv + il * a.t * D;
-    float s[16];
+template <int D>
+__global__ __launch_bounds__(256) void tattn3_kernel(const TAttnArgs a, const int ipw) {
+    using C = TAttn3Cfg<D>;
+    __shared__ __attribute__((aligned(16))) half_t vs[4][16 * C::DP];
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // everything derived from the item id stays scalar
+    half_t* myv = vs[wave];
+    const int fr = l15 < a.t ? l15 : a.t - 1;
+    const float c2 = a.scale * 1.4426950408889634f;
+    const half8v zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // per-lane element offsets inside an item (frame fr, d piece 8g); the launcher guarantees 16 * hw * ld < 2^31
+    const int lq = fr * a.hw * a.ldq + 8 * g, lk = fr * a.hw * a.ldk + 8 * g, lv = fr * a.hw * a.ldv + 8 * g;
+    const int lo = fr * a.hw * a.ldo + 4 * g;
+    // the wave's items: first + 4 * i, i < n (wave-uniform); (b, pix, h) advance incrementally
+    const int first = mv_xcd_remap((int)blockIdx.x, (int)gridDim.x) * (4 * ipw) + wave;
+    int n = first < (int)a.items ? ((int)a.items - first + 3) / 4 : 0;
+    n = n < ipw ? n : ipw;
+    int h = first % a.heads, pix = (first / a.heads) % a.hw, b = (first / a.heads) / a.hw;
+
+    half8v q0[C::NCH], k0[C::NCH], v0[C::NCH], q1[C::NCH], k1[C::NCH], v1[C::NCH];
+    half_t *o0 = nullptr, *o1 = nullptr;
+    auto fetch = [&](half8v* q, half8v* k, half8v* v, half_t** o) {  // loads the item at (b, pix, h), then steps to the wave's next one
+        const long srow = (long)b * a.t * a.hw + pix;
+        const half_t* qs = a.q + srow * a.ldq + h * D;
+        const half_t* ks = a.k + srow * a.ldk + h * D;
+        const half_t* vsrc = a.v + srow * a.ldv + h * D;
+        *o = a.out + srow * a.ldo + h * D;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        s[j] = 0.f;
-        if (j < a.t) {  // block-uniform
-            float acc = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < DCH; ++ch) {
-                const half8v kk = *reinterpret_cast<const half8v*>(kb + j * D + ch * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf((float)qv[ch][e], (float)kk[e], acc);
-            }
-            s[j] = acc;
-        }
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (j < a.t) mx = fmaxf(mx, s[j] * a.scale);
-    float l = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float e = (j < a.t) ? __expf(s[j] * a.scale - mx) : 0.f;
-        s[j] = e;
-        l += e;
-    }
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int ch = 0; ch < DCH; ++ch) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < a.t) {
-                const half8v vv = *reinterpret_cast<const half8v*>(vb + j * D + ch * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = fmaf(s[j], (float)vv[e], o[e]);
+        for (int c = 0; c < C::NCH; ++c) {
+            if (32 * c + 8 * g < D) {
+                q[c] = *reinterpret_cast<const half8v*>(qs + lq + 32 * c);
+                k[c] = *reinterpret_cast<const half8v*>(ks + lk + 32 * c);
+                v[c] = *reinterpret_cast<const half8v*>(vsrc + lv + 32 * c);
+            } else {
+                q[c] = zero8;
+                k[c] = zero8;
+                v[c] = zero8;
             }
         }
-        if (active) {
-            half8v w;
+        h += 4;
+        while (h >= a.heads) {
+            h -= a.heads;
+            ++pix;
+        }
+        while (pix >= a.hw) {
+            pix -= a.hw;
+            ++b;
+        }
+    };
+    auto compute = [&](const half8v* q, const half8v* k, const half8v* v, half_t* o) {
+        // ---- S^T = K Q^T ----
+        float4v st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = (half_t)(o[e] * inv);
-            *reinterpret_cast<half8v*>(a.out + qrow * a.ldo + h * D + ch * 8) = w;
+        for (int c = 0; c < C::NCH; ++c) st = __builtin_amdgcn_mfma_f32_16x16x32_f16(k[c], q[c], st, 0, 0, 0);
+        // ---- V rows -> the wave's LDS image ----
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c)
+            if (32 * c + 8 * g < D) *reinterpret_cast<half8v*>(myv + l15 * C::DP + 32 * c + 8 * g) = v[c];
+        // ---- softmax over the keys of query l15 (this lane: keys 4g .. 4g+3) ----
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = (4 * g + r < a.t) ? st[r] * c2 : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
+            l += sc[r];
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const half4v pf = {(half_t)(sc[0] * inv), (half_t)(sc[1] * inv), (half_t)(sc[2] * inv), (half_t)(sc[3] * inv)};
+        // ---- O^T = V^T P^T: every lane of the wave has written its V piece; the DS operations of a wave execute in order ----
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const half_t* vrow = myv + (4 * g + (l15 >> 2)) * C::DP + (l15 & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) {
+            const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vrow + 16 * j));
+            const half4v vt = __builtin_bit_cast(half4v, t);
+            const float4v acc = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (l15 < a.t && 16 * j + 4 * g < D) {
+                const half4v w = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+                *reinterpret_cast<half4v*>(o + lo + 16 * j) = w;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    if constexpr (D > 80) {  // 60 VGPRs of fragments per item: one register set, the other resident waves hide the loads
+        for (int it = 0; it < n; ++it) {
+            fetch(q0, k0, v0, &o0);
+            compute(q0, k0, v0, o0);
+        }
+        return;
+    }
+    if (n > 0) fetch(q0, k0, v0, &o0);
+    for (int it = 0; it < n; it += 2) {  // two register sets: the next item's loads are in flight while this one computes
+        if (it + 1 < n) fetch(q1, k1, v1, &o1);
+        compute(q0, k0, v0, o0);
+        if (it + 1 < n) {
+            if (it + 2 < n) fetch(q0, k0, v0, &o0);
+            compute(q1, k1, v1, o1);
         }
     }
 }
@@ -980,13 +994,16 @@ extern "C" int mv_temporal_attention_f16(const void* q, const void* k, const voi
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.b = b; a.t = t; a.hw = hw; a.heads = heads; a.d = d;
     a.scale = scale; a.items = (long)b * hw * heads;
     hipStream_t s = (hipStream_t)stream;
-    // v2 pays where the item count is large (level 0: 65 536 items of d = 40: 141 -> 98 us); at d = 80 / 160 its small
-    // blocks under-fill the CUs (measured 94 vs 80 us and 132 vs 44 us, profiles/r01f) and v1 stays
-    if (t <= 16 && d == 40) {
-        const size_t smem = (size_t)2 * 640 * t * sizeof(half_t);  // IPB * D == 640 in every configuration (<= 40 KB)
-        if (d == 40) hipLaunchKernelGGL((tattn2_kernel<40, 16>), dim3((unsigned)((a.items + 15) / 16)), dim3(256), smem, s, a);
-        else if (d == 80) hipLaunchKernelGGL((tattn2_kernel<80, 8>), dim3((unsigned)((a.items + 7) / 8)), dim3(128), smem, s, a);
-        else hipLaunchKernelGGL((tattn2_kernel<160, 4>), dim3((unsigned)((a.items + 3) / 4)), dim3(64), smem, s, a);
+    // T <= 16 at the UNet's head widths: the MFMA kernel; items per wave sized so that the grid still fills the 256 CUs
+    if (t <= 16 && (d == 40 || d == 80 || d == 160) && a.items < 0x7fffffffL &&
+        16L * hw * ldq < 0x7fffffffL && 16L * hw * ldk < 0x7fffffffL && 16L * hw * ldv < 0x7fffffffL && 16L * hw * ldo < 0x7fffffffL) {
+        int ipw = (int)(a.items / 8192);
+        ipw = ipw < 1 ? 1 : (ipw > 8 ? 8 : ipw);
+        const long per_block = 4L * ipw;
+        const unsigned grid = (unsigned)((a.items + per_block - 1) / per_block);
+        if (d == 40) hipLaunchKernelGGL((tattn3_kernel<40>), dim3(grid), dim3(256), 0, s, a, ipw);
+        else if (d == 80) hipLaunchKernelGGL((tattn3_kernel<80>), dim3(grid), dim3(256), 0, s, a, ipw);
+        else hipLaunchKernelGGL((tattn3_kernel<160>), dim3(grid), dim3(256), 0, s, a, ipw);
         MV_CHECK_LAUNCH("mv_temporal_attention_f16");
         return MV_OK;
     }

@@ -1,7 +1,7 @@
 // norm.hip -- GroupNorm(32)(+SiLU) over channels-last tensors and LayerNorm over the channel dim (gfx950).
 //
 // Both are HBM-bound streaming kernels: 16-byte (8 x fp16) vector loads, fp32 statistics, 64-lane
-// shuffle reductions.  GroupNorm runs as three launches on one stream:
+// shuffle reductions.  GroupNorm runs as three launches on one stream (small tensors: one, see gn_small_kernel):
 //   1. gn_stats    : per (item, row-split): per-CHANNEL sum / sum-of-squares (fp32; per-channel first because on the up path the
 //                    input is the channel concat of two tensors and groups of 30 / 60 channels straddle both the 8-channel
 //                    vectors and the concat seam), folded to per-GROUP partials [item][split][group][2] inside the block.
@@ -194,10 +194,136 @@ __global__ void gn_apply_kernel(const GnArgs a) {
             norm(*reinterpret_cast<const half8v*>(gn_src(a, item, r, o)));
 }
 
+// ---- small tensors (the 16x16 / 8x8-latent levels, C = 1280 / 2560): ONE launch ---------------------------------------------------
+// One block per (item, group) when the group is a whole number of 8-channel octets that does not straddle the concat seam and its
+// slab (rows x C/groups channels) is small.  Thread (row lane, octet): a fixed octet of the group, rows rl, rl + rpp, ... -- no index
+// arithmetic in the loops.  The block sums its slab (fp32, fixed order: per-thread partials over its rows, xor tree, waves in
+// order), derives mean / rstd in double and normalises.  Slabs of <= KEEP rows per thread stay in registers between the two
+// passes (one trip to memory); larger ones are re-read (L2).  The three-launch form costs ~25 us on these tensors (three kernel
+// boundaries around ~3 us of streaming).
+template <int NT, int KEEP>
+__global__ __launch_bounds__(NT) void gn_small_kernel(const GnArgs a) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[2][NW];
+    __shared__ float stat[2];
+    const int C = a.oc * 8;
+    const int cpg = C / a.groups, opg = cpg >> 3;     // channels / octets per group
+    const int gI = blockIdx.x % a.groups;
+    const long item = blockIdx.x / a.groups;
+    const int rpp = NT / opg;                          // rows per pass of the block
+    const int rl = threadIdx.x / opg, o = gI * opg + (int)(threadIdx.x - rl * opg);
+    const bool live = rl < rpp;
+    const int rows = (int)a.rows;
+    const bool second = o * 8 >= a.c1;
+    const long ld = second ? a.ld2 : a.ld1;
+    const half_t* src = (second ? a.x2 + (o * 8 - a.c1) : a.x1 + o * 8) + item * a.rows * ld;
+    const bool in_regs = rows <= KEEP * rpp;           // block-uniform
+    half8v keep[KEEP];
+    float s = 0.f, ss = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int row = rl + k * rpp;
+            if (live && row < rows) keep[k] = *reinterpret_cast<const half8v*>(src + row * ld);
+            else keep[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)keep[k][j];
+                s += f;
+                ss += f * f;
+            }
+        }
+    } else if (live) {
+        for (int r0 = rl; r0 < rows; r0 += 4 * rpp) {
+            half8v v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + u * rpp;
+                v[u] = row < rows ? *reinterpret_cast<const half8v*>(src + row * ld) : half8v{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = (float)v[u][j];
+                    s += f;
+                    ss += f * f;
+                }
+            }
+        }
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < NW; ++w) {
+            s1 += (double)red[0][w];
+            s2 += (double)red[1][w];
+        }
+        const double n = (double)cpg * (double)a.rows;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    if (!live) return;
+    const float mean = stat[0], rstd = stat[1];
+    const half8v gm = *reinterpret_cast<const half8v*>(a.gamma + o * 8);
+    const half8v bt = *reinterpret_cast<const half8v*>(a.beta + o * 8);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = rstd * (float)gm[j];
+        sh[j] = (float)bt[j] - mean * sc[j];
+    }
+    half_t* dst = a.y + item * a.rows * a.ldy + o * 8;
+    auto put = [&](const half8v v, int row) {
+        half8v w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * sc[j] + sh[j];
+            if (a.silu) f = mv_silu(f);
+            w[j] = (half_t)f;
+        }
+        *reinterpret_cast<half8v*>(dst + (long)row * a.ldy) = w;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int row = rl + k * rpp;
+            if (row < rows) put(keep[k], row);
+        }
+    } else {
+        for (int r0 = rl; r0 < rows; r0 += 4 * rpp) {
+            half8v v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + u * rpp;
+                v[u] = row < rows ? *reinterpret_cast<const half8v*>(src + row * ld) : half8v{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + u * rpp;
+                if (row < rows) put(v[u], row);
+            }
+        }
+    }
+}
+
 // ---- LayerNorm: one wave per group of R rows, up to 3 octets per lane and row (C <= 1536) ----
 // All R rows' loads are issued before any is reduced: with one row per wave a lane had a single 16-byte load in flight
 // (C = 320) and the kernel ran at half the HBM rate.  Per row the arithmetic (and its order) is unchanged.
-template <int NO, int kLnRows>  // kLnRows = R: 4 at C <= 512 (one octet per lane), else 2
+template <int NO, int kLnRows>  // kLnRows = R: 8 at C <= 512 (one octet per lane), else 4
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, half_t* y, int ldy, long rows, int c,
                                                         const half_t* gamma, const half_t* beta, float eps) {
     const int lane = threadIdx.x & 63;
@@ -300,6 +426,22 @@ extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int3
     a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta; a.y = (half_t*)y; a.ldy = ldy; a.silu = silu;
     a.groups = num_groups; a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
+    {   // small slabs: one launch (see gn_small_kernel)
+        const int cpg = C / num_groups;
+        const long slab_bytes = rows * (long)cpg * 2;
+        const int opg = cpg / 8;
+        // measured (profiles/r02i): a slab that fits the block's registers (<= 8 rows per thread of a 1024-thread block) beats the
+        // three launches; a larger one (the temporal norms of the 16x16 level: 2 items x 32 groups = 64 blocks re-reading 266 KB
+        // each) does not -- 34 us against ~25 -- and keeps the three-launch form
+        if (cpg % 8 == 0 && cpg <= 512 && c1 % cpg == 0 && rows <= 8L * (1024 / (opg > 0 ? opg : 1)) && slab_bytes <= 320 * 1024 &&
+            n_items * num_groups <= 0x7fffffffL) {
+            const dim3 grid((unsigned)(n_items * num_groups));
+            if (rows <= 8L * (256 / opg)) hipLaunchKernelGGL((gn_small_kernel<256, 8>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gn_small_kernel<1024, 8>), grid, dim3(1024), 0, s, a);
+            MV_CHECK_LAUNCH("mv_groupnorm_f16(small)");
+            return MV_OK;
+        }
+    }
     // LDS: [rl][C][2] floats = 64 bytes per thread for the row-lane fold
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), (size_t)bs * 16 * sizeof(float), s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(stats)");
@@ -318,15 +460,17 @@ extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy
     MV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && rows > 0, "mv_layernorm_f16: bad leading dims / rows");
     hipStream_t s = (hipStream_t)stream;
     const int oc = c / 8;
-    const int rpw = oc <= 64 ? 4 : 2;  // rows per wave (4 waves per block)
+    // rows per wave (4 waves per block): at C = 320 only 40 of a wave's 64 lanes hold an octet, so a wave keeps 8 rows = 8 loads
+    // per lane in flight (4 rows left the kernel at ~4 TB/s on the 106 496 x 320 level-0 tensors)
+    const int rpw = oc <= 64 ? 8 : 4;
     const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
     const half_t* xp = (const half_t*)x;
     half_t* yp = (half_t*)y;
     const half_t* g = (const half_t*)gamma;
     const half_t* b = (const half_t*)beta;
-    if (oc <= 64) hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
-    else if (oc <= 128) hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
-    else hipLaunchKernelGGL((layernorm_kernel<3, 2>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    if (oc <= 64) hipLaunchKernelGGL((layernorm_kernel<1, 8>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    else if (oc <= 128) hipLaunchKernelGGL((layernorm_kernel<2, 4>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<3, 4>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
     MV_CHECK_LAUNCH("mv_layernorm_f16");
     return MV_OK;
 }

@@ -150,6 +150,28 @@ static inline sim_float4 sim_mfma_16x16x32_f16(sim_half8 a, sim_half8 b, sim_flo
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 sim_mfma_16x16x32_f16
+// ---- MFMA 16x16x16 f16: lane (row = l & 15, group g = l >> 4) holds k = 4g .. 4g+3 of its A / B row ----
+typedef _Float16 sim_half4 __attribute__((ext_vector_type(4)));
+static inline sim_float4 sim_mfma_16x16x16_f16(sim_half4 a, sim_half4 b, sim_float4 c, int, int, int) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = 0; j < 4; ++j) {
+        sim_mfma_a[wave][lane][j] = a[j];
+        sim_mfma_b[wave][lane][j] = b[j];
+    }
+    sim_wave_barrier();
+    const int col = lane & 15, g = lane >> 4;
+    sim_float4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k)
+            acc += (float)sim_mfma_a[wave][(k >> 2) * 16 + row][k & 3] * (float)sim_mfma_b[wave][(k >> 2) * 16 + col][k & 3];
+        d[r] += acc;
+    }
+    sim_wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16f16 sim_mfma_16x16x16_f16
 
 // ---- cross-lane operations (one exchange buffer per wave, two wave barriers per operation) ----
 inline double sim_xchg[16][64];  // 8-byte slots: float, int and double payloads

@@ -485,6 +485,9 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("groupnorm_concat", lambda: case_groupnorm(n=2, rows=130, c1=640, c2=320, seed=41)),
     ("groupnorm_nosilu_eps6", lambda: case_groupnorm(n=2, rows=4096, c1=320, silu=False, eps=1e-6, seed=42)),
     ("groupnorm_c2560", lambda: case_groupnorm(n=2, rows=64, c1=1280, c2=1280, seed=43)),
+    ("groupnorm_one_launch_c1280", lambda: case_groupnorm(n=5, rows=256, c1=1280, seed=44)),
+    ("groupnorm_one_launch_reread", lambda: case_groupnorm(n=2, rows=3328, c1=1280, silu=False, seed=45)),   # temporal, 16x16 level
+    ("groupnorm_seam_inside_group", lambda: case_groupnorm(n=2, rows=256, c1=1280, c2=640, seed=46)),          # 60-channel groups: three launches
     ("layernorm_320", lambda: case_layernorm(c=320)),
     ("layernorm_640", case_layernorm),
     ("layernorm_1280", lambda: case_layernorm(c=1280, seed=51)),

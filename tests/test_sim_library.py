@@ -29,10 +29,16 @@ CASES = {
     "tconv3": "kc.case_tconv3(b=2, t=5, hw=12, c=64)",
     "groupnorm": "kc.case_groupnorm(n=3, rows=50, c1=64)",
     "groupnorm_two_src": "kc.case_groupnorm(n=2, rows=50, c1=64, c2=32, silu=False)",
+    "groupnorm_one_launch": "kc.case_groupnorm(n=2, rows=70, c1=256, c2=256)",          # whole-octet groups: gn_small_kernel
+    "groupnorm_one_launch_16_waves": "kc.case_groupnorm(n=1, rows=1100, c1=1024, silu=False)",   # 1024-thread blocks, slab in registers
+    "groupnorm_one_launch_reread": "kc.case_groupnorm(n=1, rows=2100, c1=1024, silu=False)",     # > 8 rows per thread: second pass re-reads
     "layernorm": "kc.case_layernorm(rows=99, c=64)",
     "attention_self": "kc.case_attention_self(d=40, b=1, t=2, lq=70, cond_idx=1)",
     "attention_cross_ip": "kc.case_attention_cross(d=80, nb=4, t=2, lq=40)",
     "temporal_attention": "kc.case_temporal_attention(b=1, t=13, hw=9, d=40)",
+    "temporal_attention_d80_items_per_wave": "kc.case_temporal_attention(b=2, t=13, hw=1100, d=80)",   # 17 600 items: 2 per wave
+    "temporal_attention_d160_t4": "kc.case_temporal_attention(b=1, t=4, hw=5, d=160)",
+    "temporal_attention_t20_valu": "kc.case_temporal_attention(b=1, t=20, hw=3, d=80)",
     "conv_in_out": "kc.case_conv_in_out()",
     "timestep_embedding": "kc.case_timestep_embedding()",
     "layout_and_misc": "kc.case_layout_and_misc()",
@@ -66,8 +72,8 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "layernorm", "attention_self",
-               "temporal_attention", "window_loop", "cfg_affine_step")
+    default = ("tr16_probe", "gemm", "gemm_geglu", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self",
+               "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
     code = _RUNNER.format(root=sim_lib.ROOT, here=HERE, so=sim_so, expr=CASES[name])
