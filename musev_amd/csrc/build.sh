@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast ${MV_EXTRA_FLAGS:-}"   # MV_EXTRA_FLAGS: experiment builds (e.g. -DMV_TIMELINE)
 mkdir -p build
 pids=()
 for f in lib gemm norm attention elementwise; do

@@ -143,111 +143,131 @@ __device__ __forceinline__ void epilogue_narrow(const GemmArgs& p, float4v (&acc
     }
 }
 
-// LDS-staged epilogue of one wave's (16*TM) x (16*TN) accumulator tile (see the call site).  GEGLU: even tiles hold
-// values, odd tiles gates; the output has 8*TN columns per wave.  Each wave owns a private staging region, so only
-// wave-level ordering is needed between its write and read phases.
-template <int TM, int TN, bool GEGLU, int IT>  // IT = 16-row tiles staged per pass
-__device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc)[TM][TN], float* stg_base, int wave, int mw0,
-                                                int nw0, int lane, float alpha, int Mi) {
-    constexpr int W = GEGLU ? 8 * TN : 16 * TN;  // output columns of the wave tile
-    constexpr int LD = W + 4;                    // floats; +4 keeps the 16-byte row-strided writes conflict-free
-    constexpr int CPR = W / 8;                   // 8-column chunks per row
-    constexpr int ROWS = 16 * IT;
-    constexpr int KI = (ROWS * CPR + 63) / 64;   // read iterations per pass (the last one may be partial)
-    static_assert(TM % IT == 0, "passes must tile the wave rows");
-    float* stg = stg_base + wave * (ROWS * LD);
+// LDS-staged epilogue of one wave's (16*TM) x (16*TN) accumulator tile.  The MFMA accumulator layout gives a lane 4 channels of
+// ONE row (a wave store instruction would touch 16 rows x 32 bytes); staging the tile through LDS turns it into 16-byte-per-lane
+// accesses whose consecutive lanes cover consecutive bytes of a row (residual loads and output stores in whole lines).
+// Block timelines (profiles/r02l) showed the previous form of this epilogue -- fp32 staging, per-store index division, 64-bit
+// address arithmetic and bounds branches, ~1100 VALU instructions per wave, and every pass's residual / row-bias loads waiting
+// (in-order vmcnt) behind the previous pass's stores -- at 6-12 us per 256-row block, a third of a K = 320 launch.  This one:
+//   * one pass = one 16-row accumulator row i, staged as fp16 (value after bias / row bias / alpha / activation, rounded once -- the
+//     rounding torch applies to the layer output before its residual add) into one of two per-wave buffers: pass i+1 is written
+//     BEFORE pass i is read back, so the write -> read turnaround of a pass hides under the conversions of the next one (DS
+//     operations of a wave execute in order; the wave barriers are compiler / simulator ordering only);
+//   * read phase: lane -> (row r0 = lane / CPR, 16-byte chunk lane % CPR) fixed for the whole tile, CPR chunks per row, RPI = 64 / CPR
+//     rows per iteration: no division, LDS and global offsets advance by constants; uniform base pointers + 32-bit lane offsets;
+//   * bias and row bias are already in the accumulators (the K loop starts from them); the residual chunks of pass i+1 are
+//     requested BEFORE the stores of pass i are issued, so waiting for them need not wait for a store; the residual add is a
+//     packed fp16 add (what torch's fp16 `x + residual` computes);
+//   * bounds checks only on edge tiles (`full` is block-uniform).
+// GEGLU: even accumulator tiles hold values, odd tiles gates; the output has 8*TN columns per wave.  Each wave owns a private
+// staging region, so only wave-level ordering is needed between its write and read phases.
+template <int TN, bool GEGLU> struct EpiGeom {
+    static constexpr int W = GEGLU ? 8 * TN : 16 * TN;  // output columns of the wave tile
+    static constexpr int LDW = W + 8;                   // staging row (halfs): conflict-free 8-byte row-strided writes
+    static constexpr int CPR = W / 8;                   // 16-byte chunks per row
+    static constexpr int RPI = 64 / CPR;                // rows per read iteration
+    static constexpr int KI = (16 + RPI - 1) / RPI;     // read iterations per pass
+    static constexpr int WAVE_HALFS = 2 * 16 * LDW;     // two buffers
+};
+
+template <int TM, int TN, bool GEGLU, bool RES>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc)[TM][TN], half_t* stg_base, int wave, int mw0,
+                                                int nw0, int lane, float alpha, int Mi, bool full) {
+    using G = EpiGeom<TN, GEGLU>;
+    constexpr int W = G::W, LDW = G::LDW, CPR = G::CPR, RPI = G::RPI, KI = G::KI;
+    half_t* stg = stg_base + wave * G::WAVE_HALFS;
     const int l15 = lane & 15, g = lane >> 4;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
+    // read-phase geometry of this lane
+    const int r0 = lane / CPR, ch = lane - r0 * CPR;
+    const bool lane_on = r0 < RPI;
+    const int ncol = nw0 + 8 * ch;                       // first output column of this lane's chunk
+    const bool col_ok = full || ncol < Nout;
+    const half_t* rd = stg + (r0 < 16 ? r0 : 0) * LDW + 8 * ch;  // (lanes past the pass rows read row 0, their values are unused)
+    half_t* wr = stg + l15 * LDW + 4 * g;
+    half_t* const cbase = p.c + (long)mw0 * p.ldc + nw0;                                   // wave-uniform
+    const half_t* const rbase = RES ? p.residual + (long)mw0 * p.ldr + nw0 : nullptr;
+    const unsigned coff = (unsigned)(r0 * p.ldc + 8 * ch), roff = (unsigned)(r0 * p.ldr + 8 * ch);
+    const bool silu = p.act == MV_ACT_SILU;
 
-    // per-column terms in the accumulator layout
-    float4v bv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bv[j] = float4v{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            // GEGLU: packed bias index of tile j is (2 * nw0 + 16 j + 4 g); plain: nw0 + 16 j + 4 g
-            const int n = (GEGLU ? 2 * nw0 : nw0) + 16 * j + 4 * g;
-            if (n < p.N) {
-                half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
-                bv[j] = float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-            }
-        }
-    }
-#pragma unroll
-    for (int pass = 0; pass < TM / IT; ++pass) {
-        // ---- residual loads of this pass first (row-contiguous layout), so they fly under the staging writes ----
-        half8v rs[KI];
-        if (!GEGLU && p.residual) {
+    half8v res[2][KI];
+    auto request = [&](int i, half8v* rs) {  // residual chunks of pass i, in the read layout
+        if constexpr (RES) {
 #pragma unroll
             for (int k = 0; k < KI; ++k) {
-                const int idx = lane + 64 * k;
-                const int r = idx / CPR, ch = idx - r * CPR;
-                const int m = mw0 + ROWS * pass + r, n = nw0 + 8 * ch;
+                const int row = r0 + k * RPI;
                 rs[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-                if (idx < ROWS * CPR && m < Mi && n < Nout) rs[k] = *reinterpret_cast<const half8v*>(p.residual + (long)m * p.ldr + n);
+                if (lane_on && row < 16 && col_ok && (full || mw0 + 16 * i + row < Mi))
+                    rs[k] = *reinterpret_cast<const half8v*>(rbase + (roff + (unsigned)((16 * i + k * RPI) * p.ldr)));
             }
         }
-        // ---- write phase ----
+    };
+    auto write_pass = [&](int i) __attribute__((always_inline)) {
+        half_t* wrow = wr + (i & 1) * (16 * LDW);
+        if constexpr (GEGLU) {
 #pragma unroll
-        for (int ii = 0; ii < IT; ++ii) {
-            const int i = pass * IT + ii;
-            const int m = mw0 + 16 * i + l15;
-            float* row = stg + (16 * ii + l15) * LD;
-            if constexpr (GEGLU) {
+            for (int j = 0; j < TN; j += 2) {
+                const float4v v = acc[i][j], gt = acc[i][j + 1];
+                *reinterpret_cast<half4v*>(wrow + 8 * j) = half4v{(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
+                                                                  (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    const float4v v = acc[i][j] + bv[j], gt = acc[i][j + 1] + bv[j + 1];
-                    *reinterpret_cast<float4v*>(row + 8 * j + 4 * g) =
-                        float4v{v[0] * mv_gelu(gt[0]), v[1] * mv_gelu(gt[1]), v[2] * mv_gelu(gt[2]), v[3] * mv_gelu(gt[3])};
+            for (int j = 0; j < TN; ++j) {
+                float4v v = acc[i][j] * alpha;
+                if (silu) {
+                    v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
                 }
-            } else {
-                const half_t* rbp = nullptr;
-                if (p.rowbias && m < Mi) rbp = p.rowbias + (long)(m / p.rows_per_group) * p.ldrb;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float4v v = acc[i][j] + bv[j];
-                    const int n = nw0 + 16 * j + 4 * g;
-                    if (rbp && n < p.N) {
-                        half4v b = *reinterpret_cast<const half4v*>(rbp + n);
-                        v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                    }
-                    v *= alpha;
-                    if (p.act == MV_ACT_SILU) {
-                        v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
-                    }
-                    *reinterpret_cast<float4v*>(row + 16 * j + 4 * g) = v;
-                }
+                *reinterpret_cast<half4v*>(wrow + 16 * j) = half4v{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    request(0, res[0]);
+    write_pass(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int buf = i & 1;
+        // ---- write phase of pass i+1 (other buffer; its last readers, pass i-1, come earlier in program order) ----
         __builtin_amdgcn_wave_barrier();
-        // ---- read phase: lane -> (row, 8-column chunk); consecutive lanes = consecutive 16-byte pieces of a row ----
+        if (i + 1 < TM) write_pass(i + 1);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- the next pass's residual requests go out ahead of this pass's stores ----
+        if (i + 1 < TM) request(i + 1, res[buf ^ 1]);
+        // ---- read phase of pass i: every LDS read of the pass first (lanes past the pass rows read row 0, their values unused) ----
+        const half_t* rrow = rd + buf * (16 * LDW);
+        half8v ov[KI];
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
-            const int idx = lane + 64 * k;
-            const int r = idx / CPR, ch = idx - r * CPR;
-            const int m = mw0 + ROWS * pass + r, n = nw0 + 8 * ch;
-            if (idx >= ROWS * CPR) continue;
-            const float4v f0 = *reinterpret_cast<const float4v*>(stg + r * LD + 8 * ch);
-            const float4v f1 = *reinterpret_cast<const float4v*>(stg + r * LD + 8 * ch + 4);
-            if (m < Mi && n < Nout) {
-                half8v o;
-                if (!GEGLU && p.residual) {
-                    o = half8v{(half_t)(f0[0] + (float)rs[k][0]), (half_t)(f0[1] + (float)rs[k][1]), (half_t)(f0[2] + (float)rs[k][2]),
-                               (half_t)(f0[3] + (float)rs[k][3]), (half_t)(f1[0] + (float)rs[k][4]), (half_t)(f1[1] + (float)rs[k][5]),
-                               (half_t)(f1[2] + (float)rs[k][6]), (half_t)(f1[3] + (float)rs[k][7])};
-                } else {
-                    o = half8v{(half_t)f0[0], (half_t)f0[1], (half_t)f0[2], (half_t)f0[3],
-                               (half_t)f1[0], (half_t)f1[1], (half_t)f1[2], (half_t)f1[3]};
-                }
-                *reinterpret_cast<half8v*>(p.c + (long)m * p.ldc + n) = o;
-            }
+            const int row = r0 + k * RPI;
+            ov[k] = *reinterpret_cast<const half8v*>(rrow + ((lane_on && row < 16) ? k * RPI * LDW : 0));
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the next pass overwrites the staging rows
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int row = r0 + k * RPI;
+            if (!(lane_on && row < 16 && col_ok && (full || mw0 + 16 * i + row < Mi))) continue;
+            half8v o = ov[k];
+            if constexpr (RES) o += res[buf][k];
+            *reinterpret_cast<half8v*>(cbase + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = o;
+        }
+        asm volatile("" ::: "memory");
     }
 }
+
+// Block timeline (experiment builds only, -DMV_TIMELINE; tools/gpu_gemm_timeline.py): thread 0 of every block of the first
+// K slice records the 100 MHz wall clock at entry / prologue issued / first tile landed / K loop done / epilogue issued /
+// stores drained, plus its HW_ID and XCC_ID, into a device array the tool reads back.
+#ifdef MV_TIMELINE
+constexpr int kTlBlocks = 32768;
+__device__ unsigned long long mv_tl_buf[kTlBlocks * 8];
+#define MV_TL(i) do { if (tl_on) tl[i] = wall_clock64(); } while (0)
+#define MV_TL_FLUSH() do { if (tl_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[5] = wall_clock64(); \
+        unsigned long long* o = mv_tl_buf + (size_t)blockIdx.x * 8; for (int i_ = 0; i_ < 6; ++i_) o[i_] = tl[i_]; \
+        o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+#else
+#define MV_TL(i) ((void)0)
+#define MV_TL_FLUSH() ((void)0)
+#endif
 
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
@@ -265,6 +285,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     half_t* sB = sA + NST * BM * BK;                // [NST][BN*BK]
 
     const int tid = threadIdx.x;
+#ifdef MV_TIMELINE
+    unsigned long long tl[6] = {0, 0, 0, 0, 0, 0};
+    const bool tl_on = tid == 0 && blockIdx.y == 0 && blockIdx.x < kTlBlocks;
+#endif
+    MV_TL(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -323,11 +348,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         b_off[j] = ok ? ((unsigned)n * (unsigned)p.K + lsl * 8u) * 2u : kOOB;
     }
 
+    // |alpha| (a device scalar) is requested here so that its latency hides under the prologue
+    const float alpha = p.alpha ? fabsf(*p.alpha) : 1.0f;
+    // the accumulators start from bias + row bias, requested right AFTER the prologue's LDS-DMA issue (in-order vmcnt: waiting for
+    // them is waiting for the first tile, which the K loop does anyway), so the epilogue has no loads ahead of its first LDS write
+    // and nothing is held in registers across the K loop; a split-K slice starts from zero, the reduce kernel adds both.  Lane
+    // (l15, g) holds columns 16 j + 4 g .. + 3 of rows 16 i + l15 (GEGLU: the packed [value tile | gate tile] column order is the
+    // accumulator's own).  The narrow epilogue adds them itself.
     float4v acc[TM][TN];
+    auto init_acc = [&]() __attribute__((always_inline)) {
+        const int nw0 = n0 + wn * 16 * TN;
+        const bool init = q.wide && p.nsplit <= 1;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            float4v b0 = float4v{0.f, 0.f, 0.f, 0.f};
+            const int n = nw0 + 16 * j + 4 * g;
+            if (init && p.bias && n < p.N) {
+                const half4v b = *reinterpret_cast<const half4v*>(p.bias + n);
+                b0 = float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < TM; ++i) acc[i][j] = b0;
+        }
+        if (init && p.rowbias) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * 16 * TM + 16 * i + l15;
+                const half_t* rbp = p.rowbias + (long)((m < Mi ? m : Mi - 1) / p.rows_per_group) * p.ldrb + nw0 + 4 * g;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (nw0 + 16 * j + 4 * g < p.N) {
+                        const half4v b = *reinterpret_cast<const half4v*>(rbp + 16 * j);
+                        acc[i][j] += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                    }
+                }
+            }
+        }
+    };
 
     // K tiles of this block: all of them, or the slice blockIdx.y of a split-K launch
     const int nk_all = (p.K + BK - 1) / BK;
@@ -444,6 +501,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
                 issue(t0, kt0 + t0);
             }
         }
+        MV_TL(1);
+        init_acc();
         int cur = 0;
         for (int kt = kt0; kt < nk; ++kt) {
             int younger = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight
@@ -464,6 +523,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifdef MV_TIMELINE
+            if (kt == kt0) MV_TL(2);
+#endif
             if (kt + NST - 1 < nk) {
                 prepare();
                 issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);  // (cur + NST - 1) % NST: the stage tile kt-1 just left
@@ -512,6 +574,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         };
         prepare();
         issue(0, kt0);
+        init_acc();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         end_slot();                   // tile kt0 is visible to every wave
         if (grp == 1) end_slot();     // the trailing group runs one slot behind
@@ -543,7 +606,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     } else {
         prepare();
         issue(0, kt0);
+        MV_TL(1);
+        init_acc();
         __syncthreads();  // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+        MV_TL(2);
         for (int kt = kt0; kt < nk - 1; ++kt) {
             const int cur = (kt - kt0) & 1;
             prepare();
@@ -555,6 +621,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     }
 
     // ---- epilogue ----
+    MV_TL(3);
     const int nw0 = n0 + wn * 16 * TN;
     const int mw0 = m0 + wm * 16 * TM;
     if (p.nsplit > 1) {
@@ -572,25 +639,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         }
         return;
     }
-    const float alpha = p.alpha ? fabsf(*p.alpha) : 1.0f;
     if (q.wide) {
-        // LDS-staged: the MFMA accumulator layout gives a lane 4 channels of ONE row (a wave store instruction would
-        // touch 16 rows x 32 bytes); staging the fp32 tile through LDS turns it into 16-byte-per-lane accesses whose
-        // consecutive lanes cover consecutive bytes of a row (residual loads and output stores in whole 128-byte lines).
-        __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused
-        float* stg = reinterpret_cast<float*>(smem);
-        // (the launcher sizes the dynamic LDS as max(operand stages, this staging area))
-        // 16-row tiles staged per pass: the 128-row wave tiles of the 256-row blocks sit at the 256-register cap, where the
-        // residual prefetch of a 32-row pass (20 registers) spilled an accumulator to scratch; 16-row passes keep it in registers
-        constexpr int EIT = (TM >= 8) ? 1 : 2;
+        __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused as the staging buffers
+        half_t* stg = reinterpret_cast<half_t*>(smem);  // (the launcher sizes the dynamic LDS as max(operand stages, staging area))
+        const bool full = m0 + BM <= Mi && n0 + BN <= p.N;
         if (p.geglu) {
-            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, EIT>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi);
+            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, false>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi, full);
+        } else if (p.residual) {
+            epilogue_staged<TM, TN, false, true>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full);
         } else {
-            epilogue_staged<TM, TN, false, EIT>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi);
+            epilogue_staged<TM, TN, false, false>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full);
         }
+        MV_TL(4);
+        MV_TL_FLUSH();
         return;
     }
     epilogue_narrow<TM, TN>(p, acc, mw0, nw0, lane, alpha, Mi);
+    MV_TL(4);
+    MV_TL_FLUSH();
 }
 
 // split-K second pass: out = epilogue(sum over slices, in slice order) -- one thread per 4 consecutive columns of a row
@@ -623,6 +689,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     *reinterpret_cast<half4v*>(p.c + m * p.ldc + n) = half4v{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
 }
 
+#ifdef MV_TIMELINE
+}  // namespace
+extern "C" int mv_debug_timeline(void* host, int n_blocks) {
+    if (n_blocks > kTlBlocks) n_blocks = kTlBlocks;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mv_tl_buf), (size_t)n_blocks * 8 * sizeof(unsigned long long)) == hipSuccess ? n_blocks : -1;
+}
+namespace {
+#endif
+
 int mv_num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -637,8 +713,8 @@ template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
     constexpr int smem_ops = (SCHED == 3 ? 3 * 64 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
-    // the LDS-staged epilogue reuses the operand LDS: 32 (or 16) fp32 rows of (16 TN + 4) floats per wave must fit as well
-    constexpr int smem_epi = WGM * WGN * ((TM >= 8) ? 16 : 32) * (16 * TN + 4) * 4;
+    // the LDS-staged epilogue reuses the operand LDS: two 16-row fp16 buffers of (16 TN + 8) halfs per wave must fit as well
+    constexpr int smem_epi = WGM * WGN * EpiGeom<TN, false>::WAVE_HALFS * (int)sizeof(half_t);
     constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
     GemmArgs2 a = a0;
