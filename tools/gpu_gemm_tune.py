@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--flavour", default="musev")
     ap.add_argument("--no-split", action="store_true", help="skip the forced split-K sweeps")
+    ap.add_argument("--max-cfg", type=int, default=-1, help="only catalogue ids <= this (default: all)")
     args = ap.parse_args()
     import bench
     from musev_amd import _lib, ops
@@ -78,6 +79,8 @@ def main():
     combos = [(-2, 0)] + [(c, 1) for c in range(n_cfg)] + [(c, s) for c in split_cfgs for s in (2, 4, 8)]
     if args.no_split:
         combos = [cs for cs in combos if cs[1] <= 1]
+    if args.max_cfg >= 0:
+        combos = [cs for cs in combos if cs[0] <= args.max_cfg]
     table = {}   # key -> {"n": launches, "ms": {(cfg, splitk): mean ms per launch}}
     ref_out = None
     for cfg, splitk in combos:
