@@ -20,8 +20,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row.get("Kernel_Name", "")
-                fam = ("gemm" if "gemm" in name else "attn" if "attn_kernel" in name or "attn2_kernel" in name else
-                       "tattn" if "tattn" in name else "groupnorm" if "gn_" in name else "layernorm" if "layernorm" in name else "other")
+                fam = ("gemm" if "gemm" in name or "splitk_reduce" in name else "tattn" if "tattn" in name else
+                       "attn" if "attn_kernel" in name or "attn3_kernel" in name else
+                       "groupnorm" if "gn_" in name else "layernorm" if "layernorm" in name else "other")
                 agg[fam][0] += 1
                 agg[fam][1] += float(row.get("Counter_Value", 0.0))
     out[counter] = {k: {"launches": v[0], "sum_kb": v[1], "avg_kb": v[1] / max(v[0], 1)} for k, v in agg.items()}
