@@ -89,6 +89,9 @@ class ParallelDenoiser:
         return [c[0] for c in gc]
 
     @torch.no_grad()
+    def _unet_dtype(self) -> torch.dtype:
+        return _first_param_dtype(self.unet)
+
     def __call__(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, *, num_inference_steps: int = 20,
                  guidance_scale: float = 7.5, condition_latents: Optional[torch.Tensor] = None, motion_speed: float = 8.0,
                  unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
@@ -257,7 +260,8 @@ class ParallelDenoiser:
                 works.clear()
                 ops.window_units_reduce(recv.view(max_units * world, win_len * hw, c), cover, eps_acc)  # table order -> bit-identical replicas
             sched.loop_update(lat, eps_acc, counter, guidance[step], step, t)
-            sched.consume_step_noise((1, c, T, h, w), latents.dtype, dev, generator, noise_type, w_ind_noise)
+            # the reference draws this (unused) tensor with the model output's dtype = the UNet's (:120-131), whatever the caller's latents are
+            sched.consume_step_noise((1, c, T, h, w), self._unet_dtype(), dev, generator, noise_type, w_ind_noise)
             if callback is not None:
                 callback(step, t, lat)
 
@@ -367,6 +371,12 @@ def _ident(v) -> tuple:
     if isinstance(v, (list, tuple)):
         return tuple(_ident(e) for e in v)
     return (repr(v),)
+
+
+def _first_param_dtype(module) -> torch.dtype:
+    for prm in module.parameters():
+        return prm.dtype
+    return torch.float16
 
 
 def _pack_epoch() -> int:

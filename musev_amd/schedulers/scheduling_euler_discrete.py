@@ -53,6 +53,34 @@ class EulerDiscreteScheduler:
         self.num_inference_steps: Optional[int] = None
 
     # ---- diffusers interface -------------------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config, **overrides) -> "EulerDiscreteScheduler":
+        """``EulerDiscreteScheduler.from_config(pipeline.scheduler.config)`` (pipeline_controlnet_predictor.py:258-261): ``config`` is
+        another scheduler's config (a mapping or an object with attributes); keys this constructor does not know are ignored,
+        as diffusers' ConfigMixin does."""
+        import inspect
+        names = [n for n in inspect.signature(cls.__init__).parameters if n != "self"]
+        get = (lambda k: config[k]) if isinstance(config, dict) else (lambda k: getattr(config, k))
+        has = (lambda k: k in config) if isinstance(config, dict) else (lambda k: hasattr(config, k))
+        kw = {n: get(n) for n in names if has(n)}
+        kw.update({k: v for k, v in overrides.items() if k in names})
+        return cls(**kw)
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, generator=None, noise_type: str = "random",
+             w_ind_noise: float = 0.5, return_dict: bool = False):
+        """One Euler step with s_churn = 0 on plain tensors (musev/schedulers/scheduling_euler_discrete.py:47-167): the per-step
+        noise is drawn with ``model_output``'s dtype and shape (:120-131) -- it only advances ``generator`` -- then
+        ``prev = sample + model_output * (sigma_next - sigma)`` in fp32, cast back to ``model_output``'s dtype.  The loop itself uses
+        the fused ``loop_update``; this is the drop-in for callers that step the scheduler themselves."""
+        i = self._index_of(timestep)
+        self.consume_step_noise(model_output.shape, model_output.dtype, model_output.device, generator, noise_type, w_ind_noise)
+        sigma, sigma_next = float(self.sigmas[i]), float(self.sigmas[i + 1])
+        prev = (sample.float() + model_output.float() * (sigma_next - sigma)).to(model_output.dtype)
+        pred_original = (sample.float() - sigma * model_output.float()).to(model_output.dtype)
+        if return_dict:
+            return SimpleNamespace(prev_sample=prev, pred_original_sample=pred_original)
+        return (prev, pred_original)
+
     @property
     def init_noise_sigma(self) -> float:
         max_sigma = float(self.sigmas.max())

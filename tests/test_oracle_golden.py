@@ -269,3 +269,36 @@ def test_oracle_poseguider_matches_reference(name):
     want = torch.from_numpy(gold["out"])
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < 2e-5
+
+
+def test_euler_from_config_and_step_match_reference_steps():
+    """drop-in surface the predictor uses (pipeline_controlnet_predictor.py:258-261): ``EulerDiscreteScheduler.from_config(other.config)``
+    (unknown keys ignored) and a plain-tensor ``step`` -- checked against the steps recorded from the reference's scheduler, and the
+    per-step noise is drawn with the MODEL OUTPUT's dtype (scheduling_euler_discrete.py:120-131)"""
+    from types import SimpleNamespace
+    from musev_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
+    gold = np.load(os.path.join(GOLD, "reference_euler.npz"))
+    ddim = DDIMScheduler()
+    cfg = dict(vars(ddim.config), timestep_spacing="leading", steps_offset=1, clip_sample=False, set_alpha_to_one=False)
+    for config in (cfg, SimpleNamespace(**cfg)):
+        h = EulerDiscreteScheduler.from_config(config)
+        assert h.config.timestep_spacing == "leading" and h.config.steps_offset == 1 and not hasattr(h.config, "clip_sample")
+        h.set_timesteps(20)
+        assert np.array_equal(h.sigmas.numpy(), gold["leading_sigmas"])
+    keys = [k for k in gold.files if k.startswith("leading_")]
+    x = torch.from_numpy(gold["leading_x0"])
+    eps_keys = sorted(k for k in keys if k.startswith("leading_eps"))
+    out_keys = sorted(k for k in keys if k.startswith("leading_x") and k != "leading_x0")
+    if eps_keys and len(eps_keys) == len(out_keys):
+        for i, (ek, ok) in enumerate(zip(eps_keys, out_keys)):
+            prev, _ = h.step(torch.from_numpy(gold[ek]), h.timesteps[i], x)
+            assert (prev - torch.from_numpy(gold[ok])).abs().max().item() < 1e-5, i
+            x = prev
+    # generator consumption follows the model output's dtype: an fp16 model output consumes what the reference's fp16 draw consumes
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(20)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    mo = torch.zeros(1, 4, 6, 8, 8, dtype=torch.float16)
+    s.step(mo, s.timesteps[0], torch.zeros_like(mo, dtype=torch.float32), generator=g1)
+    torch.randn(mo.shape, generator=g2, dtype=torch.float16)
+    assert torch.equal(g1.get_state(), g2.get_state())
