@@ -374,9 +374,11 @@ def _ident(v) -> tuple:
 
 
 def _first_param_dtype(module) -> torch.dtype:
-    for prm in module.parameters():
-        return prm.dtype
-    return torch.float16
+    params = getattr(module, "parameters", None)
+    if callable(params):
+        for prm in params():
+            return prm.dtype
+    return torch.float16  # (the UNet of this package computes in fp16)
 
 
 def _pack_epoch() -> int:
