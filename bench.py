@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path on a 1-GPU box: every rank uses cuda:0, collectives over gloo "
+                         "(RCCL refuses two ranks on one device).  The line is marked; its timings are not multi-GPU numbers.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,13 +256,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    if args.rehearse_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         group = dist.group.WORLD
 
     from musev_amd import ops
@@ -452,6 +460,8 @@ def main():
                        "output_finite": finite},
             "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1,
         }
+        if args.rehearse_shared_gpu:
+            line["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo: exercises the N > 1 code path only, the timings are not multi-GPU numbers"
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

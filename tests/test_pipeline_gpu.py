@@ -234,3 +234,81 @@ def test_uniform_v2_unequal_windows_on_the_gpu():
     assert torch.equal(got, got2)
     err = (got.float().cpu() - want).abs().max().item()
     assert err < 1e-2, f"|delta latent|max = {err}"
+
+
+# ---- the multi-rank path on the real kernels: N gloo ranks sharing the one GPU of the test box --------------------------------------
+# (RCCL refuses two ranks on one device; gloo moves HIP tensors through the host.  What this covers that the CPU gloo tests with
+# kernel doubles cannot: unit sharding + per-slot async all-gather + mv_window_units_reduce + captured graphs per rank, on the device.)
+def _shared_gpu_worker(rank, world, port, ret, T, win, ov, schedule, scheduler):
+    import os
+    import torch.distributed as dist
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        cfg = unet3d.flavour_config("musev", **ARCH)
+        sd = unet3d.init_state_dict(cfg, 3)
+        g = torch.Generator().manual_seed(11)
+        latents = torch.randn(1, 4, T, 8, 8, generator=g)
+        cond = 0.18215 * torch.randn(1, 4, 1, 8, 8, generator=g)
+        prompt = torch.randn(2, 77, 768, generator=g)
+        sched = None
+        if scheduler == "euler":
+            from musev_amd.schedulers import EulerDiscreteScheduler
+            sched = EulerDiscreteScheduler()
+            sched.set_timesteps(20)
+            latents = latents * sched.init_noise_sigma
+        unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+        den = ParallelDenoiser(unet, scheduler=sched, context_frames=win, context_overlap=ov, context_schedule=schedule)
+        kw = dict(num_inference_steps=20, max_steps=3, guidance_scale=3.5, motion_speed=8.0, condition_latents=cond.to(dev))
+        outs = [den(latents.to(dev), prompt.to(dev), group=dist.group.WORLD, **kw) for _ in range(2)]  # second call replays the graphs
+        torch.cuda.synchronize()
+        ret[rank] = [o.float().cpu() for o in outs]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,win,ov,schedule,scheduler", [(2, 16, 6, 2, "uniform", "ddim"), (3, 15, 6, 2, "uniform_v2", "ddim"),
+                                                             (2, 12, 6, 2, "uniform", "euler")])
+def test_ranks_sharing_the_gpu_match_the_single_process_loop(world, T, win, ov, schedule, scheduler):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_shared_gpu_worker, args=(world, port, ret, T, win, ov, schedule, scheduler), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.equal(ret[r][0], ret[r][1]), "graph replay changed the result"
+        assert torch.equal(ret[0][0], ret[r][0]), "replicated latents diverged between ranks"
+    # the same loop in ONE process (units accumulated locally instead of exchanged)
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    dev = torch.device("cuda", 0)
+    cfg = unet3d.flavour_config("musev", **ARCH)
+    sd = unet3d.init_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(11)
+    latents = torch.randn(1, 4, T, 8, 8, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, 8, 8, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    sched = None
+    if scheduler == "euler":
+        from musev_amd.schedulers import EulerDiscreteScheduler
+        sched = EulerDiscreteScheduler()
+        sched.set_timesteps(20)
+        latents = latents * sched.init_noise_sigma
+    unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+    den = ParallelDenoiser(unet, scheduler=sched, context_frames=win, context_overlap=ov, context_schedule=schedule)
+    single = den(latents.to(dev), prompt.to(dev), num_inference_steps=20, max_steps=3, guidance_scale=3.5, motion_speed=8.0,
+                 condition_latents=cond.to(dev)).float().cpu()
+    scale = 14.6 if scheduler == "euler" else 1.0
+    err = (ret[0][0] - single).abs().max().item()
+    # same fp32 predictions, summed per frame in a different (but fixed) order than the local scatter-add: fp32 rounding only
+    assert err < 2e-5 * scale, f"sharded vs single-process |delta|max = {err}"
