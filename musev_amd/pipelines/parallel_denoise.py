@@ -61,6 +61,7 @@ def group_units(units: Sequence[Unit]) -> List[Tuple[int, List[int]]]:
 
 class ParallelDenoiser:
     _device_check = True  # tests of the sharding logic (gloo, CPU, fake kernels) switch this off
+    always_exchange = False  # diagnostic: take the multi-rank exchange path in a 1-rank group as well (see __call__)
 
     def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, *, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
@@ -165,10 +166,13 @@ class ParallelDenoiser:
         my_groups = group_units(shards[rank])
         max_units = max(len(s) for s in shards)
         unit_elems = win_len * hw * c
-        send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None
-        recv = torch.empty((max_units, world, win_len * hw, c), dtype=torch.float32, device=dev) if world > 1 else None  # [slot][rank]
+        # the exchange path (send slots -> all-gather -> table-driven reduce); `always_exchange` runs it in a 1-rank group too, which
+        # lets a 1-GPU box drive RCCL through exactly the calls of a multi-GPU run (tests/test_pipeline_gpu.py)
+        exchange = world > 1 or (group is not None and self.always_exchange)
+        send = torch.zeros((max_units, win_len * hw, c), dtype=torch.float32, device=dev) if exchange else None
+        recv = torch.empty((max_units, world, win_len * hw, c), dtype=torch.float32, device=dev) if exchange else None  # [slot][rank]
         cover = None
-        if world > 1:
+        if exchange:
             # (slot, position-in-window) pairs covering every (half, frame), in unit order (= window order: the shards are
             # contiguous slices of the window-major unit list): ONE gather-reduce launch per step replaces world x max_units
             # scatter-adds, and its summation order is the same on every rank (bit-identical replicas)
@@ -219,7 +223,7 @@ class ParallelDenoiser:
         for step, t in enumerate(timesteps):
             if max_steps is not None and step >= max_steps:
                 break
-            if world == 1:
+            if not exchange:
                 eps_acc.zero_()  # (the multi-rank gather-reduce overwrites it)
             t_dev.fill_(float(t))
             # scheduler.scale_model_input (:1911): identity for DDIM, 1/sqrt(sigma^2+1) for Euler; the vision-condition
@@ -241,7 +245,7 @@ class ParallelDenoiser:
                     cn = (controlnet, ctrl_bufs[wl], text_rep_by_len[wl], cond_scale, bool(guess_mode))
                 eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx_by_len[wl], vis_idx, motion_speed,
                                       unet_kwargs, cn)
-                if world == 1:
+                if not exchange:
                     for k, hf in enumerate(hs):
                         ops.window_scatter_add(eps[k * tw * hw:(k + 1) * tw * hw], idx_dev[wi], n_cond, 1, hf, eps_acc, counter, False)
                 else:
@@ -252,7 +256,7 @@ class ParallelDenoiser:
                         works.append(torch.distributed.all_gather_into_tensor(recv[slot].view(-1), send[slot].view(-1), group=group,
                                                                               async_op=True))
                         slot += 1
-            if world > 1:
+            if exchange:
                 for k in range(slot, max_units):  # a rank with fewer units still takes part in every slot's collective
                     works.append(torch.distributed.all_gather_into_tensor(recv[k].view(-1), send[k].view(-1), group=group, async_op=True))
                 for wk in works:

@@ -312,3 +312,53 @@ def test_ranks_sharing_the_gpu_match_the_single_process_loop(world, T, win, ov, 
     err = (ret[0][0] - single).abs().max().item()
     # same fp32 predictions, summed per frame in a different (but fixed) order than the local scatter-add: fp32 rounding only
     assert err < 2e-5 * scale, f"sharded vs single-process |delta|max = {err}"
+
+
+def _rccl_one_rank_worker(rank, port, ret):
+    import os
+    import torch.distributed as dist
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # nccl == RCCL on ROCm
+    try:
+        cfg = unet3d.flavour_config("musev", **ARCH)
+        sd = unet3d.init_state_dict(cfg, 3)
+        g = torch.Generator().manual_seed(21)
+        latents = torch.randn(1, 4, 16, 8, 8, generator=g).to(dev)
+        cond = (0.18215 * torch.randn(1, 4, 1, 8, 8, generator=g)).to(dev)
+        prompt = torch.randn(2, 77, 768, generator=g).to(dev)
+        unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+        kw = dict(num_inference_steps=20, max_steps=3, guidance_scale=3.5, motion_speed=8.0, condition_latents=cond)
+        den = ParallelDenoiser(unet, context_frames=6, context_overlap=2)
+        local = den(latents, prompt, **kw).float().cpu()
+        den.always_exchange = True   # same loop through send slots -> RCCL all_gather_into_tensor(async) -> mv_window_units_reduce
+        ex1 = den(latents, prompt, group=dist.group.WORLD, **kw).float().cpu()
+        ex2 = den(latents, prompt, group=dist.group.WORLD, **kw).float().cpu()
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the calls bench.py makes around the timed region
+        dist.barrier()
+        torch.cuda.synchronize()
+        ret["local"], ret["ex1"], ret["ex2"] = local, ex1, ex2
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_path_through_rccl_with_one_rank():
+    """RCCL itself (backend "nccl") cannot be given two ranks on the test box's one GPU; a 1-rank group with
+    ``always_exchange`` still drives every RCCL call of the multi-GPU loop (per-slot async all_gather_into_tensor on the
+    process group's stream, wait = stream dependency, then the table-driven reduce), plus bench.py's barrier / all_reduce"""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_one_rank_worker, args=(port, ret), nprocs=1, join=True)
+    assert torch.equal(ret["ex1"], ret["ex2"])
+    assert (ret["ex1"] - ret["local"]).abs().max().item() < 2e-5
