@@ -24,8 +24,8 @@ real SD-1.5 MuseV architecture, 1.42 B parameters -- no checkpoints or datasets 
 
 Extra JSON objects (tier contract):
   roofline      the dominant kernel (the implicit-GEMM family, MFMA-bound): algorithmic FLOPs per launch / launch
-                duration, measured live with HIP events on the launch stream in an instrumented repeat of the timed
-                steps; plus the whole-step figure (SURVEY.md 8d analytic FLOPs / step time).
+                duration, measured live on the device: one step's launches recorded, then re-issued back to back on the
+                launch stream between one HIP event pair; plus the whole-step figure (SURVEY.md 8d analytic FLOPs / step time).
   cpu_baseline  the oracle (plain torch fp32) timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -313,8 +313,6 @@ def main():
         unet_kwargs["mid_block_additional_residual"] = (0.1 * torch.randn(n_rows, mid[0], mid[1], mid[2], generator=g6)).to(dev, torch.float16)
 
     den = ParallelDenoiser(unet, context_frames=win, context_overlap=4, context_stride=1, context_schedule="uniform")
-    if workload == "config5":
-        den.half_streams = False  # the (b t)-shaped residual tensors cover both CFG halves of a window: one batch-2 forward
     n_windows = len(den.windows(T, DENOISE_STEPS))
     total = args.warmup + args.steps
 
@@ -379,45 +377,59 @@ def main():
             step_flops += unet_flops(args.size, args.size, win + n_cond, len(hs), flavour, n_vis=n_cond)
     per_rank_flops = max(sum(unet_flops(args.size, args.size, win + n_cond, len(hs), flavour, n_vis=n_cond) for _, hs in group_units(s)) for s in shards)
 
+    # every timed step must have been a hipGraph replay (a failed capture raises in ParallelDenoiser; MUSEV_NO_GRAPH=1 is the only
+    # way to get here eager, and then the line says so)
+    graphs = den.use_graphs and den.graph_replays() > 0
+    if den.use_graphs and dev.type == "cuda" and not graphs:
+        raise SystemExit("bench.py: the timed steps did not replay a hipGraph")
+
     roofline = None
     if not args.no_roofline:
-        # instrumented repeat of the same K steps: HIP events around every implicit-GEMM launch on the launch stream
-        ops.GEMM_PROFILE = []
-        den.use_graphs = False   # per-launch events need eager launches (the timed region above replays hipGraphs)
-        den.half_streams = False  # ... issued back to back on ONE stream, so that a launch's duration is its own
+        # Dominant kernel family (every mv_gemm_f16 launch: linear / conv3x3 / tconv3 + split-K reduce), measured on the device:
+        # ONE step is recorded eagerly (descriptor copies, tensors kept alive), then the recorded launches are re-issued back to
+        # back on one stream between ONE pair of HIP events (ops.replay_gemms) -- the host enqueues a launch in microseconds and
+        # the kernels take tens to hundreds, so the elapsed time is the kernels' own plus the dispatcher's back-to-back gaps, the
+        # same thing a hipGraph replay has.  (Round 2 bracketed every eager launch with its own event pair, which put the host's
+        # launch latency inside each "duration": 104 us per launch on the driver's box against 88 us in the rocprofv3 trace.)
+        # The record is taken with the loop's own stream setting, so the problem sizes are the ones the timed region ran (two
+        # batch-1 forwards per window when the CFG halves run on two streams).
+        ops.GEMM_RECORD = []
+        den.use_graphs = False
         sync_all()
-        t0 = time.perf_counter()
-        run_steps(min(args.steps, 4))
+        run_steps(1)
         sync_all()
-        instr_ms = (time.perf_counter() - t0) * 1e3 / min(args.steps, 4)
-        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        rec_all, ops.GEMM_RECORD = ops.GEMM_RECORD, None
+        den.use_graphs = True
         names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
-        agg = {}
-        fam_bytes = 0.0
-        for mode, M, N, K, geglu, e0, e1, nbytes in (r[:8] for r in prof):
-            ms = e0.elapsed_time(e1)
-            a = agg.setdefault(names[mode], [0.0, 0.0, 0])
-            a[0] += 2.0 * M * N * K
-            a[1] += ms
-            a[2] += 1
-            fam_bytes += nbytes
-        fam_flops = sum(a[0] for a in agg.values())
-        fam_ms = sum(a[1] for a in agg.values())
-        fam_n = sum(a[2] for a in agg.values())
+        reps = 3
+        ops.replay_gemms(rec_all, 1)  # warm (clocks, code objects)
+        fam_ms = ops.replay_gemms(rec_all, reps) / reps
+        fam_n = len(rec_all)
+        fam_flops = sum(2.0 * d.M * d.N * d.K for d, _k, _b in rec_all)
+        fam_bytes = float(sum(nb for _d, _k, nb in rec_all))
+        by_mode = {}
+        for mode, nm in names.items():
+            sub = [r for r in rec_all if int(r[0].mode) == mode]
+            if not sub:
+                continue
+            ms = ops.replay_gemms(sub, reps) / reps
+            fl = sum(2.0 * d.M * d.N * d.K for d, _k, _b in sub)
+            by_mode[nm] = {"tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "ms_per_step": ms, "launches_per_step": len(sub)}
+        del rec_all
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {
             "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
             "traffic": measured_traffic(workload)[0], "traffic_unit": "HBM bytes per launch (PMC)",
             "traffic_source": measured_traffic(workload)[1],
+            "method": f"one recorded step's {fam_n} mv_gemm_f16 launches re-issued back to back on one stream, {reps} repetitions between "
+                      "one HIP event pair (device time; no per-launch host gap)",
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
-            "launches_per_step": fam_n / min(args.steps, 4),
+            "launches_per_step": fam_n,
             "avg_launch_ms": fam_ms / max(fam_n, 1),
             "algorithmic_flops_per_launch": fam_flops / max(fam_n, 1),
-            "family_ms_per_step": fam_ms / min(args.steps, 4),
-            "by_mode": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0, "ms_per_step": v[1] / min(args.steps, 4),
-                            "launches_per_step": v[2] / min(args.steps, 4)} for k, v in agg.items()},
-            "instrumented_ms_per_step": instr_ms,
+            "family_ms_per_step": fam_ms,
+            "by_mode": by_mode,
             "whole_step": {"algorithmic_tflop_per_rank_step": per_rank_flops / 1e12,
                            "achieved_tflops_per_gpu": per_rank_flops / (ms_per_step * 1e-3) / 1e12,
                            "frac_of_mfma_peak": per_rank_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
@@ -457,7 +469,7 @@ def main():
                        # strong-scaling workloads: the speed-up this rank count can reach at best = total units / the largest shard
                        "ideal_speedup_vs_1gpu_same_workload": (n_windows * 2) / max(len(s_) for s_ in shards),
                        "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
-                       "output_finite": finite},
+                       "output_finite": finite, "graphs": bool(graphs)},
             "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1,
         }
         if args.rehearse_shared_gpu:

@@ -648,8 +648,9 @@ extern "C" int mv_window_units_reduce(const float* units, int64_t unit_stride, c
 }
 
 extern "C" int mv_softmax_rows_f16(void* x, int64_t ldx, int64_t rows, int32_t cols, void* stream) {
-    MV_REQUIRE(x && rows > 0 && rows < (1L << 31) && cols > 0 && cols % 8 == 0 && cols <= 16384 && ldx % 8 == 0 && ldx >= cols,
-               "mv_softmax_rows_f16: need cols %% 8 == 0, cols <= 16384, ldx %% 8 == 0 (rows=%ld cols=%d ldx=%ld)", (long)rows, cols, (long)ldx);
+    MV_REQUIRE(x && rows > 0 && rows < (1L << 31) && cols > 0 && cols % 8 == 0 && cols <= 16384 && ldx % 8 == 0 && ldx >= cols &&
+                   (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+               "mv_softmax_rows_f16: need a 16-byte aligned x, cols %% 8 == 0, cols <= 16384, ldx %% 8 == 0 (rows=%ld cols=%d ldx=%ld)", (long)rows, cols, (long)ldx);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, (long)ldx, cols);
     MV_CHECK_LAUNCH("mv_softmax_rows_f16");
     return MV_OK;

@@ -31,10 +31,12 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- optional live instrumentation (bench.py): HIP events around every implicit-GEMM launch ---------------------
-# The events are recorded on the stream the kernels are launched on (torch's current stream), so elapsed_time() is
-# the device-side duration of that launch.  Off by default; bench.py turns it on for its roofline pass only.
-GEMM_PROFILE: Optional[list] = None
+# ---- optional launch recorder (bench.py's roofline pass) --------------------------------------------------------------
+# When a list is installed here, every implicit-GEMM launch appends (descriptor copy, tensors kept alive, algorithmic HBM bytes)
+# in launch order IN ADDITION to being launched.  bench.py records one step this way and then re-issues the recorded launches
+# back to back on one stream between ONE pair of HIP events (`replay_gemms`), so that the measured time is device time of the
+# kernels (+ the dispatcher's own back-to-back gaps, which a hipGraph replay has as well) and not host launch latency.
+GEMM_RECORD: Optional[list] = None
 
 
 # Tile configuration / split-K factor forced on every implicit-GEMM launch of this process (tuner and A/B runs; the C library
@@ -45,7 +47,7 @@ GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
 
 
-def _launch_gemm(d: GemmDesc, what: str, dev: torch.device) -> None:
+def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = ()) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
     need = lib.mv_gemm_workspace_bytes(C.byref(d))
@@ -55,20 +57,31 @@ def _launch_gemm(d: GemmDesc, what: str, dev: torch.device) -> None:
     if need > 0:  # split-K slabs: scratch from torch's caching allocator (inside a graph capture: the capture's private pool)
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), need
-    if GEMM_PROFILE is None:
-        check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
-        return
+    check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
+    if GEMM_RECORD is not None:
+        # algorithmic HBM bytes of the launch: every operand read once, the output written once
+        rows_in = int(d.M)
+        if d.mode == MV_GEMM_CONV3X3:
+            rows_in = (int(d.M) // (int(d.hout) * int(d.wout))) * int(d.hin) * int(d.win)
+        cols = int(d.N) // 2 if d.geglu else int(d.N)
+        nbytes = 2 * (rows_in * (int(d.c1) + int(d.c2)) + int(d.N) * int(d.K) + int(d.M) * cols * (2 if d.residual else 1))
+        GEMM_RECORD.append((GemmDesc.from_buffer_copy(d), keep + (ws,), nbytes))
+
+
+def replay_gemms(record: Sequence[tuple], reps: int = 1) -> float:
+    """re-issues recorded implicit-GEMM launches (see GEMM_RECORD) ``reps`` times back to back on the current stream between one
+    pair of HIP events; returns the elapsed device milliseconds of ALL reps.  The host enqueues a launch in a few microseconds and
+    the kernels take tens to hundreds, so the queue never runs dry: the elapsed time is the kernels' own."""
+    lib = _lib.load()
+    st = _stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
+    for _ in range(reps):
+        for d, _keep, _nb in record:
+            check(lib.mv_gemm_f16(C.byref(d), st), "mv_gemm_f16(replay)")
     e1.record()
-    # algorithmic HBM bytes of the launch: every operand read once, the output written once
-    rows_in = int(d.M)
-    if d.mode == MV_GEMM_CONV3X3:
-        rows_in = (int(d.M) // (int(d.hout) * int(d.wout))) * int(d.hin) * int(d.win)
-    cols = int(d.N) // 2 if d.geglu else int(d.N)
-    nbytes = 2 * (rows_in * (int(d.c1) + int(d.c2)) + int(d.N) * int(d.K) + int(d.M) * cols * (2 if d.residual else 1))
-    GEMM_PROFILE.append((int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu), e0, e1, nbytes))
+    e1.synchronize()
+    return e0.elapsed_time(e1)
 
 
 def _on_gpu(t: torch.Tensor) -> bool:
@@ -155,7 +168,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     d.M, d.N, d.K = M, N, K
     d.mode, d.geglu = MV_GEMM_LINEAR, int(geglu)
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, alpha, act, cols)
-    _launch_gemm(d, "mv_gemm_f16", a.device)
+    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha))
     return o
 
 
@@ -193,7 +206,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2
     d.mode, d.stride, d.upsample = MV_GEMM_CONV3X3, stride, int(upsample)
     d.hin, d.win, d.hout, d.wout = h, w_, ho, wo
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, None, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device)
+    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device, (x, x2, w, o, bias, rowbias, residual))
     return o
 
 
@@ -215,7 +228,7 @@ def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=No
     d.M, d.N, d.K = M, N, K
     d.mode, d.t, d.hw = MV_GEMM_TCONV3, t, hw
     _fill_epilogue(d, N, M, bias, None, 0, residual, alpha, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device)
+    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device, (x, w, o, bias, residual, alpha))
     return o
 
 
@@ -315,6 +328,8 @@ def geglu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 def softmax_rows_(x: torch.Tensor) -> torch.Tensor:
     """in-place softmax over the columns of an fp16 [rows, cols] matrix (unit inner stride, any row stride % 8)"""
     x = _mat(x, "x")
+    if x.data_ptr() & 15 or x.stride(0) % 8 or x.shape[1] % 8:
+        raise ValueError("softmax_rows_: x must be 16-byte aligned with cols and row stride in multiples of 8 (16-byte accesses)")
     check(_lib.load().mv_softmax_rows_f16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "mv_softmax_rows_f16")
     return x
 

@@ -68,7 +68,7 @@ class ParallelDenoiser:
                  context_batch_size: int = 1, use_graphs: bool = True):
         self.unet = unet
         # hipGraph capture of the per-window UNet forward (~1 500 kernel launches): replayed once per window and step,
-        # so the host only issues the loop glue.  Falls back to eager launches when capture is unavailable.
+        # so the host only issues the loop glue.  A failed capture raises (MUSEV_NO_GRAPH=1 / use_graphs=False = eager on purpose).
         self.use_graphs = use_graphs and os.environ.get("MUSEV_NO_GRAPH", "0") != "1"  # env knob for per-kernel PMC profiling
         self._graphs: Dict[tuple, "_GraphedForward"] = {}
         # the two CFG halves of a window as two batch-1 forwards on two HIP streams (+2.7 % frames/s at config 2,
@@ -89,10 +89,10 @@ class ParallelDenoiser:
                                     self.context_stride, self.context_overlap, 1)
         return [c[0] for c in gc]
 
-    @torch.no_grad()
     def _unet_dtype(self) -> torch.dtype:
         return _first_param_dtype(self.unet)
 
+    @torch.no_grad()
     def __call__(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, *, num_inference_steps: int = 20,
                  guidance_scale: float = 7.5, condition_latents: Optional[torch.Tensor] = None, motion_speed: float = 8.0,
                  unet_kwargs: Optional[dict] = None, group=None, callback: Optional[Callable] = None,
@@ -350,6 +350,10 @@ class ParallelDenoiser:
         self._graphs[key] = gf  # re-insert: dict order = recency
         return gf(x)
 
+    def graph_replays(self) -> int:
+        """hipGraph replays issued so far by this object's captured forwards (bench.py asserts the timed steps were replays)"""
+        return sum(g.replays for g in self._graphs.values())
+
     def _side_stream(self, dev):
         key = str(dev)
         if key not in self._side:
@@ -358,15 +362,20 @@ class ParallelDenoiser:
 
     @staticmethod
     def _slice_half(v, hs: List[int], halves: int):
-        """conditioning tensors batched over the CFG halves ([uncond, cond] on dim 0) are sliced to the owned halves"""
+        """conditioning tensors batched over the CFG halves are sliced to the owned halves: [uncond, cond] on dim 0, or -- the
+        ControlNet residuals, [(b t), C, h, w] (unet_3d_condition.py:1146-1156) -- b-major blocks of rows on dim 0"""
         if v is None or halves == 1 or len(hs) == halves:
             return v
         if torch.is_tensor(v):
-            return v[hs[0]:hs[0] + 1]
-        return [self_v[hs[0]:hs[0] + 1] for self_v in v]
+            per = v.shape[0] // halves
+            if per * halves != v.shape[0]:
+                raise ValueError(f"a per-half tensor of {v.shape[0]} rows cannot be split into {halves} CFG halves")
+            return v[hs[0] * per:(hs[0] + 1) * per]
+        return [ParallelDenoiser._slice_half(e, hs, halves) for e in v]
 
 
-_PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb")
+_PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb", "down_block_additional_residuals",
+                    "mid_block_additional_residual")
 
 
 def _ident(v) -> tuple:
@@ -407,23 +416,25 @@ class _GraphedForward:
         self.first_result = fn(self.static_in)  # eager warm-up; also the result of this first call
         self.graph = None
         self.static_out = None
+        self.fn = fn
+        self.replays = 0
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
         try:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
             # thread_local: other host threads (the RCCL watchdog of torch.distributed polls events) must not abort a capture
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.static_out = fn(self.static_in)
-            self.graph = g
-        except Exception as ex:  # noqa: BLE001 -- capture is an optimisation; eager launches remain correct
-            import warnings
-            warnings.warn(f"musev_amd: hipGraph capture failed ({ex!r}); running eager")
-            self.graph, self.fn = None, fn
+        except Exception as ex:
+            # a failed capture is an ERROR, not a silent switch to eager launches: the timed path is the graph replay, and a run
+            # that quietly lost it would report numbers of a different code path.  MUSEV_NO_GRAPH=1 (or use_graphs=False) is the
+            # explicit way to run eager.
             torch.cuda.synchronize()
-        self.fn = fn
+            raise RuntimeError(f"musev_amd: hipGraph capture of the window forward failed ({ex!r}); set MUSEV_NO_GRAPH=1 to run "
+                               "eager launches instead") from ex
+        self.graph = g
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        if self.graph is None:
-            return self.fn(x)
         self.static_in.copy_(x)
         self.graph.replay()
+        self.replays += 1
         return self.static_out

@@ -16,18 +16,26 @@ __all__ = ["decode_latents", "multi_shot_denoise"]
 _MAX_CALL_BYTES = 3 << 29  # 1.5 GiB: every operand of one kernel call must span < 2 GiB (32-bit buffer offsets)
 
 
+def max_frames_per_call(block_out_channels, h: int, w: int) -> int:
+    """frames one ``vae.decode`` call may carry so that every kernel operand stays below the 2 GiB limit.  The widest activation
+    at resolution level k (8h / 2^k x 8w / 2^k) is NOT C_k wide: an up block's Upsample2D emits the next finer resolution with the
+    COARSER level's channel count (up_blocks[2] of the SD VAE: 8h x 8w x block_out_channels[1] = 256 channels, which feeds
+    up_blocks[3].resnets[0].norm1 / conv1 / conv_shortcut) -- level k holds block_out_channels[min(k + 1, last)] channels."""
+    last = len(block_out_channels) - 1
+    per_frame = max(((8 * h) >> k) * ((8 * w) >> k) * block_out_channels[min(k + 1, last)] * 2 for k in range(last + 1))
+    return max(1, _MAX_CALL_BYTES // per_frame)
+
+
 @torch.no_grad()
 def decode_latents(vae, latents: torch.Tensor, decoder_t_segment: int = 200) -> torch.Tensor:
     """latents [b, c, t, h, w] -> video [b, 3, t, 8h, 8w] fp32 in [0, 1] (the reference returns the same values as a numpy array):
     ``latents / scaling_factor`` -> ``vae.decode`` -> ``(x / 2 + 0.5).clamp(0, 1)``, in slices of ``decoder_t_segment`` frames
     along t exactly as the reference (:2157-2171).  A slice is further cut so that the largest activation of one kernel call
-    (8h x 8w x C_0 fp16 per frame) stays below the kernels' 2 GiB operand limit; results do not depend on the slicing."""
+    (``max_frames_per_call``) stays below the kernels' 2 GiB operand limit; results do not depend on the slicing."""
     if latents.ndim != 5:
         raise ValueError("latents must be [b, c, t, h, w]")
     b, c, t, h, w = latents.shape
-    # bytes per frame of the widest activation: (8h / 2^k) x (8w / 2^k) x C_k fp16 at resolution level k
-    per_frame = max(((8 * h) >> k) * ((8 * w) >> k) * ck * 2 for k, ck in enumerate(vae.config.block_out_channels))
-    max_frames = max(1, _MAX_CALL_BYTES // per_frame)
+    max_frames = max_frames_per_call(vae.config.block_out_channels, h, w)
     out: List[torch.Tensor] = []
     for s0 in range(0, t, decoder_t_segment):
         seg = latents[:, :, s0:s0 + decoder_t_segment]

@@ -21,6 +21,8 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
   * reference_poseguider_*.npz  musev/models/controlnet.py PoseGuider.forward (the pose conditioning of musev_referencenet_pose)
   * reference_unet_musev_cfg2.npz / reference_unet_refnet_cfg3.npz  (``--at-size``) the same forward at the sizes of BASELINE.json
                                 configs 2 and 3: full SD-1.5 widths, B 2, T 13, 64x64 latents
+  * reference_unet_refnet_pose_cfg5.npz  (``--at-size-cfg5``) the `musev_referencenet_pose` forward at config 5's size (96x96 latents) with
+                                ControlNet residuals + PoseGuider embedding
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
 from __future__ import annotations
@@ -47,7 +49,7 @@ logging.disable(logging.CRITICAL)
 from oracle import unet3d  # noqa: E402
 
 # ---- the golden UNet cases (shared with the tests through golden_cases.py) ----
-from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, case_config, case_inputs, FLAVOUR_CTOR_KWARGS  # noqa: E402
+from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, UNET_CASES_AT_SIZE_CFG5, case_config, case_inputs, FLAVOUR_CTOR_KWARGS  # noqa: E402
 
 
 def gen_context():
@@ -263,6 +265,10 @@ def gen_poseguider():
 if __name__ == "__main__":
     if "--at-size" in sys.argv:  # the BASELINE-size UNet cases only (minutes of CPU, ~25 GB)
         gen_unet(UNET_CASES_AT_SIZE)
+        sys.exit(0)
+    if "--at-size-cfg5" in sys.argv:  # the config-5-size case (96x96 latents; ~100 TFLOP of CPU work, ~45 GB)
+        torch.set_num_threads(os.cpu_count() or 1)
+        gen_unet(UNET_CASES_AT_SIZE_CFG5)
         sys.exit(0)
     gen_poseguider()
     gen_loop_utils()

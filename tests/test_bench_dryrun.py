@@ -1,6 +1,6 @@
 """CPU dry run of bench.py's main() (the script the driver times at round end): small `musev` architecture on the emulated
 kernels, CUDA entry points replaced by stand-ins -- checks that the whole flow (timed loop with the warm-up callback,
-instrumented roofline pass, JSON assembly) runs and that the line carries every field of the contract.  Numbers are
+recorded-launch roofline pass, JSON assembly) runs and that the line carries every field of the contract.  Numbers are
 meaningless here; on the GPU the same code runs on libmusev_hip.so."""
 import json
 import os
@@ -43,20 +43,20 @@ def test_bench_main_dry_run(monkeypatch, capsys):
         m._device_check = False
         return m
 
-    # every mv_gemm_f16 launch goes through ops._launch_gemm on the GPU; the emulation bypasses it, so feed the profile hook here
+    # every mv_gemm_f16 launch goes through ops._launch_gemm on the GPU; the emulation bypasses it, so feed the launch recorder
+    # here (problem geometry only) and time the "replays" with a constant per launch
+    from types import SimpleNamespace
     for name, mode in (("gemm", 0), ("conv3x3", 1), ("tconv3", 2)):
         inner = getattr(ops, name)
 
         def f(*a, _inner=inner, _mode=mode, **k):
             out = _inner(*a, **k)
-            if ops.GEMM_PROFILE is not None:
-                e0, e1 = _FakeEvent(), _FakeEvent()
-                e0.record()
-                e1.record()
+            if ops.GEMM_RECORD is not None:
                 w = a[1]
-                ops.GEMM_PROFILE.append((_mode, out.shape[0], w.shape[0], w.shape[1], int(bool(k.get("geglu"))), e0, e1, 1000))
+                ops.GEMM_RECORD.append((SimpleNamespace(mode=_mode, M=out.shape[0], N=w.shape[0], K=w.shape[1], geglu=int(bool(k.get("geglu")))), (), 1000))
             return out
         monkeypatch.setattr(ops, name, f)
+    monkeypatch.setattr(ops, "replay_gemms", lambda rec, reps=1: 0.01 * len(rec) * reps)
 
     monkeypatch.setattr(bench, "build_unet", build_unet)
     monkeypatch.setattr(ParallelDenoiser, "_device_check", False)
@@ -79,4 +79,5 @@ def test_bench_main_dry_run(monkeypatch, capsys):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["launches_per_step"] > 50 and set(rf["by_mode"]) == {"linear", "conv3x3", "tconv3"}
+    assert abs(rf["avg_launch_ms"] - 0.01) < 1e-9 and rec["config"]["graphs"] is False   # (no device: eager emulation)
     assert rec["cpu_baseline"] is None   # --no-cpu-baseline

@@ -1,6 +1,6 @@
 """CPU dry run of tools/gpu_gemm_tune.py (the first GPU call of the next round depends on it): the model is the small `musev`
 architecture on the emulated kernels, the CUDA bits are stand-ins, and every GEMM-family launch reports a synthetic duration
-that depends on the forced configuration -- so the aggregation, the choice rule and the generated gemm_tuned.h can be checked
+that depends on the configuration in the (re-issued) descriptor -- so the aggregation, the choice rule and the generated gemm_tuned.h can be checked
 without a GPU.  The header it writes is then compiled into the host-simulator build of gemm.hip."""
 import importlib.util
 import os
@@ -16,12 +16,22 @@ import emu_ops
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class _FakeEvent:
-    def __init__(self, ms):
-        self.ms = ms
-
-    def elapsed_time(self, other):
-        return other.ms - self.ms
+def fake_desc(mode, a, w, out, geglu=False, c2=0, conv=None, tconv=None):
+    """a GemmDesc with the real problem geometry and made-up (non-null, 16-byte aligned) addresses: enough for the library's
+    host-side entry points (mv_gemm_workspace_bytes / mv_gemm_choice validate and choose, they launch nothing)"""
+    from musev_amd import _lib
+    d = _lib.GemmDesc()
+    d.a, d.w, d.c = 0x10000, 0x20000, 0x30000
+    d.M, d.N, d.K = out.shape[0], w.shape[0], w.shape[1]
+    d.lda, d.ldc, d.c1 = a.shape[1], out.shape[1], a.shape[1]
+    if c2:
+        d.a2, d.lda2, d.c2 = 0x40000, c2, c2
+    d.mode, d.geglu, d.cfg = mode, int(geglu), -1
+    if conv is not None:
+        d.hin, d.win, d.hout, d.wout, d.stride, d.upsample = conv
+    if tconv is not None:
+        d.t, d.hw = tconv
+    return d
 
 
 def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
@@ -35,8 +45,7 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
     # synthetic timing model: rules = 1.0 ms; configuration 6 is 20 % faster on conv3x3 problems (30 % with 4 K slices on
     # configuration 1), configuration 13 is 10 % faster on linear problems with K <= 320, configuration 3 is 1 % faster everywhere
     # (below the 3 % threshold: must NOT be picked)
-    def fake_ms(mode, K):
-        cfg, split = ops.GEMM_CFG, ops.GEMM_SPLITK
+    def fake_ms(mode, K, cfg, split):
         if cfg == 1 and split == 4 and mode == 1:
             return 0.7
         if cfg == 6 and mode == 1:
@@ -47,23 +56,34 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
             return 0.99
         return 1.0 if cfg == -2 else 1.05
 
+    # the emulated kernels bypass ops._launch_gemm: feed the launch recorder here, and time "replays" with the synthetic model
     def wrap(name, mode_of):
         inner = getattr(emu_ops, name)
 
         def f(*a, **k):
             out = inner(*a, **k)
-            if ops.GEMM_PROFILE is not None:
-                w = a[1]
-                mode = mode_of
-                M, N, K = out.shape[0], w.shape[0], w.shape[1]
-                geglu = int(bool(k.get("geglu")))
-                ops.GEMM_PROFILE.append((mode, M, N, K, geglu, _FakeEvent(0.0), _FakeEvent(fake_ms(mode, K)), 0))
+            if ops.GEMM_RECORD is not None:
+                x2 = k.get("a2") if name == "gemm" else k.get("x2")
+                conv = tconv = None
+                if name == "conv3x3":
+                    h, w_ = a[3], a[4]
+                    st, up = k.get("stride", 1), int(bool(k.get("upsample")))
+                    ho, wo = (2 * h, 2 * w_) if up else ((h - 1) // st + 1, (w_ - 1) // st + 1)
+                    conv = (h, w_, ho, wo, st, up)
+                if name == "tconv3":
+                    tconv = (a[3], a[4])
+                d = fake_desc(mode_of, a[0], a[1], out if not k.get("geglu") else out.new_empty(out.shape[0], 2 * out.shape[1]),
+                              geglu=bool(k.get("geglu")), c2=0 if x2 is None else x2.shape[1], conv=conv, tconv=tconv)
+                if k.get("geglu"):
+                    d.ldc = out.shape[1]
+                ops.GEMM_RECORD.append((d, (), 0))
             return out
         monkeypatch.setattr(ops, name, f)
 
     wrap("gemm", 0)
     wrap("conv3x3", 1)
     wrap("tconv3", 2)
+    monkeypatch.setattr(ops, "replay_gemms", lambda rec, reps=1: sum(fake_ms(int(d.mode), int(d.K), int(d.cfg), int(d.splitk)) for d, _k, _b in rec) * reps)
 
     arch = dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
                 up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
@@ -88,7 +108,7 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
     monkeypatch.setattr(tune, "ROOT", str(tmp_path))
     monkeypatch.setattr(sys, "argv", ["gpu_gemm_tune.py", "dry", "--size", "64", "--reps", "1"])
     tune.main()
-    assert (ops.GEMM_CFG, ops.GEMM_SPLITK) == (-1, 0), "the tuner must leave the process on `table + rules`"
+    assert (ops.GEMM_CFG, ops.GEMM_SPLITK) == (-1, 0) and ops.GEMM_RECORD is None, "the tuner must leave the process on `table + rules`"
 
     hdr = open(tmp_path / "gpurun_out" / "dry_gemm_tuned.h").read()
     entries = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", hdr)]

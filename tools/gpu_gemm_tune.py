@@ -3,9 +3,10 @@
 
     python tools/gpu_gemm_tune.py [tag] [--size 512] [--reps 3] [--min-gain 0.03]
 
-Times every launch of ONE window forward of the benchmark model (config 2: B = 2, T = 13, 64x64 latents) in situ -- HIP
-events around each mv_gemm_f16 launch on the launch stream (musev_amd.ops.GEMM_PROFILE), eager launches, one stream -- once per
-catalogue configuration / split-K factor (ops.GEMM_CFG, ops.GEMM_SPLITK -> mv_gemm_desc.cfg / .splitk), plus once under the built-in rules.  For every distinct problem
+Records every implicit-GEMM launch of ONE window forward of the benchmark model (config 2: B = 1 and B = 2, T = 13, 64x64 latents;
+--size 768 gives the config-5 problems) through musev_amd.ops.GEMM_RECORD and times every distinct problem on its real operands --
+`reps` launches back to back between one HIP event pair -- under every catalogue configuration / split-K factor
+(mv_gemm_desc.cfg / .splitk), plus once under the built-in rules.  For every distinct problem
 (mode, M, N, K, geglu) it keeps the fastest configuration if that beats the rules by more than --min-gain, and writes
 
     gpurun_out/<tag>_gemm_tuned.h      -> copy to musev_amd/csrc/gemm_tuned.h, rebuild (exact-match table in front of the rules)
@@ -81,37 +82,50 @@ def main():
         combos = [cs for cs in combos if cs[1] <= 1]
     if args.max_cfg >= 0:
         combos = [cs for cs in combos if cs[0] <= args.max_cfg]
-    table = {}   # key -> {"n": launches, "ms": {(cfg, splitk): mean ms per launch}}
-    ref_out = None
+    # ONE eager forward is recorded (musev_amd.ops.GEMM_RECORD: descriptor copies in launch order, tensors kept alive); every
+    # DISTINCT problem is then re-issued from its first recorded descriptor under every configuration / split factor -- `reps`
+    # launches back to back between one HIP event pair (ops.replay_gemms), i.e. device time without host launch gaps.  The choice
+    # travels in the descriptor (cfg / splitk); a forced split gets its workspace here.
+    forward()   # warm-up (packed weights, caches, code objects)
+    torch.cuda.synchronize()
+    ops.GEMM_RECORD = []
+    forward()
+    torch.cuda.synchronize()
+    rec, ops.GEMM_RECORD = ops.GEMM_RECORD, None
+    table = {}   # key -> {"n": launches per forward pair, "desc": first descriptor, "keep": tensors, "ms": {(cfg, splitk): ms per launch}}
+    for d, keep, _nb in rec:
+        key = (int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu))
+        ent = table.setdefault(key, {"n": 0, "desc": d, "keep": keep, "ms": {}})
+        ent["n"] += 1
+    ws_cache = {}
+
+    def time_problem(ent, cfg, splitk):
+        d = _lib.GemmDesc.from_buffer_copy(ent["desc"])
+        d.cfg, d.splitk = cfg, splitk
+        d.workspace, d.workspace_bytes = None, 0
+        need = lib.mv_gemm_workspace_bytes(C.byref(d))
+        if need < 0:
+            return None
+        if need > 0:
+            ws = ws_cache.get(need)
+            if ws is None:
+                ws = ws_cache[need] = torch.empty(need, dtype=torch.uint8, device=dev)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), need
+        one = [(d, (), 0)]
+        ops.replay_gemms(one, 1)
+        return ops.replay_gemms(one, args.reps) / args.reps
+
     for cfg, splitk in combos:
-        ops.GEMM_CFG, ops.GEMM_SPLITK = cfg, splitk   # the choice travels in every call's descriptor (the library keeps no state)
-        out = forward()   # warm-up (packed weights, caches, code objects)
-        torch.cuda.synchronize()
-        if ref_out is None:
-            ref_out = out.clone()
-        elif splitk <= 1 and not torch.equal(out, ref_out) and cfg != -2:
-            # unsplit configurations reduce over K in the same order: results must not move (a split changes the fp32 order)
-            print(f"NOTE: configuration {cfg} changed the forward's output by {(out - ref_out).abs().max().item():.3e} vs the rules "
-                  f"(expected only where the rules split K)", flush=True)
-        ops.GEMM_PROFILE = []
-        for _ in range(args.reps):
-            forward()
-        torch.cuda.synchronize()
-        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-        acc = {}
-        for rec in prof:
-            mode, M, N, K, geglu, e0, e1 = rec[:7]
-            key = (mode, M, N, K, geglu)
-            a = acc.setdefault(key, [0.0, 0])
-            a[0] += e0.elapsed_time(e1)
-            a[1] += 1
-        for key, (ms, n) in acc.items():
-            ent = table.setdefault(key, {"n": n // args.reps, "ms": {}})
-            ent["ms"][(cfg, splitk)] = ms / n
-        tot = sum(ms for ms, _ in acc.values()) / args.reps
+        tot = 0.0
+        for key, ent in table.items():
+            ms = time_problem(ent, cfg, splitk)
+            if ms is None:   # the configuration cannot run this problem (GEGLU needs an even TN): not a candidate
+                continue
+            ent["ms"][(cfg, splitk)] = ms
+            tot += ms * ent["n"]
         label = "rules" if cfg == -2 else f"cfg {cfg:2d} {descs[cfg][0]}x{descs[cfg][1]} {descs[cfg][2]}w x{descs[cfg][4]} splitk {splitk}"
-        print(f"{label:40s} GEMM family {tot:7.2f} ms / forward", flush=True)
-    ops.GEMM_CFG, ops.GEMM_SPLITK = -1, 0
+        print(f"{label:40s} GEMM family {tot:7.2f} ms / forward pair", flush=True)
+    del rec
 
     rules_total = tuned_total = 0.0
     entries, report = [], []
