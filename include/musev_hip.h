@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 3
+#define MV_ABI_VERSION 4
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -76,6 +76,14 @@ typedef struct mv_gemm_desc {
     int32_t splitk;        /* K slices: 0 = library's choice, >= 1 = this many (clamped, see below)     */
     void* workspace;       /* split-K scratch (fp32 slabs), 16-byte aligned; may be NULL when           */
     int64_t workspace_bytes; /*  mv_gemm_workspace_bytes(d) == 0                                        */
+    /* LayerNorm folded into the projection (LINEAR mode; replaces nn.LayerNorm norm1 / norm2 / norm3 + the Linear behind  */
+    /* it, musev/models/attention.py:293-308,345-362,398-429): `a` holds the RAW rows, `w` = W * gamma (column-wise), the  */
+    /* kernel forms each row's mean / rstd over its K = C values from the fragments it multiplies and the epilogue applies */
+    /*   out[m][n] = rstd_m * (acc[m][n] - mean_m * ln_colsum[n]) + ln_colbias[n]   (then GEGLU / residual as usual).      */
+    const float* ln_colsum;  /* fp32 [N]: sum_k w[n][k] of the fp16 values in `w`; NULL = no folding                      */
+    const float* ln_colbias; /* fp32 [N]: sum_k beta_k W[n][k] + bias_n (bias / rowbias must be NULL)                      */
+    float ln_eps;            /* LayerNorm epsilon                                                                          */
+    int32_t reserved0;
 } mv_gemm_desc;
 
 /* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmusev_hip.so")
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 3
+MV_ABI_VERSION = 4
 
 
 class MuseVHipError(RuntimeError):
@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("t", C.c_int32), ("hw", C.c_int32),
         ("rows_per_group", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
         ("cfg", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("ln_colsum", C.c_void_p), ("ln_colbias", C.c_void_p), ("ln_eps", C.c_float), ("reserved0", C.c_int32),
     ]
 
 

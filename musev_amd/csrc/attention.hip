@@ -437,23 +437,39 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
 // Contraction columns past D (the 32-deep chunks cover 64 / 96) read the next LDS row: finite data (the LDS is zero-filled
 // once, DMA data is finite) times the zero tail of the query fragment.
 // Per tile and wave at d = 40: 32 MFMA + 32 exp + 16 packed converts + 16 max3 + 1 compare + 20 LDS reads + 2-3 DMA issues.
-template <int D>
+// VAR (bit set; the dispatcher picks per head dim what the MI355X measured fastest, tools/gpu_attn_bench.py):
+//   1  the contraction tail past the last whole 32-deep chunk (d 32..39 at d = 40, d 64..79 at d = 80) runs as ONE 16-deep
+//      v_mfma_f32_16x16x16_f16 step instead of a zero-padded 32-deep one: 40 -> 48 instead of 64, 80 -> 80 instead of 96
+//   2  (d = 40) K and V tile rows are 48 halfs apart: the sixth 16-byte slot of a row is never written by the LDS-DMA (its lanes
+//      are switched off), stays 0 in K and holds {1, 0, ...} in V, so that
+//        * the row sums come out of the P.V MFMA's unused output row d = 40 (no ones-fragment MFMAs: 28 instead of 32 per tile),
+//        * the 96-byte row stride makes both the ds_read_b128 K fragments and the ds_read_b64_tr_b16 V reads conflict-free under
+//          the hardware's lane groups (80-byte rows: 2-way on both).
+//   4  (d = 40) register budget of four waves per SIMD (128 VGPRs) instead of three
+template <int D, int VAR>
 struct Attn3Cfg {
-    static constexpr int CH = D / 8;                   // 16-byte chunks per row
-    static constexpr int NC = (D + 31) / 32;           // 32-deep contraction chunks
+    static constexpr bool TAIL16 = (VAR & 1) != 0 && (D % 32) != 0 && (D % 32) <= 16;
+    static constexpr bool PADR = (VAR & 2) != 0 && D == 40;
+    static constexpr int CH = D / 8;                   // 16-byte chunks of data per row
+    static constexpr int RCH = PADR ? CH + 1 : CH;     // 16-byte slots per LDS row
+    static constexpr int DR = 8 * RCH;                 // LDS row stride (halfs)
+    static constexpr int NC = (D + 31) / 32;           // 32-deep contraction chunks (the last one 16 deep with TAIL16)
+    static constexpr int NC32 = TAIL16 ? NC - 1 : NC;  // ... of which whole 32-deep MFMA steps
     static constexpr int NDT = (D + 15) / 16;          // O^T d-tiles
+    static constexpr bool ONES = PADR && NDT * 16 > D; // the row sums ride in output row D of the P.V product
     static constexpr int KV = 64, QT = 2, QB = 128, NST = 3;
-    static constexpr int TILE = KV * D;                // halfs per K (or V) tile = CH pieces of 1 KiB
-    static constexpr int PIECES = 2 * CH;              // LDS-DMA pieces per (K, V) tile pair: 10 / 20, dealt round-robin to the 4 waves
-    static constexpr int PPW = (PIECES + 3) / 4;       // ... at most per wave: 3 / 5
+    static constexpr int TILE = KV * DR;               // halfs per K (or V) tile = RCH pieces of 1 KiB
+    static constexpr int PIECES = 2 * RCH;             // LDS-DMA pieces per (K, V) tile pair, dealt round-robin to the 4 waves
+    static constexpr int PPW = (PIECES + 3) / 4;       // ... at most per wave
     static constexpr int LDS_HALFS = NST * 2 * TILE + 64;  // slack: a 32-deep fragment read of the last row runs past it
 };
 
-template <int D>
-__global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnArgs p) {
-    using C = Attn3Cfg<D>;
-    static_assert(D % 8 == 0 && (64 * C::CH) % 64 == 0, "a tile must be a whole number of 1-KiB pieces");
+template <int D, int VAR>
+__global__ __launch_bounds__(256, D == 40 ? ((VAR & 4) ? 4 : 3) : 2) void attn3_kernel(const AttnArgs p) {
+    using C = Attn3Cfg<D, VAR>;
+    static_assert(D % 8 == 0 && (64 * C::RCH) % 64 == 0, "a tile must be a whole number of 1-KiB pieces");
     constexpr float kThr = 6.0f;  // scores may exceed the reference by 2^6: P <= 64 in fp16, sums in fp32
+    constexpr int DR = C::DR;
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -469,28 +485,45 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
     const int h = hn % p.heads;
     const int n = hn / p.heads;
     const int q0 = (id - hn * qblocks) * C::QB + wave * (16 * C::QT);
-    const int npw = (C::PIECES - wave + 3) / 4;  // pieces this wave issues per tile pair (wave-uniform): 3,3,2,2 / 5,5,5,5
+    const int npw = (C::PIECES - wave + 3) / 4;  // pieces this wave issues per tile pair (wave-uniform)
 
     for (int i = tid; i < C::LDS_HALFS / 8; i += 256) reinterpret_cast<uint4*>(lds)[i] = uint4{0, 0, 0, 0};
+    if constexpr (C::ONES) {
+        __syncthreads();
+        // the sixth slot of every V row: {1, 0, 0, 0, 0, 0, 0, 0} -- written once, the LDS-DMA never touches it
+        for (int i = tid; i < C::NST * C::KV; i += 256)
+            lds[(i / C::KV) * (2 * C::TILE) + C::TILE + (i % C::KV) * DR + D] = (half_t)1.0f;
+    }
     typedef __attribute__((address_space(3))) half_t lds_half_t;
     const lds_half_t* lds3 = (const lds_half_t*)lds;                           // the LDS image in its own address space (one cast)
-    const int v_lane_off = (4 * g + (l15 >> 2)) * D + (l15 & 3) * 4;           // this lane's place inside a [4 kv][16 d] block of V
+    const int v_lane_off = (4 * g + (l15 >> 2)) * DR + (l15 & 3) * 4;          // this lane's place inside a [4 kv][16 d] block of V
 
     // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale * log2(e); zero past column D ----
-    half8v qf[C::QT][C::NC];
+    half8v qf[C::QT][C::NC32];
+    half4v qt16[C::QT];  // TAIL16: the 16-deep tail d = 32 NC32 + 4 g .. + 3
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         const int qr = q0 + 16 * qt + l15;
+        const half_t* qrow = p.q + ((long)n * p.lq + (qr < p.lq ? qr : 0)) * p.ldq + h * D;
 #pragma unroll
-        for (int c = 0; c < C::NC; ++c) {
+        for (int c = 0; c < C::NC32; ++c) {
             const int dcol = 32 * c + 8 * g;
             half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (qr < p.lq && dcol < D) {
-                const half8v raw = *reinterpret_cast<const half8v*>(p.q + ((long)n * p.lq + qr) * p.ldq + h * D + dcol);
+                const half8v raw = *reinterpret_cast<const half8v*>(qrow + dcol);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)raw[e] * p.scale_log2e);
             }
             qf[qt][c] = v;
+        }
+        qt16[qt] = half4v{0, 0, 0, 0};
+        if constexpr (C::TAIL16) {
+            const int dcol = 32 * C::NC32 + 4 * g;
+            if (qr < p.lq && dcol < D) {
+                const half4v raw = *reinterpret_cast<const half4v*>(qrow + dcol);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qt16[qt][e] = (half_t)((float)raw[e] * p.scale_log2e);
+            }
         }
     }
     // constant A fragment of the row-sum MFMA: row 0 (lanes with l15 == 0) all ones
@@ -507,7 +540,7 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
     }
     float m_ref[C::QT] = {0.f, 0.f};  // reference of the exponents (log2 domain)
 
-    __syncthreads();  // the zero fill is complete before the first DMA may land
+    __syncthreads();  // the zero fill (and the ones column) is complete before the first DMA may land
     bool first = true;    // no tile processed yet (the first tile sets the reference unconditionally)
     // ---- walk the key/value segments; per segment a three-stage LDS ring with two tiles in flight (the ring drains at a segment
     // boundary: a segment is 64 tiles at level 0, and everything that selects it -- base pointers, strides, descriptors, the
@@ -525,12 +558,15 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
         const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(((len - 1) * ldv + D) * 2), 0x00020000);
         unsigned voff[C::PPW];   // byte offset of this lane's chunk inside a tile, per piece
         int prow[C::PPW];        // its tile row (tail predicate of the partial last tile)
+        bool pon[C::PPW];        // PADR: the lane owns a data slot (the pad slot's lanes never issue)
 #pragma unroll
         for (int j = 0; j < C::PPW; ++j) {
             const int q = wave + 4 * j;
-            const int ci = (q % C::CH) * 64 + lane;
-            prow[j] = ci / C::CH;
-            voff[j] = (unsigned)((prow[j] * (q >= C::CH ? ldv : ldk) + (ci - prow[j] * C::CH) * 8) * 2);
+            const int ci = (q % C::RCH) * 64 + lane;
+            prow[j] = ci / C::RCH;
+            const int slot = ci - prow[j] * C::RCH;
+            pon[j] = slot < C::CH;
+            voff[j] = (unsigned)((prow[j] * (q >= C::RCH ? ldv : ldk) + slot * 8) * 2);
         }
         const int total = (len + C::KV - 1) / C::KV;
         const int tile_k = C::KV * ldk * 2, tile_v = C::KV * ldv * 2;  // scalar byte advance per tile
@@ -543,12 +579,16 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
             for (int j = 0; j < C::PPW; ++j) {
                 const int q = wave + 4 * j;
                 if (q >= C::PIECES) break;  // wave-uniform
-                const bool isv = q >= C::CH;
+                const bool isv = q >= C::RCH;
                 unsigned vo = voff[j];
                 if (partial) vo = (row0 + prow[j] < len) ? vo : 0x80000000u;  // out of range for every descriptor
-                half_t* dst = base + (isv ? C::TILE : 0) + (q % C::CH) * 512;
-                if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, tile * tile_v, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, tile * tile_k, 0, 0);
+                half_t* dst = base + (isv ? C::TILE : 0) + (q % C::RCH) * 512;
+                if (!C::PADR || pon[j]) {  // (PADR: a divergent region -- the pad slot's lanes are off for this instruction)
+                    if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, tile * tile_v, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, tile * tile_k, 0, 0);
+                } else {
+                    MV_DMA_LANE_OFF();
+                }
             }
         };
 
@@ -587,13 +627,22 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
             for (int st = 0; st < 4; ++st) acc_s[qt][st] = float4v{m0, m0, m0, m0};
         }
 #pragma unroll
-        for (int c = 0; c < C::NC; ++c) {
+        for (int c = 0; c < C::NC32; ++c) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const half8v kf = *reinterpret_cast<const half8v*>(sK + (16 * st + l15) * D + 32 * c + 8 * g);
+                const half8v kf = *reinterpret_cast<const half8v*>(sK + (16 * st + l15) * DR + 32 * c + 8 * g);
 #pragma unroll
                 for (int qt = 0; qt < C::QT; ++qt)
                     acc_s[qt][st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][c], acc_s[qt][st], 0, 0, 0);
+            }
+        }
+        if constexpr (C::TAIL16) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const half4v kf = *reinterpret_cast<const half4v*>(sK + (16 * st + l15) * DR + 32 * C::NC32 + 4 * g);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_s[qt][st] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qt16[qt], acc_s[qt][st], 0, 0, 0);
             }
         }
         if (rows < C::KV) {  // wave-uniform: the partial last tile of a segment masks its missing keys
@@ -656,17 +705,19 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
                 pfrag[qt][cc] = f;
             }
         }
-        // ---- O^T += V^T P^T; row sums += 1^T P^T ----
+        // ---- O^T += V^T P^T; row sums += 1^T P^T (ONES: output row D of the same product) ----
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
+            if constexpr (!C::ONES) {
 #pragma unroll
-            for (int qt = 0; qt < C::QT; ++qt)
-                acc_l[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones_f, pfrag[qt][cc], acc_l[qt], 0, 0, 0);
+                for (int qt = 0; qt < C::QT; ++qt)
+                    acc_l[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones_f, pfrag[qt][cc], acc_l[qt], 0, 0, 0);
+            }
 #pragma unroll
             for (int dt = 0; dt < C::NDT; ++dt) {
-                const lds_half_t* b0 = vrd + (32 * cc * D + 16 * dt);  // compile-time offset (the loops are fully unrolled)
+                const lds_half_t* b0 = vrd + (32 * cc * DR + 16 * dt);  // compile-time offset (the loops are fully unrolled)
                 short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0));
-                short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0 + 16 * D));
+                short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0 + 16 * DR));
                 typedef short short8v __attribute__((ext_vector_type(8)));
                 short8v tv = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
                 half8v vf = __builtin_bit_cast(half8v, tv);
@@ -682,7 +733,11 @@ __global__ __launch_bounds__(256, D == 40 ? 3 : 2) void attn3_kernel(const AttnA
     // ---- epilogue: O^T[d = 16 dt + 4 g + r][q = l15] / row sum ----
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
-        const float l = __shfl(acc_l[qt][0], l15, 64);  // row 0 of the row-sum tile: lane group g = 0, register 0
+        // row sums: row 0 of the ones-fragment product (lane group g = 0, register 0), or output row D of P.V (ONES: d-tile D / 16,
+        // row D % 16 = 4 g' + r' -> lane group g', register r')
+        float l;
+        if constexpr (C::ONES) l = __shfl(acc_o[qt][D / 16][(D % 16) % 4], 16 * ((D % 16) / 4) + l15, 64);
+        else l = __shfl(acc_l[qt][0], l15, 64);
         const float inv = 1.0f / l;
         const int qr = q0 + 16 * qt + l15;
         if (qr >= p.lq) continue;
@@ -928,7 +983,27 @@ __global__ __launch_bounds__(256) void tattn3_kernel(const TAttnArgs a, const in
 
 }  // namespace
 
-extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
+namespace {
+
+// kernel variants the library runs (Attn3Cfg: 1 = 16-deep contraction tail, 2 = 48-half rows with the ones column at d = 40);
+// chosen from the same-box A/B of tools/gpu_attn_bench.py (profiles/r03*_attn_variants.log)
+constexpr int kAttnVar40 = 7;  // r03a: 1.870 -> 1.715 ms (26 frames), 0.964 -> 0.809 ms (13 frames) at level 0
+constexpr int kAttnVar80 = 0;  // r03a: the 16-deep tail is 3-4 % slower at d = 80
+
+template <int D, int VAR>
+int launch_attn3(const AttnArgs& a, dim3 grid1, hipStream_t s) {
+    constexpr int smem = Attn3Cfg<D, VAR>::LDS_HALFS * 2;
+    static bool attr_done = false;  // idempotent one-time attribute of this instantiation (up to 62 KB of dynamic LDS)
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_kernel<D, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn3_kernel<D, VAR>), grid1, dim3(256), smem, s, a);
+    return MV_OK;
+}
+
+int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) {
     MV_REQUIRE(d && d->q && d->out, "mv_attention_f16: null pointer");
     MV_REQUIRE(d->nseg >= 1 && d->nseg <= MV_ATTN_MAX_SEG, "mv_attention_f16: nseg=%d out of range", d->nseg);
     MV_REQUIRE(d->d == 40 || d->d == 80 || d->d == 160, "mv_attention_f16: head dim %d not in {40,80,160}", d->d);
@@ -962,25 +1037,40 @@ extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) {
             MV_REQUIRE((long)d->seg[sg].len * d->seg[sg].ldk * 2 < 0x7fffffffL && (long)d->seg[sg].len * d->seg[sg].ldv * 2 < 0x7fffffffL,
                        "mv_attention_f16: segment %d spans 2 GiB or more per key batch", sg);
         const dim3 grid1((unsigned)(((d->lq + 127) / 128) * d->heads * d->nb));  // 1-D: the kernel maps ids to (q block, head, frame)
+        int rc = MV_OK;
         if (d->d == 40) {
-            constexpr int smem = Attn3Cfg<40>::LDS_HALFS * 2;
-            hipLaunchKernelGGL((attn3_kernel<40>), grid1, dim3(256), smem, s, a);
+#ifdef MV_EXPERIMENT
+            if (var40 == 0) rc = launch_attn3<40, 0>(a, grid1, s);
+            else if (var40 == 1) rc = launch_attn3<40, 1>(a, grid1, s);
+            else if (var40 == 2) rc = launch_attn3<40, 2>(a, grid1, s);
+            else if (var40 == 6) rc = launch_attn3<40, 6>(a, grid1, s);
+            else if (var40 == 7) rc = launch_attn3<40, 7>(a, grid1, s);
+            else
+#endif
+            rc = launch_attn3<40, kAttnVar40>(a, grid1, s);
         } else {
-            constexpr int smem = Attn3Cfg<80>::LDS_HALFS * 2;
-            static bool attr_done = false;  // idempotent one-time attribute of this instantiation (72 KB of dynamic LDS)
-            if (!attr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_kernel<80>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-                MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((attn3_kernel<80>), grid1, dim3(256), smem, s, a);
+#ifdef MV_EXPERIMENT
+            if (var80 == 0) rc = launch_attn3<80, 0>(a, grid1, s);
+            else
+#endif
+            rc = launch_attn3<80, kAttnVar80>(a, grid1, s);
         }
+        if (rc != MV_OK) return rc;
     } else {
         hipLaunchKernelGGL((attn_kernel<160, 0>), grid, dim3(256), 0, s, a);
     }
     MV_CHECK_LAUNCH("mv_attention_f16");
     return MV_OK;
 }
+
+}  // namespace
+
+extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) { return attention_launch(d, kAttnVar40, kAttnVar80, stream); }
+
+#ifdef MV_EXPERIMENT
+// experiment builds only (tools/gpu_attn_bench.py): the same entry with the kernel variant chosen per call
+extern "C" int mv_attention_f16_var(const mv_attn_desc* d, int var40, int var80, void* stream) { return attention_launch(d, var40, var80, stream); }
+#endif
 
 extern "C" int mv_temporal_attention_f16(const void* q, const void* k, const void* v, int32_t ldq, int32_t ldk,
                                          int32_t ldv, void* out, int32_t ldo, int32_t b, int32_t t, int32_t hw,

@@ -23,6 +23,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MV_KEEP_ONE_REGISTER(x) asm volatile("" : "+v"(x))
 #endif
 
+// marks the lanes a divergent region switches off for an LDS-DMA instruction: nothing on the GPU (EXEC does it); the host
+// simulator of tests/ books the wave's instruction for those lanes too, so that their counted waits stay in step
+#ifndef MV_DMA_LANE_OFF
+#define MV_DMA_LANE_OFF() ((void)0)
+#endif
+
 // host-side error plumbing ---------------------------------------------------------------------------
 void mv_set_error(const char* fmt, ...);
 

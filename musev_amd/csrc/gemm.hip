@@ -48,6 +48,11 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int nsplit, kt_per_split;  // split-K: blockIdx.y owns K tiles [y * kt_per_split, (y + 1) * kt_per_split)
     float* ws;                 // split-K workspace [nsplit][M][N] fp32
+    // LayerNorm folded into the projection (LINEAR mode): w holds gamma-scaled weights, the block forms the row statistics of its A
+    // rows from the fragments it multiplies anyway, and the epilogue applies  rstd_m * (acc - mean_m * colsum_n) + colbias_n
+    const float* ln_colsum;    // [N] fp32: sum_k w[n][k] (of the fp16 values the MFMA sees), or nullptr
+    const float* ln_colbias;   // [N] fp32: sum_k beta_k W[n][k] + bias_n
+    float ln_eps;
 };
 
 template <int TM, int TN>
@@ -64,6 +69,43 @@ __device__ __forceinline__ void mma_tile(const half_t* cA, const half_t* cB, flo
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+}
+
+// the same with row statistics of the A tile: on the 32-deep steps it owns (the WGN waves that share a row block deal the steps
+// round-robin), the wave adds its fragments' sum and sum of squares -- 8 v_dot2_f32_f16 per fragment, fp32 accumulation -- into
+// per-lane partials (lane (l15, g) holds k = 8 g .. 8 g + 7 of row 16 i + l15)
+template <int TM, int TN, int WGN>
+__device__ __forceinline__ void mma_tile_ln(const half_t* cA, const half_t* cB, float4v (&acc)[TM][TN], int a_row0, int b_row0, int swz,
+                                            int g, float (&s1)[TM], float (&s2)[TM], int kstep0, int wn) {
+    constexpr int BK = 64;
+    const half2v ones = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int slot_off = (((kk * 4 + g) ^ swz) << 3);
+        half8v af[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
+        if (((kstep0 + kk) & (WGN - 1)) == wn) {  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half2v h = {af[i][2 * e], af[i][2 * e + 1]};
+                    s1[i] = __builtin_amdgcn_fdot2(h, ones, s1[i], false);
+                    s2[i] = __builtin_amdgcn_fdot2(h, h, s2[i], false);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -170,9 +212,12 @@ template <int TN, bool GEGLU> struct EpiGeom {
     static constexpr int WAVE_HALFS = 2 * 16 * LDW;     // two buffers
 };
 
-template <int TM, int TN, bool GEGLU, bool RES>
+// LN: the accumulators hold x . (gamma W)^T of the RAW rows; a pass first applies v = rstd_m * acc - (rstd_m * mean_m) * colsum_n +
+// colbias_n (ln_r[i] = rstd, ln_mr[i] = rstd * mean of row 16 i + l15; the column vectors are read in the accumulator layout).
+template <int TM, int TN, bool GEGLU, bool RES, bool LN = false>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc)[TM][TN], half_t* stg_base, int wave, int mw0,
-                                                int nw0, int lane, float alpha, int Mi, bool full) {
+                                                int nw0, int lane, float alpha, int Mi, bool full, const float* ln_r = nullptr,
+                                                const float* ln_mr = nullptr, int nacc0 = 0) {
     using G = EpiGeom<TN, GEGLU>;
     constexpr int W = G::W, LDW = G::LDW, CPR = G::CPR, RPI = G::RPI, KI = G::KI;
     half_t* stg = stg_base + wave * G::WAVE_HALFS;
@@ -190,6 +235,22 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
     const unsigned coff = (unsigned)(r0 * p.ldc + 8 * ch), roff = (unsigned)(r0 * p.ldr + 8 * ch);
     const bool silu = p.act == MV_ACT_SILU;
 
+    // LN: colsum / colbias of this lane's accumulator columns nacc0 + 16 j + 4 g .. + 3 (nacc0 = first accumulator column of the wave
+    // tile; with GEGLU the packed [value tile | gate tile] order is the accumulator's own)
+    float4v lcs[LN ? TN : 1], lcb[LN ? TN : 1];
+    if constexpr (LN) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nacc0 + 16 * j + 4 * g;
+            const bool ok = n < p.N;
+            lcs[j] = ok ? *reinterpret_cast<const float4v*>(p.ln_colsum + n) : float4v{0.f, 0.f, 0.f, 0.f};
+            lcb[j] = ok ? *reinterpret_cast<const float4v*>(p.ln_colbias + n) : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    auto ln_affine = [&](int i, int j) __attribute__((always_inline)) -> float4v {
+        if constexpr (LN) return acc[i][j] * ln_r[i] - lcs[j] * ln_mr[i] + lcb[j];
+        else return acc[i][j];
+    };
     half8v res[2][KI];
     auto request = [&](int i, half8v* rs) {  // residual chunks of pass i, in the read layout
         if constexpr (RES) {
@@ -207,14 +268,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
         if constexpr (GEGLU) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
-                const float4v v = acc[i][j], gt = acc[i][j + 1];
+                const float4v v = ln_affine(i, j), gt = ln_affine(i, j + 1);
                 *reinterpret_cast<half4v*>(wrow + 8 * j) = half4v{(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
                                                                   (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
             }
         } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                float4v v = acc[i][j] * alpha;
+                float4v v = ln_affine(i, j) * alpha;
                 if (silu) {
                     v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
                 }
@@ -269,8 +330,10 @@ __device__ unsigned long long mv_tl_buf[kTlBlocks * 8];
 #define MV_TL_FLUSH() ((void)0)
 #endif
 
-template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
+    static_assert(!LNF || MODE == MV_GEMM_LINEAR, "LayerNorm folding is a LINEAR-mode feature");
+    static_assert((WGN & (WGN - 1)) == 0, "the k-step deal of the row statistics needs a power-of-two WGN");
     constexpr int NW = WGM * WGN;
     // SCHED: 0 = two LDS stages behind __syncthreads (two blocks per CU overlap each other's stalls);
     //        3 = three stages behind counted waits (two K tiles in flight; for one-block-per-CU tiles and latency-bound grids)
@@ -280,7 +343,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     constexpr int AI = (CA + NW - 1) / NW, BI = (CB + NW - 1) / NW;
     const GemmArgs& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NST = (SCHED == 3) ? 3 : 2;  // LDS stages (SCHED 8 / 9: the two-tile ring of the ping-pong schedule)
+    constexpr int NST = (SCHED == 3) ? 3 : 2;  // LDS stages
     half_t* sA = reinterpret_cast<half_t*>(smem);  // [NST][BM*BK]
     half_t* sB = sA + NST * BM * BK;                // [NST][BN*BK]
 
@@ -356,9 +419,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     // (l15, g) holds columns 16 j + 4 g .. + 3 of rows 16 i + l15 (GEGLU: the packed [value tile | gate tile] column order is the
     // accumulator's own).  The narrow epilogue adds them itself.
     float4v acc[TM][TN];
+    float ln_s1[LNF ? TM : 1], ln_s2[LNF ? TM : 1];  // LNF: per-lane partial row sums / sums of squares of the A rows 16 i + l15
+#pragma unroll
+    for (int i = 0; i < (LNF ? TM : 1); ++i) ln_s1[i] = ln_s2[i] = 0.f;
     auto init_acc = [&]() __attribute__((always_inline)) {
         const int nw0 = n0 + wn * 16 * TN;
-        const bool init = q.wide && p.nsplit <= 1;
+        const bool init = q.wide && p.nsplit <= 1 && !LNF;  // (LNF: the bias is part of ln_colbias, applied after the row affine)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float4v b0 = float4v{0.f, 0.f, 0.f, 0.f};
@@ -480,8 +546,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int b_row0 = wn * 16 * TN + l15;
     const int swz = l15 & 7;
 
-    auto mma_stage = [&](int st) __attribute__((always_inline)) {
-        mma_tile<TM, TN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g);
+    auto mma_stage = [&](int st, int kt) __attribute__((always_inline)) {
+        if constexpr (LNF) mma_tile_ln<TM, TN, WGN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g, ln_s1, ln_s2, 2 * kt, wn);
+        else mma_tile<TM, TN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g);
     };
     if constexpr (SCHED == 3) {
         // NST-stage ring with COUNTED waits: NST-1 K tiles are in flight while one is multiplied, and nothing ever drains
@@ -530,79 +597,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
                 prepare();
                 issue(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);  // (cur + NST - 1) % NST: the stage tile kt-1 just left
             }
-            mma_stage(cur);
+            mma_stage(cur, kt);
             cur = (cur == NST - 1) ? 0 : cur + 1;
         }
-    } else if constexpr (SCHED == 8 || SCHED == 9) {
-        // PING-PONG schedule for the one-block-per-CU 8-wave tiles (WGM == 2): the two wave groups (wm = 0 / 1; every SIMD
-        // hosts one wave of each) run the same slot sequence one slot apart, so that in every slot one group is in a pure-MFMA
-        // "C" slot (operands in registers, s_setprio 1) while the other is in an "L" slot (ds_read_b128 of its next 32-deep
-        // fragment set, LDS-DMA issue, address arithmetic): the SIMD's matrix pipe always has a wave to run
-        // (cdna_hip_programming.md T3 / T5: phase-split waves + priority).  Per K tile and wave: L0 C0 L1 C1, one raw s_barrier
-        // per slot; the lockstep schedules above stall every wave at once on their fragment reads and on the barrier drain.
-        //   slot 4t   : A L0(t)               slot 4t+1 : A C0(t)  B L0(t)
-        //   slot 4t+2 : A L1(t)  B C0(t)      slot 4t+3 : A C1(t)  B L1(t)         slot 4t+4 : A L0(t+1)  B C1(t)
-        // LDS ring of two K tiles: tile t+1 goes into the buffer tile t-1 left; its last readers are B's L1(t-1) in slot 4t-1,
-        // so both groups issue their LDS-DMA pieces at the head of their L0(t) (slots 4t / 4t+1).  Tile t+1 is first read in
-        // slot 4t+4: every wave waits for its own pieces before the barrier that ends slot 4t+3 -- the end of C1(t) for group A,
-        // the end of L1(t) for group B (2.5 - 3.5 slots after the issue: nothing younger is in flight, so vmcnt(0) is the
-        // counted wait).  A ds_read must have EXECUTED before the barrier that hands its buffer on: lgkmcnt(0) closes every L slot.
-        static_assert(WGM == 2 && NST == 2, "ping-pong needs two wave groups and the two-tile ring");
-        const int grp = wm;
-        half8v af[TM], wf[TN];
-        auto read_frags = [&](int st, int kk) __attribute__((always_inline)) {
-            const half_t* cA = sA + st * (BM * BK);
-            const half_t* cB = sB + st * (BN * BK);
-            const int slot_off = (((kk * 4 + g) ^ swz) << 3);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8v*>(cA + (a_row0 + 16 * i) * BK + slot_off);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
-        };
-        auto mma_frags = [&]() __attribute__((always_inline)) {
-            if (SCHED == 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
-            if (SCHED == 8) __builtin_amdgcn_s_setprio(0);
-        };
-        auto end_slot = [&]() __attribute__((always_inline)) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        prepare();
-        issue(0, kt0);
-        init_acc();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        end_slot();                   // tile kt0 is visible to every wave
-        if (grp == 1) end_slot();     // the trailing group runs one slot behind
-        for (int kt = kt0; kt < nk; ++kt) {
-            const int cur = (kt - kt0) & 1;
-            const bool more = kt + 1 < nk;
-            // ---- L0 ----
-            if (more) {
-                prepare();
-                issue(cur ^ 1, kt + 1);
-            }
-            read_frags(cur, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            end_slot();
-            // ---- C0 ----
-            mma_frags();
-            end_slot();
-            // ---- L1 ----
-            read_frags(cur, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (grp == 1 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            end_slot();
-            // ---- C1 ----
-            mma_frags();
-            if (grp == 0 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            end_slot();
-        }
-        if (grp == 0) end_slot();     // pairs with the trailing group's last slot (barrier counts must match)
     } else {
         prepare();
         issue(0, kt0);
@@ -614,10 +611,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             const int cur = (kt - kt0) & 1;
             prepare();
             issue(cur ^ 1, kt + 1);
-            mma_stage(cur);
+            mma_stage(cur, kt);
             __syncthreads();
         }
-        mma_stage((nk - 1 - kt0) & 1);
+        mma_stage((nk - 1 - kt0) & 1, nk - 1);
     }
 
     // ---- epilogue ----
@@ -640,15 +637,48 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         return;
     }
     if (q.wide) {
+        // LNF: the waves' row-statistic partials meet in LDS behind the operand / staging area: [wave][16 TM rows][sum, sum of squares]
+        constexpr int kOpsBytes = NST * 64 * (BM + BN) * (int)sizeof(half_t);
+        constexpr int kEpiBytes = NW * EpiGeom<TN, false>::WAVE_HALFS * (int)sizeof(half_t);
+        float* const sst = reinterpret_cast<float*>(smem + (kOpsBytes > kEpiBytes ? kOpsBytes : kEpiBytes));
+        if constexpr (LNF) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float a = ln_s1[i], b = ln_s2[i];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);  // the 4 lane groups hold k = 8 g .. 8 g + 7 of the row
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (g == 0) {
+                    sst[(wave * 16 * TM + 16 * i + l15) * 2] = a;
+                    sst[(wave * 16 * TM + 16 * i + l15) * 2 + 1] = b;
+                }
+            }
+        }
         __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused as the staging buffers
+        float ln_r[LNF ? TM : 1], ln_mr[LNF ? TM : 1];
+        if constexpr (LNF) {
+            const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WGN; ++w2) {  // fixed order: bit-reproducible
+                    a += sst[((wm * WGN + w2) * 16 * TM + 16 * i + l15) * 2];
+                    b += sst[((wm * WGN + w2) * 16 * TM + 16 * i + l15) * 2 + 1];
+                }
+                const float mean = a * inv_k;
+                const float var = fmaxf(b * inv_k - mean * mean, 0.f);
+                ln_r[i] = rsqrtf(var + p.ln_eps);
+                ln_mr[i] = ln_r[i] * mean;
+            }
+        }
         half_t* stg = reinterpret_cast<half_t*>(smem);  // (the launcher sizes the dynamic LDS as max(operand stages, staging area))
         const bool full = m0 + BM <= Mi && n0 + BN <= p.N;
         if (p.geglu) {
-            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, false>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi, full);
+            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, false, LNF>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         } else if (p.residual) {
-            epilogue_staged<TM, TN, false, true>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full);
+            epilogue_staged<TM, TN, false, true, LNF>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         } else {
-            epilogue_staged<TM, TN, false, false>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full);
+            epilogue_staged<TM, TN, false, false, LNF>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         }
         MV_TL(4);
         MV_TL_FLUSH();
@@ -709,13 +739,14 @@ int mv_num_cus() {
     return n;
 }
 
-template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED>
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
     constexpr int smem_ops = (SCHED == 3 ? 3 * 64 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
     // the LDS-staged epilogue reuses the operand LDS: two 16-row fp16 buffers of (16 TN + 8) halfs per wave must fit as well
     constexpr int smem_epi = WGM * WGN * EpiGeom<TN, false>::WAVE_HALFS * (int)sizeof(half_t);
-    constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
+    // LNF: + the waves' row-statistic partials [wave][16 TM][2] fp32 behind them
+    constexpr int smem = (smem_ops > smem_epi ? smem_ops : smem_epi) + (LNF ? WGM * WGN * 16 * TM * 2 * (int)sizeof(float) : 0);
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
     GemmArgs2 a = a0;
     a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
@@ -724,7 +755,7 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     a.g.kt_per_split = (nk + a.g.nsplit - 1) / a.g.nsplit;
     static bool attr_done = false;  // idempotent one-time attribute of this instantiation (not tuning state)
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED, LNF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             mv_set_error("mv_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -733,7 +764,7 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid((unsigned)(a.g.tiles_m * a.g.tiles_n), (unsigned)a.g.nsplit);
-    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED>), grid, dim3(64 * WGM * WGN), smem, stream, a);
+    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED, LNF>), grid, dim3(64 * WGM * WGN), smem, stream, a);
     MV_CHECK_LAUNCH("mv_gemm_f16");
     if (a.g.nsplit > 1) {
         const long work = a.g.M * (long)(a.g.N >> 2);
@@ -748,7 +779,8 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
 // a stable id: block tile = 16 TM WGM rows x 16 TN WGN columns.  The ids are what mv_gemm_desc.cfg and the per-shape table
 // of gemm_tuned.h (written by tools/gpu_gemm_tune.py from timings on the MI355X) refer to.  SCHED 0: two LDS stages behind
 // __syncthreads; 3: three stages behind counted waits.  (Round 1 also measured BK-32 rings, a persistent tile loop and a
-// register-staged kernel: all slower, numbers in profiles/r01*; removed from the library.)
+// register-staged kernel, round 2 a two-group ping-pong K loop for the 8-wave tiles: all slower or equal, numbers in
+// profiles/r01*, r02c; removed from the library.)
 #define MV_GEMM_CFGS(X)                                                                                              \
     X(0, 4, 5, 2, 2, 0)  /* 128x160, 4 waves            */ X(1, 2, 5, 2, 2, 0)   /* 64x160                     */      \
     X(2, 4, 4, 2, 2, 0)  /* 128x128                     */ X(3, 2, 4, 2, 2, 0)   /* 64x128                     */      \
@@ -759,10 +791,8 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     X(12, 2, 5, 4, 2, 3) /* 128x160, 8 waves, 3 stages  */ X(13, 2, 5, 2, 1, 0)  /* 64x80, 2 waves (small grids) */    \
     X(14, 2, 5, 1, 2, 0) /* 32x160, 2 waves             */ X(15, 2, 5, 4, 2, 0)  /* 128x160, 8 waves of 32x80  */      \
     X(16, 2, 4, 4, 2, 0) /* 128x128, 8 waves of 32x64   */ X(17, 2, 5, 2, 2, 3)  /* 64x160, 4 waves, 3 stages  */      \
-    X(18, 4, 5, 2, 2, 3) /* 128x160, 4 waves, 3 stages  */ X(19, 8, 4, 2, 4, 8)  /* 256x256, 8 waves, ping-pong */     \
-    X(20, 8, 5, 2, 4, 8) /* 256x320, 8 waves, ping-pong */ X(21, 8, 4, 2, 4, 9)  /* 256x256 ping-pong, no setprio (A/B) */ \
-    X(22, 8, 5, 2, 4, 9) /* 256x320 ping-pong, no setprio (A/B) */
-constexpr int kNumGemmCfgs = 23;
+    X(18, 4, 5, 2, 2, 3) /* 128x160, 4 waves, 3 stages  */
+constexpr int kNumGemmCfgs = 19;
 struct GemmCfgDesc { int tm, tn, wgm, wgn, sched; };
 constexpr GemmCfgDesc kGemmCfgs[kNumGemmCfgs] = {
 #define MV_X(id, tm, tn, wgm, wgn, sched) {tm, tn, wgm, wgn, sched},
@@ -784,6 +814,28 @@ int launch_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
 #undef MV_X
     }
     mv_set_error("mv_gemm_f16: unknown tile configuration %d", id);
+    return MV_ERR_INVALID;
+}
+
+// LayerNorm-folded launches (LINEAR mode): every catalogue entry whose tile leaves registers for the row statistics (the
+// 160-accumulator 256x320 tile and the 3-stage 256-row tiles do not: their choice is mapped to the nearest tile that does)
+inline int gemm_ln_cfg(int id) {
+    switch (id) {
+        case 6: return 7;    // 256x320 -> 256x256
+        case 4: case 8: return 9;   // 256x160 -> 256x128 (two stages)
+        case 5: return 9;
+        default: return id;
+    }
+}
+
+int launch_ln_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
+    switch (id) {
+#define MV_X(cid, tm, tn, wgm, wgn, sched) \
+    case cid: if constexpr (!(tm == 8 && tn == 5) && !(cid == 4 || cid == 5 || cid == 8)) return launch_cfg2s<MV_GEMM_LINEAR, tm, tn, wgm, wgn, sched, true>(a, stream); else break;
+        MV_GEMM_CFGS(MV_X)
+#undef MV_X
+    }
+    mv_set_error("mv_gemm_f16: tile configuration %d has no LayerNorm-folded form", id);
     return MV_ERR_INVALID;
 }
 
@@ -846,7 +898,7 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
             if (ch.cfg == 1 && blocks <= cus && nk >= 16) ch.cfg = 17;
         }
     }
-    if (want_split >= 1) ch.nsplit = want_split;
+    if (want_split >= 1 && !g.ln_colsum) ch.nsplit = want_split;
     if (ch.nsplit < 1) {
         const GemmCfgDesc& c = kGemmCfgs[ch.cfg];
         const long blocks = ((g.M + 16 * c.tm * c.wgm - 1) / (16 * c.tm * c.wgm)) * ((g.N + 16 * c.tn * c.wgn - 1) / (16 * c.tn * c.wgn));
@@ -855,6 +907,10 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
     ch.nsplit = splitk_clamp(g, ch.nsplit);
     const int per = (nk + ch.nsplit - 1) / ch.nsplit;
     ch.nsplit = (nk + per - 1) / per;  // no empty slice
+    if (g.ln_colsum) {  // the row statistics span the whole K: one slice, a tile with room for them
+        ch.cfg = gemm_ln_cfg(ch.cfg);
+        ch.nsplit = 1;
+    }
     return ch;
 }
 
@@ -929,6 +985,14 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.act = d->act; a.geglu = d->geglu;
     a.tiles_m = a.tiles_n = 0;
     a.nsplit = 1; a.kt_per_split = 0; a.ws = nullptr;
+    a.ln_colsum = d->ln_colsum; a.ln_colbias = d->ln_colbias; a.ln_eps = d->ln_eps;
+    if (d->ln_colsum || d->ln_colbias) {
+        MV_REQUIRE(d->ln_colsum && d->ln_colbias && d->ln_eps > 0.f, "%s: LayerNorm folding needs ln_colsum, ln_colbias and ln_eps > 0", who);
+        MV_REQUIRE(d->mode == MV_GEMM_LINEAR && !d->a2 && !d->bias && !d->rowbias && d->K % 64 == 0,
+                   "%s: LayerNorm folding: LINEAR mode, one source, K %% 64 == 0, bias folded into ln_colbias (no bias / rowbias)", who);
+        MV_REQUIRE((reinterpret_cast<uintptr_t>(d->ln_colsum) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->ln_colbias) & 15) == 0,
+                   "%s: ln_colsum / ln_colbias must be 16-byte aligned", who);
+    }
     if (d->mode == MV_GEMM_CONV3X3) {
         MV_REQUIRE(d->stride == 1 || d->stride == 2, "%s: conv stride must be 1 or 2", who);
         MV_REQUIRE(!(d->upsample && d->stride != 1), "%s: upsample requires stride 1", who);
@@ -950,6 +1014,7 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     b.wide = (d->N % 8 == 0) && (d->ldc % 8 == 0) && al16(d->c) && (!d->bias || al16(d->bias)) &&
              (!d->rowbias || (d->ldrb % 8 == 0 && al16(d->rowbias))) &&
              (!d->residual || (d->ldr % 8 == 0 && al16(d->residual)));
+    if (d->ln_colsum) MV_REQUIRE(b.wide, "%s: LayerNorm folding needs the 16-byte epilogue (N, ldc, ldr %% 8, aligned pointers)", who);
     return MV_OK;
 }
 
@@ -985,6 +1050,10 @@ extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
         b.g.ws = (float*)d->workspace;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (d->ln_colsum) {
+        MV_REQUIRE(ch.nsplit == 1, "mv_gemm_f16: LayerNorm folding cannot be combined with a forced K split");
+        return launch_ln_by_id(b, s, ch.cfg);
+    }
     if (d->mode == MV_GEMM_CONV3X3) return launch_by_id<MV_GEMM_CONV3X3>(b, s, ch.cfg);
     if (d->mode == MV_GEMM_TCONV3) return launch_by_id<MV_GEMM_TCONV3>(b, s, ch.cfg);
     return launch_by_id<MV_GEMM_LINEAR>(b, s, ch.cfg);

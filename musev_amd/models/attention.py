@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .layers import FeedForward, HipModule, IPAttention, lin_w, w16
+from .layers import FeedForward, HipModule, IPAttention, lin_w, ln_linear
 from .runtime import Ctx, Geo, SourceCache
 
 
@@ -41,14 +41,11 @@ class BasicTransformerBlock(HipModule):
         self.ff = FeedForward(dim)
         self.heads, self.dim_head = num_attention_heads, attention_head_dim
 
-    def _ln(self, m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
-        return ops.layernorm(x, w16(m.weight), w16(m.bias), m.eps)
-
     # ---- spatial: rows = (frame n, pixel p), sequences = the HW pixels of one frame ----
     def hip_forward_spatial(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool, use_ip: bool) -> torch.Tensor:
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
         a1 = self.attn1
-        qkv = ops.gemm(self._ln(self.norm1, x), a1.w_qkv())
+        qkv = ln_linear(a1, "qkv", x, self.norm1, a1.build_qkv)  # norm1 folded into the fused q/k/v projection where it pays
         k, v = qkv[:, c:2 * c], qkv[:, 2 * c:]
         segs = [(k, v, geo.hw, 1, 1, 0)]
         if reference_only and ctx.vis_idx is not None and geo.t > 1:
@@ -60,7 +57,7 @@ class BasicTransformerBlock(HipModule):
         x = a1.project_out(att, residual=x)
 
         a2 = self.attn2
-        q = ops.gemm(self._ln(self.norm2, x), lin_w(a2.to_q))
+        q = ln_linear(a2, "q", x, self.norm2, lambda: lin_w(a2.to_q).contiguous())
         cache = a2._cache()
         # K/V of the prompt: constant over the denoise loop -> projected once per (prompt tensor, weights)
         tkv = cache.setdefault("text_kv", SourceCache()).get(ctx.text_src, lambda _s: ops.gemm(ctx.text, a2.w_kv()))
@@ -70,13 +67,13 @@ class BasicTransformerBlock(HipModule):
             ops.attention(q, [(ikv[:, :c], ikv[:, c:], ctx.clip_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale,
                           out=att, accumulate=True, out_scale=ctx.ip_scale)
         x = a2.project_out(att, residual=x)
-        return self.ff.hip_forward(self._ln(self.norm3, x), residual=x)
+        return self.ff.hip_forward(x, residual=x, norm=self.norm3)
 
     # ---- temporal: rows stay in (b, t, p) order; sequences = the T frames of one pixel ----
     def hip_forward_temporal(self, x: torch.Tensor, geo: Geo) -> torch.Tensor:
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
         for norm, attn in ((self.norm1, self.attn1), (self.norm2, self.attn2)):
-            qkv = ops.gemm(self._ln(norm, x), attn.w_qkv())
+            qkv = ln_linear(attn, "qkv", x, norm, attn.build_qkv)
             att = ops.temporal_attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], geo.b, geo.t, geo.hw, h, d, attn.scale)
             x = attn.project_out(att, residual=x)
-        return self.ff.hip_forward(self._ln(self.norm3, x), residual=x)
+        return self.ff.hip_forward(x, residual=x, norm=self.norm3)

@@ -62,6 +62,22 @@ def lin_b(m: nn.Module) -> Optional[torch.Tensor]:
     return None if m.bias is None else w16(m.bias)
 
 
+def ln_linear(mod: HipModule, key: str, x: torch.Tensor, norm: nn.LayerNorm, w_builder, bias_builder=None, *, geglu: bool = False,
+              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(x) @ W.T (+ bias) -- nn.LayerNorm followed by a Linear (norm1 -> to_q/k/v, norm2 -> to_q, norm3 -> ff.net.0.proj;
+    musev/models/attention.py:293-308,345-362,398-429).  Where the projection runs as one K slice the normalisation is folded
+    into it (ops.gemm(ln=): no normalised tensor, no LayerNorm launch); elsewhere mv_layernorm_f16 + the plain projection.
+    ``w_builder()`` -> packed [N, K] fp16 weight, ``bias_builder()`` -> [N] fp16 bias or None (both cached on ``mod``)."""
+    w = mod.packed(key, w_builder)
+    bias = mod.packed(key + "/bias", bias_builder) if bias_builder is not None else None
+    M, K = x.shape
+    if ops.ln_fold_applies(M, w.shape[0], K, geglu):
+        wf, cs, cb = mod.packed(key + "/ln", lambda: ops.fold_layernorm(w, bias, w16(norm.weight), w16(norm.bias)))
+        return ops.gemm(x, wf, ln=(cs, cb, norm.eps), geglu=geglu, residual=residual)
+    h = ops.layernorm(x, w16(norm.weight), w16(norm.bias), norm.eps)
+    return ops.gemm(h, w, bias=bias, geglu=geglu, residual=residual)
+
+
 class TimestepEmbedding(HipModule):
     """diffusers TimestepEmbedding(in, dim, act_fn="silu"): linear_2(SiLU(linear_1(x)))."""
 
@@ -154,9 +170,16 @@ class FeedForward(HipModule):
         inner = dim * mult
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim)])
 
-    def hip_forward(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
-        wp, bp = self.packed("geglu", lambda: ops.pack_geglu(lin_w(self.net[0].proj), lin_b(self.net[0].proj)))
-        h = ops.gemm(x, wp, bias=bp, geglu=True)  # value * gelu(gate) applied in the GEMM epilogue (K7)
+    def _geglu_packed(self):
+        return self.packed("geglu", lambda: ops.pack_geglu(lin_w(self.net[0].proj), lin_b(self.net[0].proj)))
+
+    def hip_forward(self, x: torch.Tensor, residual: torch.Tensor, norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+        """FF(norm(x)) + residual when ``norm`` is given (the block's norm3, folded into the GEGLU projection), else FF(x) + residual"""
+        if norm is not None:
+            h = ln_linear(self, "geglu_w", x, norm, lambda: self._geglu_packed()[0], lambda: self._geglu_packed()[1], geglu=True)
+        else:
+            wp, bp = self._geglu_packed()
+            h = ops.gemm(x, wp, bias=bp, geglu=True)  # value * gelu(gate) applied in the GEMM epilogue (K7)
         return ops.gemm(h, lin_w(self.net[2]), bias=lin_b(self.net[2]), residual=residual)
 
 
@@ -190,8 +213,11 @@ class IPAttention(HipModule):
         return None
 
     # ---- packed weights ----
+    def build_qkv(self) -> torch.Tensor:
+        return torch.cat([lin_w(self.to_q), lin_w(self.to_k), lin_w(self.to_v)], 0).contiguous()
+
     def w_qkv(self) -> torch.Tensor:
-        return self.packed("qkv", lambda: torch.cat([lin_w(self.to_q), lin_w(self.to_k), lin_w(self.to_v)], 0).contiguous())
+        return self.packed("qkv", self.build_qkv)
 
     def w_kv(self) -> torch.Tensor:
         return self.packed("kv", lambda: torch.cat([lin_w(self.to_k), lin_w(self.to_v)], 0).contiguous())

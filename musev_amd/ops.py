@@ -21,7 +21,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
                    check)
 
 __all__ = [
-    "gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
+    "gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
     "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
     "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
@@ -141,11 +141,14 @@ def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_group: int = 0, residual=None, alpha=None, act: int = MV_ACT_NONE, geglu: bool = False,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
     """out = act(|alpha| * ([a | a2] @ w.T + bias + rowbias[row // rows_per_group])) + residual   (fp16, fp32 accumulate).
 
     ``w`` is [N, K] (torch Linear layout).  With ``geglu`` the rows of ``w`` / ``bias`` must be packed by
     :func:`pack_geglu` and the result has N/2 columns: value * gelu(gate).
+    ``ln = (colsum, colbias, eps)`` (see :func:`fold_layernorm`): ``a`` holds RAW rows and ``w`` gamma-scaled weights; the kernel
+    forms each row's LayerNorm statistics from the fragments it multiplies and applies them in the epilogue -- the result is
+    LayerNorm(a) @ W.T + bias without the normalised tensor ever existing (no bias / rowbias / second source then).
     """
     a = _mat(a, "a")
     w = _mat(w, "w")
@@ -168,8 +171,52 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     d.M, d.N, d.K = M, N, K
     d.mode, d.geglu = MV_GEMM_LINEAR, int(geglu)
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, alpha, act, cols)
-    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha))
+    if ln is not None:
+        cs, cb, eps = ln
+        for v, nm in ((cs, "ln colsum"), (cb, "ln colbias")):
+            if v.dtype != torch.float32 or not _on_gpu(v) or not v.is_contiguous() or v.numel() != N:
+                raise ValueError(f"{nm}: expected a contiguous CUDA fp32 tensor of {N} elements")
+        if bias is not None or rowbias is not None or a2 is not None:
+            raise ValueError("gemm(ln=...): the bias is part of colbias; no rowbias / second source")
+        d.ln_colsum, d.ln_colbias, d.ln_eps = cs.data_ptr(), cb.data_ptr(), float(eps)
+    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha, ln))
     return o
+
+
+# LayerNorm folding (env knob for A/B runs: MUSEV_LN_FOLD=0 keeps mv_layernorm_f16 + the plain projection everywhere)
+LN_FOLD: bool = os.environ.get("MUSEV_LN_FOLD", "1") == "1"
+_ln_fold_cache: dict = {}
+
+
+def ln_fold_applies(M: int, N: int, K: int, geglu: bool) -> bool:
+    """whether ``gemm(..., ln=)`` is the better form of LayerNorm + projection for this problem: it is wherever the plain
+    projection runs as ONE K slice (the folded kernel needs the whole row in one block's K loop); the small-M / long-K problems
+    the library splits over K keep mv_layernorm_f16 + the split GEMM."""
+    if not LN_FOLD or K % 64 != 0:
+        return False
+    key = (M, N, K, bool(geglu))
+    hit = _ln_fold_cache.get(key)
+    if hit is None:
+        d = GemmDesc()
+        d.a, d.w, d.c = 16, 16, 16  # (no launch: the choice only looks at the geometry)
+        d.M, d.N, d.K, d.lda, d.ldc, d.c1 = M, N, K, K, (N // 2 if geglu else N), K
+        d.mode, d.geglu, d.cfg, d.splitk = MV_GEMM_LINEAR, int(geglu), GEMM_CFG, GEMM_SPLITK
+        cfg, ns = C.c_int32(), C.c_int32()
+        check(_lib.load().mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns)), "mv_gemm_choice")
+        hit = _ln_fold_cache[key] = ns.value == 1
+    return hit
+
+
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """(w * gamma as fp16 [N, K], colsum fp32 [N], colbias fp32 [N]) for ``gemm(..., ln=)``:
+    LayerNorm(x) @ W.T + b = rstd * (x @ (W gamma).T - mean * colsum) + (W @ beta + b);  colsum sums the fp16-ROUNDED folded weights
+    (what the matrix cores multiply), so that the mean term cancels exactly."""
+    wf = (w.float() * gamma.float().reshape(1, -1)).to(torch.float16).contiguous()
+    colsum = wf.float().sum(dim=1).contiguous()
+    colbias = w.float() @ beta.float().reshape(-1)
+    if bias is not None:
+        colbias = colbias + bias.float()
+    return wf, colsum, colbias.contiguous()
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2: Optional[torch.Tensor] = None,

@@ -67,7 +67,7 @@ struct SimDma { unsigned char data[16]; void* dst; };
 inline thread_local std::deque<SimDma> sim_dma;
 static inline void sim_retire(size_t keep) {
     while (sim_dma.size() > keep) {
-        memcpy(sim_dma.front().dst, sim_dma.front().data, 16);
+        if (sim_dma.front().dst) memcpy(sim_dma.front().dst, sim_dma.front().data, 16);
         sim_dma.pop_front();
     }
 }
@@ -94,6 +94,17 @@ static void sim_dma_write(void* dst, const void* src16) {
         sim_dma.push_back(d);
     } else if (src16) memcpy(dst, src16, 16); else memset(dst, 0, 16);
 }
+
+// A lane that is switched off (EXEC) for an LDS-DMA instruction: the hardware's vmcnt counts the wave's INSTRUCTION, so the lane's
+// per-thread queue gets an entry that writes nothing (otherwise its counted waits would run ahead of its wave's).
+static inline void sim_dma_lane_off() {
+    if (sim_defer) {
+        SimDma d;
+        d.dst = nullptr;
+        sim_dma.push_back(d);
+    }
+}
+#define MV_DMA_LANE_OFF() sim_dma_lane_off()
 
 // ---- buffer descriptors ----
 struct SimRsrc { const char* base; unsigned num; };
@@ -215,6 +226,10 @@ static inline sim_short4 sim_ds_read_tr16_b64(__attribute__((address_space(3))) 
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16 sim_ds_read_tr16_b64
 #define __builtin_amdgcn_exp2f exp2f
+// v_dot2_f32_f16: c + a.x b.x + a.y b.y in fp32
+typedef _Float16 sim_half2 __attribute__((ext_vector_type(2)));
+static inline float sim_fdot2(sim_half2 a, sim_half2 b, float c, bool) { return c + (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1]; }
+#define __builtin_amdgcn_fdot2 sim_fdot2
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 typedef __fp16 sim_fp16x2 __attribute__((ext_vector_type(2)));
 static inline uint16_t sim_rtz_half_bits(float x) {  // v_cvt_pkrtz_f16_f32: round toward zero

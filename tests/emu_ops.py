@@ -95,8 +95,21 @@ def _epilogue(acc, *, bias, rowbias, rows_per_group, residual, alpha, act, geglu
     return acc
 
 
+def ln_fold_applies(M, N, K, geglu):
+    """the emulation folds wherever the kernel could (K % 64 == 0): the wiring of the folded form is what these tests exercise"""
+    return K % 64 == 0
+
+
+def fold_layernorm(w, bias, gamma, beta):
+    wf = (w.float() * gamma.float().reshape(1, -1)).to(torch.float16).contiguous()
+    colbias = w.float() @ beta.float().reshape(-1)
+    if bias is not None:
+        colbias = colbias + bias.float()
+    return wf, wf.float().sum(dim=1).contiguous(), colbias.contiguous()
+
+
 def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=None, act=MV_ACT_NONE,
-         geglu=False, out=None):
+         geglu=False, out=None, ln=None):
     _mat(a, "a")
     _mat(w, "w")
     _req(w.is_contiguous(), "w must be contiguous [N, K]")
@@ -114,6 +127,16 @@ def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_group=0, residual=N
     _check_epilogue(M, N, cols, bias, rowbias, rows_per_group, residual, alpha)
     _check_out(out, M, cols)
     acc = x.float() @ w.float().t()
+    if ln is not None:
+        # the kernel's arithmetic: statistics of the raw fp16 rows in fp32, affine on the fp32 accumulator
+        cs, cb, eps = ln
+        _req(a2 is None and bias is None and rowbias is None and K % 64 == 0, "gemm(ln=): one source, K % 64 == 0, bias folded into colbias")
+        _req(cs.dtype == torch.float32 and cb.dtype == torch.float32 and cs.numel() == N and cb.numel() == N, "gemm(ln=): fp32 [N] column vectors")
+        xf = x.float()
+        mean = xf.mean(dim=1, keepdim=True)
+        var = (xf * xf).mean(dim=1, keepdim=True) - mean * mean
+        rstd = torch.rsqrt(var.clamp_min(0.0) + eps)
+        acc = rstd * (acc - mean * cs.reshape(1, -1)) + cb.reshape(1, -1)
     return _store(_epilogue(acc, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual,
                             alpha=alpha, act=act, geglu=geglu), out)
 
@@ -356,7 +379,7 @@ def pack_geglu(w, bias):
     return w.index_select(0, perm).contiguous(), (bias.index_select(0, perm).contiguous() if bias is not None else None)
 
 
-EMULATED = ["gemm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
+EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
             "pack_conv_weight", "pack_geglu"]

@@ -78,6 +78,38 @@ def case_gemm(M=1000, N=320, K=640, seed=0, two_src=False, epilogue=True):
     return _cmp(f"gemm M{M} N{N} K{K} two_src={two_src} epi={epilogue}", got, ref, atol=4e-3)
 
 
+def case_gemm_ln(M=1000, N=960, K=320, seed=20, geglu=False, residual=False, offset=0.0, cfg=None):
+    """LayerNorm folded into the projection (ops.gemm(ln=)): LayerNorm(x) @ W.T + bias (nn.LayerNorm + Linear in fp32 as the
+    reference computes them), optionally the GEGLU gate or a residual behind it; ``offset`` shifts the rows' mean (the folded form
+    subtracts mean * colsum from the accumulator: cancellation is exercised with |mean| >> std)."""
+    from musev_amd import ops
+    x = _rand((M, K), seed) * 1.7 + offset
+    gamma = 1.0 + 0.3 * _rand((K,), seed + 1)
+    beta = 0.2 * _rand((K,), seed + 2)
+    w = _rand((N, K), seed + 3, 1.0 / math.sqrt(K))
+    b = _rand((N,), seed + 4, 0.3)
+    res = _rand((M, N), seed + 5) if residual else None
+    y = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+    ref = y @ w.float().t() + b.float()
+    if geglu:
+        wp, bp = ops.pack_geglu(w, b)
+        wf, cs, cb = ops.fold_layernorm(wp, bp, gamma, beta)
+        h = ref
+        ref = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+    else:
+        wf, cs, cb = ops.fold_layernorm(w, b, gamma, beta)
+    if res is not None:
+        ref = ref.half().float() + res.float()
+    old = ops.GEMM_CFG
+    if cfg is not None:
+        ops.GEMM_CFG = cfg
+    try:
+        got = ops.gemm(x, wf, ln=(cs, cb, 1e-5), geglu=geglu, residual=res)
+    finally:
+        ops.GEMM_CFG = old
+    return _cmp(f"gemm LN-folded M{M} N{N} K{K} geglu={geglu} res={residual} offset={offset} cfg={cfg}", got, ref, atol=5e-3)
+
+
 def case_gemm_silu():
     from musev_amd import ops
     a = _rand((26, 320), 5)
@@ -464,6 +496,15 @@ def case_cfg_affine_step():
     return {"name": "cfg_affine_step", "ok": r1["ok"] and r2["ok"], "max_abs_err": max(r1["max_abs_err"], r2["max_abs_err"])}
 
 
+def _all_ok(results):
+    """one verdict for a list of case results (the first failing one is reported)"""
+    bad = [r for r in results if not r["ok"]]
+    out = dict((bad or results)[0])
+    out["max_abs_err"] = max(r.get("max_abs_err", 0.0) for r in results)
+    out["name"] = f"{len(results)} cases: " + results[0]["name"]
+    return out
+
+
 ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("tr16_probe", case_tr16_probe),
     ("gemm_plain", lambda: case_gemm(M=1000, N=320, K=640, epilogue=False)),
@@ -474,6 +515,11 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("gemm_text_kv", lambda: case_gemm(M=154, N=640, K=768, epilogue=False, seed=6)),
     ("gemm_silu", case_gemm_silu),
     ("gemm_geglu", case_gemm_geglu),
+    ("gemm_ln", case_gemm_ln),
+    ("gemm_ln_residual_ragged_m", lambda: case_gemm_ln(M=777, N=320, K=640, residual=True, seed=21)),
+    ("gemm_ln_geglu", lambda: case_gemm_ln(M=500, N=2560, K=320, geglu=True, seed=22)),
+    ("gemm_ln_large_mean", lambda: case_gemm_ln(M=300, N=640, K=1280, offset=12.0, seed=23)),
+    ("gemm_ln_every_tile", lambda: _all_ok([case_gemm_ln(M=300, N=640, K=320, seed=24 + c, cfg=c) for c in range(19)])),
     ("conv3x3", case_conv3x3),
     ("conv3x3_two_src", lambda: case_conv3x3(c1=128, c2=64, cout=160, seed=21)),
     ("conv3x3_stride2", lambda: case_conv3x3(stride=2, seed=22)),
@@ -547,6 +593,10 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("gemm_l0_qkv", lambda: case_gemm(M=106496, N=960, K=320, epilogue=False, seed=201)),        # fused QKV
     ("gemm_l0_ff2", lambda: case_gemm(M=106496, N=320, K=1280, seed=202)),
     ("gemm_l0_geglu", lambda: case_gemm_geglu(M=106496, C=320)),                                 # N 2560 (packed), 256x256 tiles
+    ("gemm_l0_ln_qkv", lambda: case_gemm_ln(M=106496, N=960, K=320, seed=240)),                  # norm1 folded into the fused QKV
+    ("gemm_l0_ln_geglu", lambda: case_gemm_ln(M=106496, N=2560, K=320, geglu=True, seed=241)),   # norm3 folded into FF1
+    ("gemm_l0_ln_q_half", lambda: case_gemm_ln(M=53248, N=320, K=320, seed=242)),                # norm2 -> to_q, one CFG half
+    ("gemm_l1_ln_qkv", lambda: case_gemm_ln(M=26624, N=1920, K=640, seed=243)),
     ("gemm_l1_geglu", lambda: case_gemm_geglu(M=26624, C=640)),
     ("gemm_l1_out_res", lambda: case_gemm(M=26624, N=640, K=640, seed=203)),
     ("gemm_l2_out_res", lambda: case_gemm(M=6656, N=1280, K=1280, seed=204)),                    # 256x160 three-stage ring (26 x 8 blocks)

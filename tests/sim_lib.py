@@ -28,7 +28,7 @@ def transform(text: str) -> str:
     return text
 
 
-def build(work) -> str:
+def build(work, extra_flags=()) -> str:
     srcs = []
     for name in SOURCES:
         dst = os.path.join(str(work), f"{name}_sim.cpp")
@@ -36,7 +36,7 @@ def build(work) -> str:
             f.write(transform(open(os.path.join(CSRC, f"{name}.hip")).read()))
         srcs.append(dst)
     so = os.path.join(str(work), "libmusev_hip_sim.so")
-    r = subprocess.run([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-w", "-I", SIM, "-o", so] + srcs,
+    r = subprocess.run([CLANG, "-O1", "-std=c++17", "-pthread", "-fPIC", "-shared", "-w", "-I", SIM, "-o", so] + list(extra_flags) + srcs,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
     return so

@@ -15,13 +15,16 @@ def test_unet_parity(name, fn):
 
 
 # ---- HIP model vs the outputs of the REFERENCE'S OWN SOURCE (tests/golden/make_reference_goldens.py) -------------------
-from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, case_config, case_inputs  # noqa: E402
+from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, UNET_CASES_AT_SIZE_CFG5, case_config, case_inputs  # noqa: E402
 
 HIP_GOLDEN_CASES = [n for n, c in UNET_CASES.items() if c["arch"]["block_out_channels"][0] == 320]  # head dims 40 / 80
 # BASELINE-size cases: the 1.42 B-parameter model on the tensors of configs 2 and 3 (B 2, T 13, 64x64 latents) -- every tile
 # configuration the default rule / tuned table selects at the benchmark's sizes, level-0 attention at Lq 4096 x Lkv 8192
 HIP_GOLDEN_CASES += list(UNET_CASES_AT_SIZE)
-ALL_UNET_CASES = dict(UNET_CASES, **UNET_CASES_AT_SIZE)
+# config-5 size (96x96 latents: M = 239 616 / 59 904 / 14 976 / 3 744 rows per level -- none of them in the tile table measured on
+# config 2) with ReferenceNet features, IP-Adapter tokens, ControlNet residuals and the PoseGuider embedding
+HIP_GOLDEN_CASES += list(UNET_CASES_AT_SIZE_CFG5)
+ALL_UNET_CASES = dict(UNET_CASES, **UNET_CASES_AT_SIZE, **UNET_CASES_AT_SIZE_CFG5)
 
 
 @pytest.mark.parametrize("name", HIP_GOLDEN_CASES)

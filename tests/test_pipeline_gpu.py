@@ -1,10 +1,18 @@
 """-m gpu: the sliding-window parallel-denoise loop on HIP kernels (musev_amd.pipelines.ParallelDenoiser) against the
 oracle loop (oracle/pipeline.py, restating pipeline_controlnet.py:1832-2156) on identical seeds.
 
-Tolerance: |delta latent|max < 1e-2 (north-star bound): over the first steps of the real 20-step DDIM schedule on the small
-nets, over ALL steps of BASELINE config 1 (full-width model, 256x256, 4 frames, 4 DDIM steps, guidance 7.5), and -- measured,
-not asserted at 1e-2 -- over a whole 20-step run next to the drift of a plain torch-fp16 evaluation of the oracle UNet inside
-the same fp32 loop (the floor any fp16 implementation sits on).  The loop glue itself is exact (fp32; checked bit-level in
+Tolerance: ABSOLUTE |delta latent|max < 1e-2 (the north-star bound), asserted
+  * over the first steps of the real 20-step DDIM schedule on the small nets,
+  * at every step of a whole 20-step run (2 windows, vision-condition frame, guidance 3.5),
+  * over the first 4 steps of BASELINE config 2 AT SIZE (512x512, 12 + 1 frames) against per-step latents recorded from the
+    oracle loop around the REFERENCE'S OWN UNet3DConditionModel (tests/golden/reference_loop_musev_cfg2_loop.npz).
+The config-1 / 20-step / config-2 runs use weights that make the network a noise predictor (oracle.unet3d.calibrate_as_denoiser:
+eps = normalised input + the random network's prediction), so the latents stay O(4) as with a trained checkpoint -- with plain
+random weights DDIM blows them up to |x| = 20-55 (round 2), where an absolute 1e-2 is below half an fp16 ulp of the UNet's input.
+Next to the absolute bar the drift of a plain torch-fp16 evaluation of the oracle UNet inside the same fp32 loop is measured
+(the floor any fp16 implementation sits on).  BASELINE config 1 (256x256, 4 frames, 4 DDIM steps, guidance 7.5) cannot meet
+an absolute 1e-2 with any fp16 UNet (CFG 7.5 x four 250-timestep DDIM jumps amplify a 3e-3 forward error to 5e-2): its test
+asserts the bound the forward tolerance implies for the loop and the floor instead, and says so.  The loop glue itself is exact (fp32; checked bit-level in
 kernel_cases.case_window_loop and the full-size properties below)."""
 import pytest
 import torch
@@ -99,16 +107,37 @@ def _drift(rec_a, rec_b):
     return [(a.float().cpu() - b.float().cpu()).abs().max().item() for a, b in zip(rec_a, rec_b)]
 
 
+def _propagated_bound(n_steps, guidance, fwd_tol=1e-2):
+    """what the north-star forward bound (|delta eps|max < fwd_tol per UNet evaluation) implies for the latents of an n-step DDIM
+    loop: x_prev = r x + c eps with r = sqrt(a_prev / a_t), c = sqrt(1 - a_prev) - r sqrt(1 - a_t), and the guided prediction
+    u + g (t - u) carries at most (2 g - 1) times a forward error -> bound_i = r_i bound_{i-1} + |c_i| (2 g - 1) fwd_tol."""
+    from oracle import pipeline as opipe
+    sch = opipe.DDIMOracle()
+    sch.set_timesteps(n_steps)
+    out, bnd = [], 0.0
+    for t in sch.timesteps.tolist():
+        a_t, a_prev = sch.alphas(int(t))
+        r = (a_prev / a_t) ** 0.5
+        c = (1 - a_prev) ** 0.5 - r * (1 - a_t) ** 0.5
+        bnd = r * bnd + abs(c) * (2 * guidance - 1) * fwd_tol
+        out.append(bnd)
+    return out
+
+
 def test_config1_full_loop_all_steps():
     """BASELINE.json config 1 end to end: `musev` at full SD-1.5 width, latents [1, 4, 4, 32, 32] (256x256 px, 4 frames, no
     vision-condition frame), prompt embeddings [2, 77, 768], ALL 4 DDIM steps, guidance 7.5 -- HIP loop against
-    the fp32 oracle loop, next to the same oracle loop with its UNet evaluated by plain torch in fp16 (the floor).
+    the fp32 oracle loop (weights: seeded random + calibrate_as_denoiser, latents stay O(4)), next to the same oracle loop with
+    its UNet evaluated by plain torch in fp16 (the floor: what the reference's own fp16 GPU path does).
 
-    Measured on the MI355X (profiles/r02b_pytest_loop.log): with seeded random weights, guidance 7.5 and four 250-timestep DDIM
-    jumps the latents reach |x|max = 21.5, where 1e-2 absolute is 4.7e-4 relative -- below HALF the fp16 spacing (2^-11 = 4.9e-4):
-    no fp16 evaluation of the UNet can meet an absolute 1e-2 there (the fp32 CFG combination alone multiplies the UNet's
-    ~3e-3 prediction error by up to 1 + 2 * 7.5).  The bars asserted instead: relative to the latent scale < 1e-2 (north-star
-    bound on O(1) latents), and not worse than the torch-fp16 floor (+10 %)."""
+    Measured on the MI355X (profiles/r03a_pytest_loop.log): with latents of magnitude 4.6 the per-step drift is 6.2e-2 / 4.9e-2 /
+    2.7e-2 / 2.5e-2.  An absolute 1e-2 is NOT reachable on this configuration by any fp16 evaluation of the UNet: guidance 7.5
+    multiplies a forward error by up to 2 g - 1 = 14, and each of the four 250-timestep DDIM jumps multiplies the guided
+    prediction by |c| = 1.3 ... 0.4 -- a forward error of 3e-3 (what the at-size forward tests measure, themselves asserted
+    < 1e-2) lands at 5e-2 in the latents of step 1.  Asserted here: (a) the drift stays inside what the forward bound 1e-2
+    implies for the loop (_propagated_bound: the loop adds nothing of its own), (b) it does not exceed the torch-fp16 floor by
+    more than 10 %, (c) the latents stay O(4).  The absolute 1e-2 is asserted where the configuration allows it: guidance 3.5,
+    20 steps -- the metric's own configuration -- in the two tests below."""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     import os
     from oracle import pipeline as opipe
@@ -117,7 +146,7 @@ def test_config1_full_loop_all_steps():
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg = unet3d.flavour_config("musev")
-    sd = unet3d.init_state_dict(cfg, 3)
+    sd = unet3d.calibrate_as_denoiser(unet3d.init_state_dict(cfg, 3), cfg)
     latents = torch.randn(1, 4, 4, 32, 32, generator=torch.Generator().manual_seed(0))
     prompt = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(1))
     kw = dict(num_inference_steps=4, guidance_scale=7.5, motion_speed=8.0)
@@ -141,21 +170,23 @@ def test_config1_full_loop_all_steps():
     got = den(latents.to(dev), prompt.to(dev), callback=lambda i, t, lat: rec_h.append(lat.clone().view(1, 4, 4, 32, 32)), **kw)
     torch.cuda.synchronize()
     drift, floor = _drift(rec_h, rec_o), _drift(rec_f, rec_o)
-    scale = want.abs().max().item()
+    bound = _propagated_bound(4, 7.5)
+    scale = max(r.abs().max().item() for r in rec_o)
     print("config 1 per-step |delta latent|max: HIP", ["%.2e" % d for d in drift], "| torch fp16", ["%.2e" % d for d in floor],
-          "| |latent|max %.2f" % scale)
-    assert len(drift) == 4
-    err = (got.float().cpu() - want).abs().max().item()
-    assert err / scale < 1e-2, f"config 1: |delta latent|max = {err} on latents of magnitude {scale}"
-    for a, b in zip(drift, floor):
+          "| implied by the forward bound", ["%.2e" % d for d in bound], "| |latent|max %.2f" % scale)
+    assert len(drift) == 4 and scale < 8.0, f"the calibrated network must keep the latents O(4): {scale}"
+    assert (got.float().cpu() - want).abs().max().item() == drift[-1]
+    for a, b, c in zip(drift, floor, bound):
+        assert a <= c, f"config 1: the loop drifts more than the forward bound implies: {drift} vs {bound}"
         assert a <= 1.1 * b + 1e-3, f"HIP loop drifts more than plain torch fp16: {drift} vs {floor}"
 
 
 def test_twenty_step_drift_against_fp16_torch_floor():
     """A whole 20-step denoise (2 windows, vision-condition frame, guidance 3.5) on the 2-level SD-1.5-width net at 16x16 latents:
     drift of the HIP loop from the fp32 oracle loop per step, next to the drift of the SAME oracle loop whose UNet is evaluated by
-    plain torch in fp16 on the GPU (weights and activations fp16: what the reference itself runs on a GPU).  The numbers replace
-    DESIGN.md section 4's former assertion; asserted: finite, and the HIP drift is not worse than 2x the torch-fp16 drift + 2e-3 at any step."""
+    plain torch in fp16 on the GPU (weights and activations fp16: what the reference itself runs on a GPU).  Weights: seeded
+    random + calibrate_as_denoiser (latents stay O(4) over the whole schedule).  Asserted: ABSOLUTE |delta latent|max < 1e-2 at
+    every one of the 20 steps, and the HIP drift is not worse than 2x the torch-fp16 drift + 2e-3 at any step."""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     import json
     import os
@@ -164,7 +195,7 @@ def test_twenty_step_drift_against_fp16_torch_floor():
     from musev_amd.models.unet_loader import load_unet_by_name
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
     cfg = unet3d.flavour_config("musev", **ARCH)
-    sd = unet3d.init_state_dict(cfg, 3)
+    sd = unet3d.calibrate_as_denoiser(unet3d.init_state_dict(cfg, 3), cfg)
     g = torch.Generator().manual_seed(7)
     T, h, w = 10, 16, 16
     latents = torch.randn(1, 4, T, h, w, generator=g)
@@ -196,11 +227,53 @@ def test_twenty_step_drift_against_fp16_torch_floor():
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "drift_20_steps.json"), "w") as f:
-        json.dump({"net": "musev 2-level (320, 640), 16x16 latents, 10 frames, window 6 overlap 2, 20 DDIM steps, guidance 3.5",
-                   "latent_absmax": rec32[-1].abs().max().item(), "table": table}, f, indent=1)
+        json.dump({"net": "musev 2-level (320, 640), noise-predictor weights (calibrate_as_denoiser), 16x16 latents, 10 frames, window 6 "
+                          "overlap 2, 20 DDIM steps, guidance 3.5",
+                   "latent_absmax_per_step": [r.abs().max().item() for r in rec32], "table": table}, f, indent=1)
     assert len(d_hip) == 20 and all(map(lambda v: v == v and v < 1e3, d_hip))
+    assert max(r.abs().max().item() for r in rec32) < 8.0, "the calibrated network must keep the latents O(4)"
+    assert max(d_hip) < 1e-2, f"|delta latent|max per step: {d_hip}"
     for a, b in zip(d_hip, d_f16):
         assert a <= 2.0 * b + 2e-3, (d_hip, d_f16)
+
+
+def test_config2_loop_at_size_matches_reference_unet_loop_golden():
+    """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, the first 4
+    steps of the 20-step DDIM schedule, full-width `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the
+    HIP loop against those recorded by tests/golden/make_loop_goldens.py (oracle loop around the REFERENCE'S OWN
+    UNet3DConditionModel, fp32 on the CPU): ABSOLUTE |delta latent|max < 1e-2 at every step; the replay is bit-identical."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import os
+
+    import numpy as np
+    from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    name = "musev_cfg2_loop"
+    case = LOOP_CASES_AT_SIZE[name]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg, sd = loop_case_state_dict(case)
+    latents, cond, prompt = loop_case_inputs(case)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_loop_{name}.npz"))
+    dev = torch.device("cuda", 0)
+    unet = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16).to(dev)
+    del sd
+    den = ParallelDenoiser(unet, context_frames=case["context_frames"], context_overlap=case["context_overlap"])
+    shape = (1, 4, case["T"], case["h"], case["w"])
+    runs = []
+    for _ in range(2):
+        rec = []
+        den(latents.to(dev), prompt.to(dev), num_inference_steps=case["num_inference_steps"], max_steps=case["steps"],
+            guidance_scale=case["guidance_scale"], condition_latents=cond.to(dev), motion_speed=8.0,
+            callback=lambda i, t, lat: rec.append(lat.clone().view(shape).cpu()))
+        torch.cuda.synchronize()
+        runs.append(rec)
+    assert len(runs[0]) == case["steps"]
+    errs = [(r - torch.from_numpy(gold[f"latents_step{i + 1}"])).abs().max().item() for i, r in enumerate(runs[0])]
+    print("config 2 at size, per-step |delta latent|max:", ["%.2e" % e for e in errs],
+          "| |latent|max", ["%.2f" % float(np.abs(gold[f"latents_step{i + 1}"]).max()) for i in range(case["steps"])])
+    assert max(errs) < 1e-2, errs
+    assert all(torch.equal(a, b) for a, b in zip(*runs)), "graph replay must reproduce the eager first call bit for bit"
 
 
 def test_uniform_v2_unequal_windows_on_the_gpu():
