@@ -29,6 +29,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MV_DMA_LANE_OFF() ((void)0)
 #endif
 
+// a * b + c as ONE scalar v_fma_f32 the optimiser cannot merge into a packed-fp32 instruction.  Used for the row affine of the
+// LayerNorm-folded GEMM epilogue: hipcc packed that expression into v_pk_mul_f32 / v_pk_fma_f32 with op_sel operand swizzles
+// (the per-row scalars of two 16-row passes share a register pair), and on the MI355X the LOW results of exactly those
+// instructions came out wrong sporadically on lanes 48-63 (profiles/r03d, r03e: run-to-run different, always pass 1 / tile 0 /
+// elements 0 and 2).  The host simulator of tests/ defines it as fmaf.
+#ifndef MV_FMA_SCALAR
+__device__ __forceinline__ float mv_fma_scalar(float a, float b, float c) {
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+#define MV_FMA_SCALAR(a, b, c) mv_fma_scalar((a), (b), (c))
+#endif
+
 // host-side error plumbing ---------------------------------------------------------------------------
 void mv_set_error(const char* fmt, ...);
 

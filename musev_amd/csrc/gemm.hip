@@ -77,14 +77,60 @@ __device__ __forceinline__ void mma_tile(const half_t* cA, const half_t* cB, flo
     }
 }
 
-// the same with row statistics of the A tile: on the 32-deep steps it owns (the WGN waves that share a row block deal the steps
-// round-robin), the wave adds its fragments' sum and sum of squares -- 8 v_dot2_f32_f16 per fragment, fp32 accumulation -- into
-// per-lane partials (lane (l15, g) holds k = 8 g .. 8 g + 7 of row 16 i + l15)
+// the same with row statistics of the A tile: the wave adds its fragments' sum and sum of squares -- 8 v_dot2_f32_f16 per
+// fragment, fp32 accumulation -- into per-lane partials (lane (l15, g) holds k = 8 g .. 8 g + 7 of row 16 i + l15).
+// MV_LN_VARIANT (experiment builds; the default is what measured fastest, profiles/r03c):
+//   0  the WGN waves that share a row block deal the 32-deep steps round-robin; statistics ahead of the step's MFMAs
+//   1  the same deal, statistics behind the step's MFMAs (an in-order wave issues its MFMAs first, the dot products run in their shadow)
+//   2  every wave keeps the statistics of all of its fragments (no deal, no LDS exchange), issued behind the MFMAs and interleaved
+//      with them by the scheduler (two dot products per MFMA)
+#ifndef MV_LN_VARIANT
+#define MV_LN_VARIANT 0
+#endif
+template <int TM>
+__device__ __forceinline__ void ln_stats_step(const half8v (&af)[TM], float (&s1)[TM], float (&s2)[TM]) {
+#ifdef MV_LN_DOT2
+    const half2v ones = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float a0 = s1[i], b0 = s2[i], a1 = 0.f, b1 = 0.f;  // two chains per statistic: half the dependent latency
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const half2v h0 = {af[i][2 * e], af[i][2 * e + 1]};
+            const half2v h1 = {af[i][2 * e + 2], af[i][2 * e + 3]};
+            a0 = __builtin_amdgcn_fdot2(h0, ones, a0, false);
+            a1 = __builtin_amdgcn_fdot2(h1, ones, a1, false);
+            b0 = __builtin_amdgcn_fdot2(h0, h0, b0, false);
+            b1 = __builtin_amdgcn_fdot2(h1, h1, b1, false);
+        }
+        s1[i] = a0 + a1;
+        s2[i] = b0 + b1;
+    }
+#else
+    // mixed-precision FMAs (v_fma_mix_f32: fp16 operands, fp32 accumulate), two chains per statistic.  NOT v_dot2c_f32_f16: next to
+    // MFMAs it produced sporadically corrupted accumulators on the MI355X (profiles/r03d: single elements of single 16 x 16 tiles,
+    // run-to-run different) -- the in-place dot product overwrote registers an in-flight MFMA was still reading as its C operand.
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float a0 = s1[i], b0 = s2[i], a1 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float x0 = (float)af[i][e], x1 = (float)af[i][e + 1];
+            a0 += x0;
+            a1 += x1;
+            b0 = fmaf(x0, x0, b0);
+            b1 = fmaf(x1, x1, b1);
+        }
+        s1[i] = a0 + a1;
+        s2[i] = b0 + b1;
+    }
+#endif
+}
+
 template <int TM, int TN, int WGN>
 __device__ __forceinline__ void mma_tile_ln(const half_t* cA, const half_t* cB, float4v (&acc)[TM][TN], int a_row0, int b_row0, int swz,
                                             int g, float (&s1)[TM], float (&s2)[TM], int kstep0, int wn) {
     constexpr int BK = 64;
-    const half2v ones = {(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int slot_off = (((kk * 4 + g) ^ swz) << 3);
@@ -95,22 +141,25 @@ __device__ __forceinline__ void mma_tile_ln(const half_t* cA, const half_t* cB, 
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             wf[j] = *reinterpret_cast<const half8v*>(cB + (b_row0 + 16 * j) * BK + slot_off);
-        if (((kstep0 + kk) & (WGN - 1)) == wn) {  // wave-uniform
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const half2v h = {af[i][2 * e], af[i][2 * e + 1]};
-                    s1[i] = __builtin_amdgcn_fdot2(h, ones, s1[i], false);
-                    s2[i] = __builtin_amdgcn_fdot2(h, h, s2[i], false);
-                }
-            }
-        }
+#if MV_LN_VARIANT == 0
+        if (((kstep0 + kk) & (WGN - 1)) == wn) ln_stats_step<TM>(af, s1, s2);  // wave-uniform
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+#if MV_LN_VARIANT == 1
+        if (((kstep0 + kk) & (WGN - 1)) == wn) ln_stats_step<TM>(af, s1, s2);  // wave-uniform
+#elif MV_LN_VARIANT == 2
+        ln_stats_step<TM>(af, s1, s2);
+        // issue order of this step: one MFMA, then two of the 10 TM VALU instructions of the statistics, ...
+#pragma unroll
+        for (int m = 0; m < TM * TN; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
+        }
+#endif
     }
 }
 
@@ -248,8 +297,16 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
         }
     }
     auto ln_affine = [&](int i, int j) __attribute__((always_inline)) -> float4v {
-        if constexpr (LN) return acc[i][j] * ln_r[i] - lcs[j] * ln_mr[i] + lcb[j];
-        else return acc[i][j];
+        if constexpr (LN) {
+            // rstd * acc - (rstd * mean) * colsum + colbias, element by element (MV_FMA_SCALAR: see common.h)
+            const float r = ln_r[i], nmr = -ln_mr[i];
+            float4v v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = MV_FMA_SCALAR(acc[i][j][e], r, MV_FMA_SCALAR(lcs[j][e], nmr, lcb[j][e]));
+            return v;
+        } else {
+            return acc[i][j];
+        }
     };
     half8v res[2][KI];
     auto request = [&](int i, half8v* rs) {  // residual chunks of pass i, in the read layout
@@ -647,10 +704,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
                 float a = ln_s1[i], b = ln_s2[i];
                 a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);  // the 4 lane groups hold k = 8 g .. 8 g + 7 of the row
                 b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                ln_s1[i] = a;
+                ln_s2[i] = b;
+#if MV_LN_VARIANT != 2
                 if (g == 0) {
                     sst[(wave * 16 * TM + 16 * i + l15) * 2] = a;
                     sst[(wave * 16 * TM + 16 * i + l15) * 2 + 1] = b;
                 }
+#endif
             }
         }
         __syncthreads();  // every wave is done reading the operand tiles: their LDS is reused as the staging buffers
@@ -660,15 +721,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float a = 0.f, b = 0.f;
+#if MV_LN_VARIANT == 2
+                a = ln_s1[i];
+                b = ln_s2[i];
+#else
 #pragma unroll
                 for (int w2 = 0; w2 < WGN; ++w2) {  // fixed order: bit-reproducible
                     a += sst[((wm * WGN + w2) * 16 * TM + 16 * i + l15) * 2];
                     b += sst[((wm * WGN + w2) * 16 * TM + 16 * i + l15) * 2 + 1];
                 }
+#endif
                 const float mean = a * inv_k;
                 const float var = fmaxf(b * inv_k - mean * mean, 0.f);
                 ln_r[i] = rsqrtf(var + p.ln_eps);
                 ln_mr[i] = ln_r[i] * mean;
+
             }
         }
         half_t* stg = reinterpret_cast<half_t*>(smem);  // (the launcher sizes the dynamic LDS as max(operand stages, staging area))
@@ -839,8 +906,9 @@ int launch_ln_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
     return MV_ERR_INVALID;
 }
 
-// per-shape choices measured on the MI355X (exact match on mode / M / N / K / geglu; anything else follows the rules below)
-struct GemmTuned { int mode; long M; int N, K, geglu, cfg, nsplit; };
+// per-shape choices measured on the MI355X (mode / N / K / geglu exact, nearest M within a factor of 3; anything else follows the
+// rules below)
+struct GemmTuned { int mode; long M; int N, K, geglu, ln, cfg, nsplit; };
 #include "gemm_tuned.h"
 
 struct GemmChoice { int cfg, nsplit; };
@@ -867,13 +935,30 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
     GemmChoice ch{-1, 0};
     if (want_cfg >= 0 && gemm_cfg_applies(want_cfg, g)) ch.cfg = want_cfg;
     if (ch.cfg < 0 && want_cfg == -1) {
+        // measured table: the entry of this (mode, N, K, geglu) whose M is NEAREST on a log scale, within a factor of 3 -- the
+        // table is measured on the 512 x 512 benchmark (M = 26 or 13 frames x 4096 / 1024 / 256 / 64 rows), and other resolutions
+        // (768 x 768: x 2.25, 512 x 320: x 0.625) inherit the choice of the same layer at the nearest size instead of falling back
+        // to the rules.  An entry measured on the LayerNorm-folded form of the launch wins over a plain one at the same distance;
+        // the split factor is only inherited at (nearly) the measured M, elsewhere the split rule decides.
+        int best = -1;
+        double best_d = 1e30;
+        const bool want_ln = g.ln_colsum != nullptr;
         for (int i = 0; i < kNumGemmTuned; ++i) {
             const GemmTuned& e = kGemmTuned[i];
-            if (e.mode == mode && e.M == g.M && e.N == g.N && e.K == g.K && e.geglu == g.geglu && gemm_cfg_applies(e.cfg, g)) {
-                ch.cfg = e.cfg;
-                ch.nsplit = e.nsplit;
-                break;
+            if (e.mode != mode || e.N != g.N || e.K != g.K || e.geglu != g.geglu || e.M <= 0 || !(e.cfg == -2 || gemm_cfg_applies(e.cfg, g))) continue;
+            if (e.ln && !want_ln) continue;
+            const double r = (double)g.M / (double)e.M;
+            double dist = r > 1.0 ? r : 1.0 / r;  // >= 1: the size ratio
+            if (dist > 3.0) continue;
+            if ((e.ln != 0) != want_ln) dist *= 1.0001;  // tie-break only
+            if (dist < best_d) {
+                best_d = dist;
+                best = i;
             }
+        }
+        if (best >= 0 && kGemmTuned[best].cfg >= 0) {  // (cfg -2: the rules below measured best for this problem)
+            ch.cfg = kGemmTuned[best].cfg;
+            ch.nsplit = best_d <= 1.26 ? kGemmTuned[best].nsplit : 0;
         }
     }
     const int cus = mv_num_cus();

@@ -192,7 +192,9 @@ def ln_fold_applies(M: int, N: int, K: int, geglu: bool) -> bool:
     """whether ``gemm(..., ln=)`` is the better form of LayerNorm + projection for this problem: it is wherever the plain
     projection runs as ONE K slice (the folded kernel needs the whole row in one block's K loop); the small-M / long-K problems
     the library splits over K keep mv_layernorm_f16 + the split GEMM."""
-    if not LN_FOLD or K % 64 != 0:
+    if not LN_FOLD or K % 64 != 0 or geglu:
+        # (GEGLU: the gate's epilogue already bounds that launch -- folded it measured 4-11 % SLOWER than LayerNorm + GEMM at every
+        # level, profiles/r03e_ln_fold_variants.log; the q / k / v projections gain 5-44 %)
         return False
     key = (M, N, K, bool(geglu))
     hit = _ln_fold_cache.get(key)

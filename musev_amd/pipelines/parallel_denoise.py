@@ -375,7 +375,7 @@ class ParallelDenoiser:
 
 
 _PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb", "down_block_additional_residuals",
-                    "mid_block_additional_residual")
+                    "mid_block_additional_residual", "pose_guider_emb")
 
 
 def _ident(v) -> tuple:

@@ -79,10 +79,12 @@ static inline void sim_wave_barrier() { pthread_barrier_wait(&sim_wave_bar[threa
 #define __builtin_amdgcn_wave_barrier sim_wave_barrier
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define MV_KEEP_ONE_REGISTER(x) ((void)0)
+#define MV_FMA_SCALAR(a, b, c) fmaf((a), (b), (c))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 template <class T> static inline T sim_atomic_fetch_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __hip_atomic_fetch_add(p, v, order, scope) sim_atomic_fetch_add((p), (v))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 

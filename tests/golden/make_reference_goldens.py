@@ -23,6 +23,7 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
                                 configs 2 and 3: full SD-1.5 widths, B 2, T 13, 64x64 latents
   * reference_unet_refnet_pose_cfg5.npz  (``--at-size-cfg5``) the `musev_referencenet_pose` forward at config 5's size (96x96 latents) with
                                 ControlNet residuals + PoseGuider embedding
+  * reference_pipeline_signature.json  keyword list of MusevControlNetPipeline.__call__ (pipeline_controlnet.py:1295-1420), read with ast
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
 from __future__ import annotations
@@ -262,7 +263,34 @@ def gen_poseguider():
         print("poseguider", name, tuple(out.shape), "absmax", float(out.abs().max()), "fresh zero:", bool((fresh == 0).all()))
 
 
+def gen_pipeline_signature():
+    """the keyword list (names, order, literal defaults) of MusevControlNetPipeline.__call__ and of the predictor's shot loop call
+    site, read from the reference's SOURCE with ast (the module itself imports the un-vendored diffusers pipeline base)"""
+    import ast
+    src = open("/root/reference/musev/pipelines/pipeline_controlnet.py").read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "MusevControlNetPipeline")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+    args = fn.args.args[1:]  # without self
+    defaults = [None] * (len(args) - len(fn.args.defaults)) + list(fn.args.defaults)
+    out = []
+    for a, d in zip(args, defaults):
+        if d is None:
+            out.append({"name": a.arg, "required": True})
+        else:
+            try:
+                out.append({"name": a.arg, "default": ast.literal_eval(d)})
+            except ValueError:
+                out.append({"name": a.arg, "default_src": ast.unparse(d)})
+    with open(os.path.join(HERE, "reference_pipeline_signature.json"), "w") as f:
+        json.dump({"source": "musev/pipelines/pipeline_controlnet.py MusevControlNetPipeline.__call__", "lineno": fn.lineno, "args": out}, f, indent=0)
+    print("pipeline signature:", len(out), "keywords, def at line", fn.lineno)
+
+
 if __name__ == "__main__":
+    if "--signature" in sys.argv:
+        gen_pipeline_signature()
+        sys.exit(0)
     if "--at-size" in sys.argv:  # the BASELINE-size UNet cases only (minutes of CPU, ~25 GB)
         gen_unet(UNET_CASES_AT_SIZE)
         sys.exit(0)
@@ -270,6 +298,7 @@ if __name__ == "__main__":
         torch.set_num_threads(os.cpu_count() or 1)
         gen_unet(UNET_CASES_AT_SIZE_CFG5)
         sys.exit(0)
+    gen_pipeline_signature()
     gen_poseguider()
     gen_loop_utils()
     gen_context()

@@ -353,3 +353,63 @@ def test_denoise_loop_with_controlnet(guess_mode, emulated):
     got = den(latents, prompt, controlnet=net, **kw)
     err = (got.float() - want).abs().max().item()
     assert err < TOL, f"|delta latent|max = {err}"
+
+
+# ---- 7. MusevControlNetPipeline: the reference's __call__ surface over the HIP loop ----------------------------------------------
+def test_pipeline_call_keeps_the_reference_keyword_list():
+    """every keyword of the reference's MusevControlNetPipeline.__call__ (pipeline_controlnet.py:1295-1420; names, order and
+    literal defaults recorded from its source by make_reference_goldens.py --signature) exists here with the same default, so a
+    caller written against the reference (the predictor, pipeline_controlnet_predictor.py:643-745) needs no edit"""
+    import inspect
+    import json
+    from musev_amd.pipelines.pipeline_controlnet import MusevControlNetPipeline
+    ref = json.load(open(os.path.join(GOLDEN, "reference_pipeline_signature.json")))["args"]
+    sig = inspect.signature(MusevControlNetPipeline.__call__)
+    params = [p for n, p in sig.parameters.items() if n != "self"]
+    names = [p.name for p in params]
+    assert names[:len(ref)] == [a["name"] for a in ref], "keyword order must match the reference (positional callers)"
+    for a, p in zip(ref, params):
+        if a.get("required"):
+            assert p.default is inspect.Parameter.empty, a
+        else:
+            assert p.default == a["default"], (a, p.default)
+
+
+def test_pipeline_call_runs_the_loop_like_the_oracle(emulated):
+    """prompt_embeds / negative_prompt_embeds, explicit latents and condition latents, DDIM, 2 steps, two windows: the adapter's
+    output latents equal the oracle loop's; strings without a text encoder and unsupported branches raise"""
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    from musev_amd.pipelines.pipeline_controlnet import MusevControlNetPipeline
+    arch = UNET_CASES["musev_narrow"]["arch"]
+    _widths(emulated, arch)
+    cfg = unet3d.flavour_config("musev", **arch)
+    sd = unet3d.init_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(0)
+    T, win, ov, h, w = 8, 6, 2, 8, 8
+    latents = torch.randn(1, 4, T, h, w, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    want = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt, num_inference_steps=2,
+                              guidance_scale=3.5, condition_latents=cond, motion_speed=8.0, context_frames=win, context_overlap=ov)
+    unet = _cpu(load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **arch))
+    emulated.setattr(ParallelDenoiser, "_device_check", False)
+    pipe = MusevControlNetPipeline(unet=unet)
+    out = pipe(video_length=T, prompt_embeds=prompt[1:], negative_prompt_embeds=prompt[:1], latents=latents, condition_latents=cond,
+               num_inference_steps=2, guidance_scale=3.5, context_frames=win, context_overlap=ov, output_type="latent")
+    assert out.videos is None and out.latents.shape == want.shape
+    # two 500-timestep DDIM jumps of a random network blow the latents up: the bound scales with their magnitude (as in
+    # test_denoise_loop_over_the_module)
+    scale = max(1.0, float(want.abs().max()) / 4.0)
+    err = (out.latents.float() - want).abs().max().item()
+    assert err < TOL * scale, (err, scale)
+    # the same through the tuple return and [negative | positive] embeddings in one tensor
+    tup = pipe(T, prompt_embeds=prompt, latents=latents, condition_latents=cond, num_inference_steps=2, guidance_scale=3.5,
+               context_frames=win, context_overlap=ov, output_type="latent", return_dict=False)
+    assert torch.equal(tup[1], out.latents)
+    with pytest.raises(ValueError):
+        pipe(T, prompt="a cat", latents=latents, num_inference_steps=2)          # strings need a text encoder callable
+    with pytest.raises(NotImplementedError):
+        pipe(T, prompt_embeds=prompt, latents=latents, image=torch.zeros(1, 3, T, 64, 64), num_inference_steps=2)   # img2img branch

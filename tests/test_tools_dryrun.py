@@ -111,12 +111,15 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
     assert (ops.GEMM_CFG, ops.GEMM_SPLITK) == (-1, 0) and ops.GEMM_RECORD is None, "the tuner must leave the process on `table + rules`"
 
     hdr = open(tmp_path / "gpurun_out" / "dry_gemm_tuned.h").read()
-    entries = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", hdr)]
+    # {mode, M, N, K, geglu, ln, cfg, nsplit}; every problem has an entry, cfg -2 = "the rules measured best"
+    entries = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (-?\d+), (\d+)\},", hdr)]
+    entries = [e for e in entries if e[0] >= 0]
     n_decl = int(re.search(r"kNumGemmTuned = (\d+);", hdr).group(1))
     assert n_decl == len(entries) > 0
-    assert all((c, sp) == (1, 4) for mode, M, N, K, g, c, sp in entries if mode == 1) and any(mode == 1 for mode, *_ in entries)
-    assert all((c, sp) == (13, 1) for mode, M, N, K, g, c, sp in entries if mode == 0) and all(K <= 320 for mode, M, N, K, g, c, sp in entries if mode == 0)
-    assert not any(mode == 2 for mode, *_ in entries), "a 1 % gain is below the threshold"
+    assert all((c, sp) == (1, 4) for mode, M, N, K, g, ln, c, sp in entries if mode == 1) and any(mode == 1 for mode, *_ in entries)
+    lin = [(K, c, sp) for mode, M, N, K, g, ln, c, sp in entries if mode == 0]
+    assert all((c, sp) == ((13, 1) if K <= 320 else (-2, 0)) for K, c, sp in lin) and any(K <= 320 for K, _, _ in lin) and any(K > 320 for K, _, _ in lin)
+    assert all(c == -2 for mode, M, N, K, g, ln, c, sp in entries if mode == 2) and any(mode == 2 for mode, *_ in entries), "a 1 % gain is below the threshold"
     import json
     rep = json.load(open(tmp_path / "gpurun_out" / "dry_gemm_tune.json"))
     assert rep["tuned_ms_per_forward"] < rep["rules_ms_per_forward"] and len(rep["problems"]) > 10

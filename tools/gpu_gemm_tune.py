@@ -94,7 +94,7 @@ def main():
     rec, ops.GEMM_RECORD = ops.GEMM_RECORD, None
     table = {}   # key -> {"n": launches per forward pair, "desc": first descriptor, "keep": tensors, "ms": {(cfg, splitk): ms per launch}}
     for d, keep, _nb in rec:
-        key = (int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu))
+        key = (int(d.mode), int(d.M), int(d.N), int(d.K), int(d.geglu), int(bool(d.ln_colsum)))
         ent = table.setdefault(key, {"n": 0, "desc": d, "keep": keep, "ms": {}})
         ent["n"] += 1
     ws_cache = {}
@@ -136,14 +136,15 @@ def main():
         pick = best if ent["ms"][best] < (1.0 - args.min_gain) * base else None
         rules_total += base * ent["n"]
         tuned_total += (ent["ms"][pick] if pick is not None else base) * ent["n"]
-        mode, M, N, K, geglu = key
+        mode, M, N, K, geglu, ln = key
         flops = 2.0 * M * N * K
-        report.append({"mode": names[mode], "M": M, "N": N, "K": K, "geglu": geglu, "launches": ent["n"], "rules_ms": base,
+        report.append({"mode": names[mode], "M": M, "N": N, "K": K, "geglu": geglu, "ln": ln, "launches": ent["n"], "rules_ms": base,
                        "rules_tflops": flops / base / 1e9, "best_cfg": best[0], "best_splitk": best[1], "best_ms": ent["ms"][best],
                        "best_tflops": flops / ent["ms"][best] / 1e9, "picked": list(pick) if pick else None,
                        "ms": {f"{c}/{s}": v for (c, s), v in ent["ms"].items()}})
-        if pick is not None:
-            entries.append((mode, M, N, K, geglu, pick[0], pick[1], base, ent["ms"][pick]))
+        # every problem gets an entry (the lookup inherits choices across sizes by nearest M, so "the rules measured best" must be
+        # recorded too: cfg -2)
+        entries.append((mode, M, N, K, geglu, ln) + ((pick[0], pick[1], base, ent["ms"][pick]) if pick is not None else (-2, 0, base, base)))
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"{args.tag}_gemm_tune.json"), "w") as f:
@@ -153,14 +154,15 @@ def main():
              "// GENERATED by tools/gpu_gemm_tune.py (do not edit by hand); ids refer to MV_GEMM_CFGS in gemm.hip.",
              f"// {torch.cuda.get_device_name(0)}; {args.flavour}, {args.size}x{args.size}, T = 13, one batch-1 + one batch-2 forward; rules "
              f"{rules_total:.2f} ms -> table {tuned_total:.2f} ms of GEMM time.",
-             "// {mode, M, N, K, geglu, cfg, nsplit}   nsplit: K slices (clamped by the workspace cap); 0 = split-K rule",
+             "// {mode, M, N, K, geglu, ln, cfg, nsplit}   ln: LayerNorm-folded launch; nsplit: K slices (clamped by the workspace cap); 0 = split-K rule; "
+             "cfg -2: the rules' own choice measured best",
              "static const GemmTuned kGemmTuned[] = {"]
-    for mode, M, N, K, geglu, pick, split, base, best in entries:
-        lines.append(f"    {{{mode}, {M}, {N}, {K}, {geglu}, {pick}, {split}}},  // {names[mode]}: {base * 1e3:.0f} -> {best * 1e3:.0f} us")
-    lines += ["    {-1, 0, 0, 0, 0, -1, 0},  // sentinel (never matches)", "};", f"static const int kNumGemmTuned = {len(entries)};", ""]
+    for mode, M, N, K, geglu, ln, pick, split, base, best in entries:
+        lines.append(f"    {{{mode}, {M}, {N}, {K}, {geglu}, {ln}, {pick}, {split}}},  // {names[mode]}{' +LN' if ln else ''}: {base * 1e3:.0f} -> {best * 1e3:.0f} us")
+    lines += ["    {-1, 0, 0, 0, 0, 0, -1, 0},  // sentinel (never matches)", "};", f"static const int kNumGemmTuned = {len(entries)};", ""]
     with open(os.path.join(out_dir, f"{args.tag}_gemm_tuned.h"), "w") as f:
         f.write("\n".join(lines))
-    print(f"rules {rules_total:.2f} ms -> tuned {tuned_total:.2f} ms per forward over {len(table)} problems, {len(entries)} table entries")
+    print(f"rules {rules_total:.2f} ms -> tuned {tuned_total:.2f} ms per forward over {len(table)} problems, {sum(1 for e in entries if e[6] >= 0)} non-rule entries")
     for r in report[:24]:
         print(f"{r['mode']:8s} M{r['M']:<7d} N{r['N']:<6d} K{r['K']:<6d} g{r['geglu']} x{r['launches']:<3d} rules {r['rules_ms'] * 1e3:6.0f} us "
               f"{r['rules_tflops']:5.0f} TF | best cfg {r['best_cfg']:2d}/{r['best_splitk']} {r['best_ms'] * 1e3:6.0f} us {r['best_tflops']:5.0f} TF")
