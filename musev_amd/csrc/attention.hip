@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
 //        * the 96-byte row stride makes both the ds_read_b128 K fragments and the ds_read_b64_tr_b16 V reads conflict-free under
 //          the hardware's lane groups (80-byte rows: 2-way on both).
 //   4  (d = 40) register budget of four waves per SIMD (128 VGPRs) instead of three
+//   8  eight waves = 256 query rows per block share every K / V tile (half the L2 -> LDS traffic and half the barriers per MFMA)
 template <int D, int VAR>
 struct Attn3Cfg {
     static constexpr bool TAIL16 = (VAR & 1) != 0 && (D % 32) != 0 && (D % 32) <= 16;
@@ -457,16 +458,19 @@ struct Attn3Cfg {
     static constexpr int NC32 = TAIL16 ? NC - 1 : NC;  // ... of which whole 32-deep MFMA steps
     static constexpr int NDT = (D + 15) / 16;          // O^T d-tiles
     static constexpr bool ONES = PADR && NDT * 16 > D; // the row sums ride in output row D of the P.V product
-    static constexpr int KV = 64, QT = 2, QB = 128, NST = 3;
+    static constexpr int NW = (VAR & 8) ? 8 : 4;       // waves per block (each owns 32 query rows)
+    static constexpr int KV = 64, QT = 2, QB = 32 * NW, NST = 3;
     static constexpr int TILE = KV * DR;               // halfs per K (or V) tile = RCH pieces of 1 KiB
-    static constexpr int PIECES = 2 * RCH;             // LDS-DMA pieces per (K, V) tile pair, dealt round-robin to the 4 waves
-    static constexpr int PPW = (PIECES + 3) / 4;       // ... at most per wave
+    static constexpr int PIECES = 2 * RCH;             // LDS-DMA pieces per (K, V) tile pair, dealt round-robin to the waves
+    static constexpr int PPW = (PIECES + NW - 1) / NW; // ... at most per wave
     static constexpr int LDS_HALFS = NST * 2 * TILE + 64;  // slack: a 32-deep fragment read of the last row runs past it
 };
 
 template <int D, int VAR>
-__global__ __launch_bounds__(256, D == 40 ? ((VAR & 4) ? 4 : 3) : 2) void attn3_kernel(const AttnArgs p) {
+__global__ __launch_bounds__((64 * Attn3Cfg<D, VAR>::NW), (D == 40 ? ((VAR & 4) ? 4 : 3) : 2))  // (threads, waves per SIMD)
+void attn3_kernel(const AttnArgs p) {
     using C = Attn3Cfg<D, VAR>;
+    constexpr int NT = 64 * C::NW;
     static_assert(D % 8 == 0 && (64 * C::RCH) % 64 == 0, "a tile must be a whole number of 1-KiB pieces");
     constexpr float kThr = 6.0f;  // scores may exceed the reference by 2^6: P <= 64 in fp16, sums in fp32
     constexpr int DR = C::DR;
@@ -485,13 +489,13 @@ __global__ __launch_bounds__(256, D == 40 ? ((VAR & 4) ? 4 : 3) : 2) void attn3_
     const int h = hn % p.heads;
     const int n = hn / p.heads;
     const int q0 = (id - hn * qblocks) * C::QB + wave * (16 * C::QT);
-    const int npw = (C::PIECES - wave + 3) / 4;  // pieces this wave issues per tile pair (wave-uniform)
+    const int npw = (C::PIECES - wave + C::NW - 1) / C::NW;  // pieces this wave issues per tile pair (wave-uniform)
 
-    for (int i = tid; i < C::LDS_HALFS / 8; i += 256) reinterpret_cast<uint4*>(lds)[i] = uint4{0, 0, 0, 0};
+    for (int i = tid; i < C::LDS_HALFS / 8; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0, 0, 0, 0};
     if constexpr (C::ONES) {
         __syncthreads();
         // the sixth slot of every V row: {1, 0, 0, 0, 0, 0, 0, 0} -- written once, the LDS-DMA never touches it
-        for (int i = tid; i < C::NST * C::KV; i += 256)
+        for (int i = tid; i < C::NST * C::KV; i += NT)
             lds[(i / C::KV) * (2 * C::TILE) + C::TILE + (i % C::KV) * DR + D] = (half_t)1.0f;
     }
     typedef __attribute__((address_space(3))) half_t lds_half_t;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(256, D == 40 ? ((VAR & 4) ? 4 : 3) : 2) void attn3_
         bool pon[C::PPW];        // PADR: the lane owns a data slot (the pad slot's lanes never issue)
 #pragma unroll
         for (int j = 0; j < C::PPW; ++j) {
-            const int q = wave + 4 * j;
+            const int q = wave + C::NW * j;
             const int ci = (q % C::RCH) * 64 + lane;
             prow[j] = ci / C::RCH;
             const int slot = ci - prow[j] * C::RCH;
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(256, D == 40 ? ((VAR & 4) ? 4 : 3) : 2) void attn3_
             const bool partial = len - row0 < C::KV;  // wave-uniform: rows past the end read as zero
 #pragma unroll
             for (int j = 0; j < C::PPW; ++j) {
-                const int q = wave + 4 * j;
+                const int q = wave + C::NW * j;
                 if (q >= C::PIECES) break;  // wave-uniform
                 const bool isv = q >= C::RCH;
                 unsigned vo = voff[j];
@@ -601,7 +605,8 @@ __global__ __launch_bounds__(256, D == 40 ? ((VAR & 4) ? 4 : 3) : 2) void attn3_
         const int stage = t % C::NST;
         // this wave's pieces of tile t have landed when at most its pieces of tile t+1 are still in flight
         if (t + 1 < total) {
-            if (npw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (npw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (npw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (npw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         } else {
@@ -999,7 +1004,9 @@ int launch_attn3(const AttnArgs& a, dim3 grid1, hipStream_t s) {
         MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn3_kernel<D, VAR>), grid1, dim3(256), smem, s, a);
+    constexpr int QB = Attn3Cfg<D, VAR>::QB;
+    const dim3 grid((unsigned)(((a.lq + QB - 1) / QB) * a.heads * a.nb));  // 1-D: the kernel maps ids to (q block, head, frame)
+    hipLaunchKernelGGL((attn3_kernel<D, VAR>), grid, dim3(64 * Attn3Cfg<D, VAR>::NW), smem, s, a);
     return MV_OK;
 }
 
@@ -1045,12 +1052,17 @@ int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) 
             else if (var40 == 2) rc = launch_attn3<40, 2>(a, grid1, s);
             else if (var40 == 6) rc = launch_attn3<40, 6>(a, grid1, s);
             else if (var40 == 7) rc = launch_attn3<40, 7>(a, grid1, s);
+            else if (var40 == 15) rc = launch_attn3<40, 15>(a, grid1, s);
+            else if (var40 == 14) rc = launch_attn3<40, 14>(a, grid1, s);
+            else if (var40 == 11) rc = launch_attn3<40, 11>(a, grid1, s);
             else
 #endif
             rc = launch_attn3<40, kAttnVar40>(a, grid1, s);
         } else {
 #ifdef MV_EXPERIMENT
             if (var80 == 0) rc = launch_attn3<80, 0>(a, grid1, s);
+            else if (var80 == 1) rc = launch_attn3<80, 1>(a, grid1, s);
+            else if (var80 == 8) rc = launch_attn3<80, 8>(a, grid1, s);
             else
 #endif
             rc = launch_attn3<80, kAttnVar80>(a, grid1, s);

@@ -36,6 +36,7 @@ class BasicTransformerBlock(HipModule):
                                  attention_head_dim, bias=attention_bias, cross_attn_temporal_cond=ip_adapter_cross_attn,
                                  ip_adapter_dim=cross_attention_dim if not double_self_attention else attention_head_dim,
                                  need_t2i_facein=need_t2i_facein, need_t2i_ip_adapter_face=need_t2i_ip_adapter_face,
+                                 ip_adapter_face_dim=cross_attention_dim if not double_self_attention else attention_head_dim,
                                  processor=processor)
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
@@ -53,6 +54,16 @@ class BasicTransformerBlock(HipModule):
             # projections are the rows already computed for that frame
             for ci in ctx.vis_idx:
                 segs.append((k, v, geo.hw, geo.t, geo.t, int(ci)))
+        if reference_only and ctx.refer_self is not None:
+            # attention_processor.py:476-491: the tokens of refer_self_attn_emb[block] ("b c t h w -> b 1 (t h w) c", repeated over
+            # the frames) join the keys / values; they are constant over the denoise loop -> projected once per source tensor
+            ref = ctx.refer_self[self.spatial_self_attn_idx]
+            if ref.shape[0] != geo.b or ref.shape[1] != c:
+                raise ValueError(f"refer_self_attn_emb[{self.spatial_self_attn_idx}] must be [b = {geo.b}, c = {c}, t, h, w]")
+            n_ref = ref.shape[2] * ref.shape[3] * ref.shape[4]
+            rkv = a1._cache().setdefault("refer_self_kv", SourceCache()).get(
+                ref, lambda src: ops.gemm(ops.bcthw_to_bthwc(src), a1.w_kv()))
+            segs.append((rkv[:, :c], rkv[:, c:], n_ref, geo.t, 1, 0))
         att = ops.attention(qkv[:, :c], segs, geo.n, geo.hw, h, d, a1.scale)
         x = a1.project_out(att, residual=x)
 
@@ -66,6 +77,11 @@ class BasicTransformerBlock(HipModule):
             ikv = cache.setdefault("clip_kv", SourceCache()).get(ctx.clip_src, lambda _s: ops.gemm(ctx.clip, a2.w_kv_ip()))
             ops.attention(q, [(ikv[:, :c], ikv[:, c:], ctx.clip_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale,
                           out=att, accumulate=True, out_scale=ctx.ip_scale)
+        if a2.need_t2i_ip_adapter_face and ctx.face is not None and ctx.face_scale > 0:
+            # IP-Adapter-FaceID (attention_processor.py:308-338): a third attention of the same queries over the face tokens
+            fkv = cache.setdefault("face_kv", SourceCache()).get(ctx.face_src, lambda _s: ops.gemm(ctx.face, a2.w_kv_face()))
+            ops.attention(q, [(fkv[:, :c], fkv[:, c:], ctx.face_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale,
+                          out=att, accumulate=True, out_scale=ctx.face_scale)
         x = a2.project_out(att, residual=x)
         return self.ff.hip_forward(x, residual=x, norm=self.norm3)
 

@@ -190,12 +190,11 @@ class IPAttention(HipModule):
 
     def __init__(self, query_dim: int, cross_attention_dim: Optional[int] = None, heads: int = 8, dim_head: int = 64,
                  bias: bool = False, cross_attn_temporal_cond: bool = False, ip_adapter_dim: Optional[int] = None,
-                 need_t2i_facein: bool = False, need_t2i_ip_adapter_face: bool = False, processor=None):
+                 need_t2i_facein: bool = False, need_t2i_ip_adapter_face: bool = False, ip_adapter_face_dim: Optional[int] = None,
+                 processor=None):
         super().__init__()
         if need_t2i_facein:
             raise NotImplementedError("facein")  # attention_processor.py:123-124
-        if need_t2i_ip_adapter_face:
-            raise NotImplementedError("ip_adapter_face is outside the hot-path scope (SURVEY.md 8)")
         inner = heads * dim_head
         kv = cross_attention_dim if cross_attention_dim is not None else query_dim
         self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
@@ -207,6 +206,11 @@ class IPAttention(HipModule):
         if cross_attn_temporal_cond:
             self.to_k_ip = nn.Linear(ip_adapter_dim, query_dim, bias=False)
             self.to_v_ip = nn.Linear(ip_adapter_dim, query_dim, bias=False)
+        # IP-Adapter-FaceID: a second pair of image-prompt projections (attention_processor.py:127-135)
+        self.need_t2i_ip_adapter_face = need_t2i_ip_adapter_face
+        if need_t2i_ip_adapter_face:
+            self.ip_adapter_face_to_k_ip = nn.Linear(ip_adapter_face_dim, query_dim, bias=False)
+            self.ip_adapter_face_to_v_ip = nn.Linear(ip_adapter_face_dim, query_dim, bias=False)
         self.processor = processor
 
     def set_use_memory_efficient_attention_xformers(self, *args, **kwargs):  # pipeline compatibility no-op
@@ -224,6 +228,9 @@ class IPAttention(HipModule):
 
     def w_kv_ip(self) -> torch.Tensor:
         return self.packed("kv_ip", lambda: torch.cat([lin_w(self.to_k_ip), lin_w(self.to_v_ip)], 0).contiguous())
+
+    def w_kv_face(self) -> torch.Tensor:
+        return self.packed("kv_face", lambda: torch.cat([lin_w(self.ip_adapter_face_to_k_ip), lin_w(self.ip_adapter_face_to_v_ip)], 0).contiguous())
 
     def project_out(self, a: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         return ops.gemm(a, lin_w(self.to_out[0]), bias=lin_b(self.to_out[0]), residual=residual)

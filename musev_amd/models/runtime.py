@@ -52,6 +52,11 @@ class Ctx:
     skip_temporal: bool
     text_src: Optional[torch.Tensor] = None  # the caller's tensors the rows were made from (cache identity)
     clip_src: Optional[torch.Tensor] = None
+    face: Optional[torch.Tensor] = None      # [B*L_face, cross_dim] fp16 rows of ip_adapter_face_emb (IP-Adapter-FaceID)
+    face_len: int = 0
+    face_scale: float = 0.0
+    face_src: Optional[torch.Tensor] = None
+    refer_self: Optional[List[torch.Tensor]] = None  # refer_self_attn_emb ("read"): per spatial block [b, c, t, h, w]
     # every ResnetBlock2D.time_emb_proj / TransformerTemporalModel.frame_emb_proj of the network applied in ONE GEMM at
     # the top of the forward ([frames, sum of C_out]); a block takes its column slice.  (39 one-tile launches with
     # M = 26 rows, each a serial 20-step K loop, become 2 launches that fill the chip.)

@@ -213,12 +213,13 @@ class UNet3DConditionModel(HipModule):
         return self.conv_in.weight.device
 
     def _spatial_blocks(self):
-        out = []
-        for name, m in self.named_modules():
-            if isinstance(m, Transformer2DModel):
-                for i, blk in enumerate(m.transformer_blocks):
-                    out.append((f"{name}.transformer_blocks.{i}", blk))
-        return out
+        """the reference's ``get_attns(include="attentions", exclude="temp_attentions")`` (:1699-1740), quirk included: its exclude
+        test overwrites the include test, so EVERY BasicTransformerBlock whose module name lacks "temp_attentions" is listed --
+        the spatial transformers and, for the `musev` flavour, the block of ``transformer_in`` -- sorted by name (:1684-1685).
+        Index-based consumers (insert_spatial_self_attn_idx, the IP-Adapter loader) therefore see the reference's numbering."""
+        from .attention import BasicTransformerBlock
+        out = [(name, m) for name, m in self.named_modules() if isinstance(m, BasicTransformerBlock) and "temp_attentions" not in name]
+        return sorted(out, key=lambda nb: nb[0])
 
     @property
     def spatial_self_attns(self):
@@ -323,9 +324,10 @@ class UNet3DConditionModel(HipModule):
             vision_condition_frames_sample=vision_condition_frames_sample,
             vision_conditon_frames_sample_index=vision_conditon_frames_sample_index, sample_frame_rate=sample_frame_rate,
             skip_temporal_layers=skip_temporal_layers, frame_index=frame_index, down_block_refer_embs=down_block_refer_embs,
-            mid_block_refer_emb=mid_block_refer_emb, refer_self_attn_emb=refer_self_attn_emb, vision_clip_emb=vision_clip_emb,
+            mid_block_refer_emb=mid_block_refer_emb, refer_self_attn_emb=refer_self_attn_emb,
+            refer_self_attn_emb_mode=refer_self_attn_emb_mode, vision_clip_emb=vision_clip_emb,
             ip_adapter_scale=ip_adapter_scale, face_emb=face_emb, ip_adapter_face_emb=ip_adapter_face_emb,
-            pose_guider_emb=pose_guider_emb)
+            ip_adapter_face_scale=ip_adapter_face_scale, pose_guider_emb=pose_guider_emb)
         out_dtype = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float32
         out = ops.bthwc_to_bcthw(rows, b, t, h, w, dtype=out_dtype)
         if not return_dict:
@@ -338,15 +340,14 @@ class UNet3DConditionModel(HipModule):
                      mid_block_additional_residual=None, sample_index=None, vision_condition_frames_sample=None,
                      vision_conditon_frames_sample_index=None, sample_frame_rate=10, skip_temporal_layers=None,
                      frame_index=None, down_block_refer_embs=None, mid_block_refer_emb=None, refer_self_attn_emb=None,
-                     vision_clip_emb=None, ip_adapter_scale: float = 1.0, face_emb=None, ip_adapter_face_emb=None,
-                     pose_guider_emb=None) -> torch.Tensor:
+                     refer_self_attn_emb_mode: str = "read", vision_clip_emb=None, ip_adapter_scale: float = 1.0, face_emb=None, ip_adapter_face_emb=None,
+                     ip_adapter_face_scale: float = 1.0, pose_guider_emb=None) -> torch.Tensor:
         """The network on channels-last rows: x fp16 [(b t h w), in_channels] -> fp32 [(b t h w), out_channels] (the
         fp32 accumulator of conv_out, unrounded: CFG and the scheduler amplify the prediction's last-bit error).
         Used directly by musev_amd.pipelines.parallel_denoise (which builds window inputs in this layout)."""
         for name, val in (("class_labels", class_labels), ("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
                           ("vision_condition_frames_sample", vision_condition_frames_sample), ("frame_index", frame_index),
-                          ("refer_self_attn_emb", refer_self_attn_emb), ("face_emb", face_emb),
-                          ("ip_adapter_face_emb", ip_adapter_face_emb)):
+                          ("face_emb", face_emb)):
             if val is not None:
                 raise NotImplementedError(f"{name} is outside the hot-path scope of this build (SURVEY.md 8)")
         if skip_temporal_layers is not None:
@@ -398,10 +399,27 @@ class UNet3DConditionModel(HipModule):
                 raise NotImplementedError("vision_clip_emb must be [b, n, q]")
             clip = vision_clip_emb.to(dtype=torch.float16).reshape(-1, vision_clip_emb.shape[-1]).contiguous()
             clip_len = vision_clip_emb.shape[1]
+        refer_self = None
+        if refer_self_attn_emb is not None:
+            # attention.py:261-289 ("read"): block i's reference-only self-attention also attends to the tokens of
+            # refer_self_attn_emb[i] ([b, c, t, h, w]: a ReferenceNet's self-attention inputs).  "write" is the producer side of
+            # the same list (a ReferenceNet run with need_self_attn_block_embs, which no shipped flavour enables): not built.
+            if str(refer_self_attn_emb_mode).lower() != "read":
+                raise NotImplementedError("refer_self_attn_emb_mode='write' (producing the embeddings) is not built; 'read' is")
+            if not hasattr(self._spatial_blocks()[0][1], "spatial_self_attn_idx"):
+                raise ValueError("must call unet.insert_spatial_self_attn_idx to generate spatial attn index")
+            refer_self = list(refer_self_attn_emb)
+        face, face_len = None, 0
+        if self.need_t2i_ip_adapter_face and ip_adapter_face_emb is not None:   # (:1000-1006; ignored by models built without it)
+            if ip_adapter_face_emb.ndim != 3 or ip_adapter_face_emb.shape[0] != b:
+                raise NotImplementedError("ip_adapter_face_emb must be [b, n, q]")
+            face = ip_adapter_face_emb.to(dtype=torch.float16).reshape(-1, ip_adapter_face_emb.shape[-1]).contiguous()
+            face_len = ip_adapter_face_emb.shape[1]
         emb_proj = self._batched_emb_proj(temb_act, femb_act)
         ctx = Ctx(emb_proj=emb_proj, temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
                   clip=clip, clip_len=clip_len, ip_scale=float(ip_adapter_scale), skip_temporal=False,
-                  text_src=encoder_hidden_states, clip_src=vision_clip_emb)
+                  text_src=encoder_hidden_states, clip_src=vision_clip_emb, face=face, face_len=face_len,
+                  face_scale=float(ip_adapter_face_scale), face_src=ip_adapter_face_emb, refer_self=refer_self)
 
         # ---- 2. pre-process (:1008-1063) ----
         pose = None

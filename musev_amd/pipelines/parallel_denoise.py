@@ -100,7 +100,7 @@ class ParallelDenoiser:
                  guidance_scale_method: str = "linear", generator=None, noise_type: str = "random",
                  w_ind_noise: float = 0.5, controlnet=None, control_image: Optional[torch.Tensor] = None,
                  controlnet_conditioning_scale: float = 1.0, control_guidance_start: float = 0.0,
-                 control_guidance_end: float = 1.0, guess_mode: bool = False) -> torch.Tensor:
+                 control_guidance_end: float = 1.0, guess_mode: bool = False, start_step: int = 0) -> torch.Tensor:
         """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
         [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
         ``group``: torch.distributed process group to shard the units over (None = this process alone).
@@ -114,6 +114,8 @@ class ParallelDenoiser:
         (get_controlnet_emb, :1202-1291; window gather of the control frames :1947-1976): its residuals are added to the
         UNet's skips / mid block.  The control frames of a window are the condition frames followed by the window's frames.
         ``max_steps``: run only the first max_steps steps of the num_inference_steps-long schedule (smoke / bench helper).
+        ``start_step``: enter the schedule at this step with ``latents`` being the latents of that step (what the reference's
+        ``get_timesteps(strength)`` does for img2img starts, :1613-1622; the parity tests use it to start a step from recorded latents).
         Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
         if latents.ndim != 5 or latents.shape[0] != 1:
             raise ValueError("latents must be [1, c, T, h, w]")
@@ -223,6 +225,8 @@ class ParallelDenoiser:
         for step, t in enumerate(timesteps):
             if max_steps is not None and step >= max_steps:
                 break
+            if step < start_step:
+                continue
             if not exchange:
                 eps_acc.zero_()  # (the multi-rank gather-reduce overwrites it)
             t_dev.fill_(float(t))
@@ -375,7 +379,7 @@ class ParallelDenoiser:
 
 
 _PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb", "down_block_additional_residuals",
-                    "mid_block_additional_residual", "pose_guider_emb")
+                    "mid_block_additional_residual", "pose_guider_emb", "ip_adapter_face_emb")
 
 
 def _ident(v) -> tuple:

@@ -67,8 +67,9 @@ def _norm(d, p, c):
     d[p + ".bias"] = (c,)
 
 
-def _attn(d, p, c, kv_dim, ip_dim=None):
-    # diffusers Attention: bias-free q/k/v, biased out; IPAttention adds to_k_ip/to_v_ip (attention_processor.py:117-119)
+def _attn(d, p, c, kv_dim, ip_dim=None, face_dim=None):
+    # diffusers Attention: bias-free q/k/v, biased out; IPAttention adds to_k_ip/to_v_ip (attention_processor.py:117-119) and, for
+    # IP-Adapter-FaceID, ip_adapter_face_to_k_ip / _to_v_ip (:127-135)
     _lin(d, p + ".to_q", c, c, bias=False)
     _lin(d, p + ".to_k", c, kv_dim, bias=False)
     _lin(d, p + ".to_v", c, kv_dim, bias=False)
@@ -76,14 +77,18 @@ def _attn(d, p, c, kv_dim, ip_dim=None):
     if ip_dim is not None:
         _lin(d, p + ".to_k_ip", c, ip_dim, bias=False)
         _lin(d, p + ".to_v_ip", c, ip_dim, bias=False)
+    if face_dim is not None:
+        _lin(d, p + ".ip_adapter_face_to_k_ip", c, face_dim, bias=False)
+        _lin(d, p + ".ip_adapter_face_to_v_ip", c, face_dim, bias=False)
 
 
-def _basic_block(d, p, c, cross_dim, ip):
+def _basic_block(d, p, c, cross_dim, ip, face=False):
     # musev/models/attention.py:52-153 (+ diffusers BasicTransformerBlock norms / FeedForward(geglu))
     _norm(d, p + ".norm1", c)
     _attn(d, p + ".attn1", c, c)
     _norm(d, p + ".norm2", c)
-    _attn(d, p + ".attn2", c, cross_dim if cross_dim is not None else c, ip_dim=cross_dim if ip else None)
+    _attn(d, p + ".attn2", c, cross_dim if cross_dim is not None else c, ip_dim=cross_dim if ip else None,
+          face_dim=cross_dim if face else None)
     _norm(d, p + ".norm3", c)
     _lin(d, p + ".ff.net.0.proj", 8 * c, c)
     _lin(d, p + ".ff.net.2", c, 4 * c)
@@ -111,11 +116,11 @@ def _temp_conv(d, p, c):
     d[p + ".temporal_weight"] = (1,)
 
 
-def _transformer2d(d, p, c, cross_dim, ip):
+def _transformer2d(d, p, c, cross_dim, ip, face=False):
     _norm(d, p + ".norm", c)
     d[p + ".proj_in.weight"] = (c, c, 1, 1)
     d[p + ".proj_in.bias"] = (c,)
-    _basic_block(d, p + ".transformer_blocks.0", c, cross_dim, ip)
+    _basic_block(d, p + ".transformer_blocks.0", c, cross_dim, ip, face)
     d[p + ".proj_out.weight"] = (c, c, 1, 1)
     d[p + ".proj_out.bias"] = (c,)
 
@@ -140,6 +145,7 @@ def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     L = cfg["layers_per_block"]
     xd = cfg["cross_attention_dim"]
     ip = cfg["ip_adapter_cross_attn"]
+    face = cfg.get("need_t2i_ip_adapter_face", False)
     ref = cfg["need_refer_emb"]
     temb = ch[0] * 4
     d["conv_in.weight"] = (ch[0], cfg["in_channels"], 3, 3)
@@ -161,7 +167,7 @@ def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
             _resnet(d, f"{p}.resnets.{j}", cin if j == 0 else cout, cout, temb)
             _temp_conv(d, f"{p}.temp_convs.{j}", cout)
             if bt == "CrossAttnDownBlock3D":
-                _transformer2d(d, f"{p}.attentions.{j}", cout, xd, ip)
+                _transformer2d(d, f"{p}.attentions.{j}", cout, xd, ip, face)
                 _temporal_transformer(d, f"{p}.temp_attentions.{j}", cout, temb)
         if not final:
             d[f"{p}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
@@ -173,7 +179,7 @@ def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     c = ch[-1]
     _resnet(d, "mid_block.resnets.0", c, c, temb)
     _temp_conv(d, "mid_block.temp_convs.0", c)
-    _transformer2d(d, "mid_block.attentions.0", c, xd, ip)
+    _transformer2d(d, "mid_block.attentions.0", c, xd, ip, face)
     _temporal_transformer(d, "mid_block.temp_attentions.0", c, temb)
     _resnet(d, "mid_block.resnets.1", c, c, temb)
     _temp_conv(d, "mid_block.temp_convs.1", c)
@@ -190,7 +196,7 @@ def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
             _resnet(d, f"{p}.resnets.{j}", rin + skip, out_c, temb)
             _temp_conv(d, f"{p}.temp_convs.{j}", out_c)
             if bt == "CrossAttnUpBlock3D":
-                _transformer2d(d, f"{p}.attentions.{j}", out_c, xd, ip)
+                _transformer2d(d, f"{p}.attentions.{j}", out_c, xd, ip, face)
                 _temporal_transformer(d, f"{p}.temp_attentions.{j}", out_c, temb)
         if i != len(ch) - 1:
             d[f"{p}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
@@ -376,16 +382,23 @@ def temporal_conv_layer(sd, p: str, x: Tensor, num_frames: int) -> Tensor:
     return rearrange(h, "b c t h w -> (b t) c h w")
 
 
-def attn_self_reference_only(sd, p: str, x: Tensor, heads: int, num_frames: int, vis_idx: Optional[Tensor]) -> Tensor:
+def attn_self_reference_only(sd, p: str, x: Tensor, heads: int, num_frames: int, vis_idx: Optional[Tensor],
+                             refer_emb: Optional[Tensor] = None) -> Tensor:
     """NonParamT2ISelfReferenceXFormersAttnProcessor, musev/models/attention_processor.py:378-546
-    (refer_emb is None for all shipped flavours: referencenet_loader.py:111-119)."""
+    (refer_emb -- refer_self_attn_emb[block] in "read" mode, attention.py:261-289 -- is None for all shipped flavours:
+    referencenet_loader.py:111-119)."""
     ehs = x
-    if vis_idx is not None and num_frames > 1:
+    if (vis_idx is not None and num_frames > 1) or refer_emb is not None:     # :431-433
         e = rearrange(x, "(b t) hw c -> b t hw c", t=num_frames)
-        ip = e.index_select(1, vis_idx)
-        ip = rearrange(ip, "b t hw c -> b 1 (t hw) c")
-        ip = align_repeat(ip, num_frames, dim=1)
-        e = torch.cat([e, ip], dim=2)
+        if vis_idx is not None and num_frames > 1:
+            ip = e.index_select(1, vis_idx)
+            ip = rearrange(ip, "b t hw c -> b 1 (t hw) c")
+            ip = align_repeat(ip, num_frames, dim=1)
+            e = torch.cat([e, ip], dim=2)
+        if refer_emb is not None:                                                # :476-491
+            r = rearrange(refer_emb, "b c t h w -> b 1 (t h w) c")
+            r = align_repeat(r, num_frames, dim=1)
+            e = torch.cat([e, r], dim=2)
         ehs = rearrange(e, "b t hw c -> (b t) hw c")
     q = F.linear(x, sd[p + ".to_q.weight"])
     k = F.linear(ehs, sd[p + ".to_k.weight"])
@@ -395,7 +408,7 @@ def attn_self_reference_only(sd, p: str, x: Tensor, heads: int, num_frames: int,
 
 
 def attn_cross(sd, p: str, x: Tensor, ehs: Tensor, heads: int, vision_clip_emb: Optional[Tensor], ip_scale: float,
-               use_ip: bool) -> Tensor:
+               use_ip: bool, face_emb: Optional[Tensor] = None, face_scale: float = 0.0) -> Tensor:
     """text cross-attention; with use_ip the T2IReferencenetIPAdapterXFormersAttnProcessor branch
     (attention_processor.py:176-359), else diffusers' default processor (same math, no IP term)."""
     q = F.linear(x, sd[p + ".to_q.weight"])
@@ -406,6 +419,11 @@ def attn_cross(sd, p: str, x: Tensor, ehs: Tensor, heads: int, vision_clip_emb: 
         ik = align_repeat(F.linear(vision_clip_emb, sd[p + ".to_k_ip.weight"]), batch, dim=0)
         iv = align_repeat(F.linear(vision_clip_emb, sd[p + ".to_v_ip.weight"]), batch, dim=0)
         o = o + ip_scale * sdp_attention(q, ik, iv, heads)
+    if face_emb is not None and face_scale > 0:   # IP-Adapter-FaceID, attention_processor.py:308-338
+        batch = ehs.shape[0]
+        fk = align_repeat(F.linear(face_emb, sd[p + ".ip_adapter_face_to_k_ip.weight"]), batch, dim=0)
+        fv = align_repeat(F.linear(face_emb, sd[p + ".ip_adapter_face_to_v_ip.weight"]), batch, dim=0)
+        o = o + face_scale * sdp_attention(q, fk, fv, heads)
     return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
 
@@ -424,9 +442,13 @@ def basic_block_spatial(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dic
     """musev/models/attention.py:172-431, spatial instance (attn1 = reference-only self-attn, attn2 = text cross).
     The CFG recompute at :319-334 writes a value that is never read (dead) and is not restated."""
     n = _ln(sd, p + ".norm1", x)
-    x = attn_self_reference_only(sd, p + ".attn1", n, heads, ctx["num_frames"], ctx["vis_idx"]) + x
+    refer_emb = None
+    if ctx.get("refer_self_attn_emb") is not None:   # attention.py:261-289: indexed by the block's spatial_self_attn_idx
+        refer_emb = ctx["refer_self_attn_emb"][ctx["spatial_idx"][p]]
+    x = attn_self_reference_only(sd, p + ".attn1", n, heads, ctx["num_frames"], ctx["vis_idx"], refer_emb) + x
     n = _ln(sd, p + ".norm2", x)
-    x = attn_cross(sd, p + ".attn2", n, ehs, heads, ctx["vision_clip_emb"], ctx["ip_adapter_scale"], ctx["use_ip"]) + x
+    x = attn_cross(sd, p + ".attn2", n, ehs, heads, ctx["vision_clip_emb"], ctx["ip_adapter_scale"], ctx["use_ip"],
+                   ctx.get("ip_adapter_face_emb"), ctx.get("ip_adapter_face_scale", 0.0)) + x
     n = _ln(sd, p + ".norm3", x)
     return feed_forward_geglu(sd, p + ".ff", n) + x
 
@@ -496,10 +518,14 @@ def unet3d_forward(
     mid_block_refer_emb: Optional[Tensor] = None, vision_clip_emb: Optional[Tensor] = None,
     ip_adapter_scale: float = 1.0, down_block_additional_residuals: Optional[Sequence[Tensor]] = None,
     mid_block_additional_residual: Optional[Tensor] = None, pose_guider_emb: Optional[Tensor] = None,
-    skip_temporal_layers: bool = False, collect: Optional[dict] = None,
+    skip_temporal_layers: bool = False, collect: Optional[dict] = None, ip_adapter_face_emb: Optional[Tensor] = None,
+    ip_adapter_face_scale: float = 1.0, refer_self_attn_emb: Optional[Sequence[Tensor]] = None,
+    refer_self_attn_emb_mode: str = "read",
 ) -> Tensor:
     """UNet3DConditionModel.forward (unet_3d_condition.py:773-1280).  sample [b, c, t, h, w] -> same shape.
     `collect` (optional dict) receives named intermediate activations for block-level parity tests."""
+    if refer_self_attn_emb is not None and refer_self_attn_emb_mode.lower() != "read":
+        raise NotImplementedError("refer_self_attn_emb_mode='write' is the ReferenceNet's side of the hand-over (not restated)")
     ch = cfg["block_out_channels"]
     heads = cfg["attention_head_dim"]
     L = cfg["layers_per_block"]
@@ -529,7 +555,17 @@ def unet3d_forward(
     ehs = align_repeat(encoder_hidden_states, emb.shape[0], dim=0)  # :938-941
 
     ctx = dict(num_frames=num_frames, vis_idx=vis_idx, vision_clip_emb=vision_clip_emb,
-               ip_adapter_scale=ip_adapter_scale, use_ip=cfg["ip_adapter_cross_attn"])
+               ip_adapter_scale=ip_adapter_scale, use_ip=cfg["ip_adapter_cross_attn"],
+               # unet_3d_condition.py:1000-1006: only models built with need_t2i_ip_adapter_face hand the face tokens on
+               ip_adapter_face_emb=ip_adapter_face_emb if cfg.get("need_t2i_ip_adapter_face", False) else None,
+               ip_adapter_face_scale=ip_adapter_face_scale,
+               # refer_self_attn_emb ("read"): the spatial blocks are numbered in the sorted order of their module names
+               # (insert_spatial_self_attn_idx, unet_3d_condition.py:1663-1686)
+               refer_self_attn_emb=refer_self_attn_emb,
+               # -- every BasicTransformerBlock outside "temp_attentions", i.e. incl. transformer_in's (get_attns' exclude test
+               # overwrites its include test, :1720-1726)
+               spatial_idx={k: i for i, k in enumerate(sorted({key[:-len(".norm1.weight")] for key in sd
+                                                               if "temp_attentions" not in key and key.endswith(".transformer_blocks.0.norm1.weight")}))})
 
     def rec(name, x):
         if collect is not None:

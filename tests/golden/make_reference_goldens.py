@@ -23,6 +23,7 @@ What is pinned by these fixtures (consumed by tests/test_oracle_golden.py and te
                                 configs 2 and 3: full SD-1.5 widths, B 2, T 13, 64x64 latents
   * reference_unet_refnet_pose_cfg5.npz  (``--at-size-cfg5``) the `musev_referencenet_pose` forward at config 5's size (96x96 latents) with
                                 ControlNet residuals + PoseGuider embedding
+  * reference_multi_shot.npz    musev/pipelines/pipeline_controlnet_predictor.py run_pipe_text2video's shot loop (its own source, pipeline stubbed)
   * reference_pipeline_signature.json  keyword list of MusevControlNetPipeline.__call__ (pipeline_controlnet.py:1295-1420), read with ast
 Only seeds, configs and OUTPUTS are stored (inputs and weights are regenerated from the seeds by the tests).
 """
@@ -80,9 +81,13 @@ def gen_unet(cases=None):
         ctor.update(block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg["layers_per_block"],
                     down_block_types=tuple(cfg["down_block_types"]), up_block_types=tuple(cfg["up_block_types"]),
                     cross_attention_dim=cfg["cross_attention_dim"], attention_head_dim=cfg["attention_head_dim"])
+        if cfg.get("need_t2i_ip_adapter_face"):
+            ctor["need_t2i_ip_adapter_face"] = True
         model = UNet3DConditionModel(**ctor).eval()
         missing, unexpected = model.load_state_dict(sd, strict=True)
         x, t, ehs, kw = case_inputs(case, cfg)
+        if case.get("refer_self"):
+            model.insert_spatial_self_attn_idx()
         with torch.no_grad():
             out = model(x, t, encoder_hidden_states=ehs, return_dict=False, **kw)[0]
             extra = {}
@@ -263,6 +268,65 @@ def gen_poseguider():
         print("poseguider", name, tuple(out.shape), "absmax", float(out.abs().max()), "fresh zero:", bool((fresh == 0).all()))
 
 
+def gen_multi_shot():
+    from golden_cases import MULTI_SHOT_CASES, multi_shot_stub_outputs
+    """musev/pipelines/pipeline_controlnet_predictor.py:356-745 -- ``DiffusersPipelinePredictor.run_pipe_text2video``: the function's
+    OWN SOURCE (cut out of the file with ast; the module itself imports cv2 / omegaconf / h5py / mmcm, none of which exist here) is
+    executed against a stub pipeline that returns deterministic frames, with the vision-condition latents given (no first-frame
+    generation); recorded: the condition latents every call received and the concatenated result."""
+    import ast
+    import textwrap
+    import typing
+    path = "/root/reference/musev/pipelines/pipeline_controlnet_predictor.py"
+    src = open(path).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DiffusersPipelinePredictor")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "run_pipe_text2video")
+    code = textwrap.dedent(ast.get_source_segment(src, fn))
+
+    class _Log:
+        def debug(self, *a, **k):
+            pass
+    ns = dict(np=np, torch=torch, logger=_Log(), set_all_seed=lambda s: (None, None), hist_match_video_bcthw=None,
+              batch_dynamic_crop_resize_images_v2=None, **{k: getattr(typing, k) for k in ("Union", "List", "Optional", "Callable", "Dict", "Any", "Tuple")})
+    exec(compile(code, path, "exec"), ns)
+    run = ns["run_pipe_text2video"]
+    out = {}
+    for name, (n_cond, T, shots, fixed) in MULTI_SHOT_CASES.items():
+        calls = []
+
+        class _Out:
+            pass
+
+        class _Pipe:
+            referencenet = None
+            ip_adapter_image_proj = None
+            facein_image_proj = None
+
+            def __call__(self, **kw):
+                cond = kw["condition_latents"]
+                calls.append(dict(cond=cond.clone(), video_length=kw["video_length"]))
+                lat = multi_shot_stub_outputs(cond, kw["video_length"], len(calls) - 1)
+                o = _Out()
+                o.latents = lat
+                o.videos = lat[:, :3].numpy()        # "np" output: the stub's video IS its first three latent channels
+                return o
+
+        class _Self:
+            pipeline = _Pipe()
+        g = torch.Generator().manual_seed(60 + n_cond)
+        cond0 = torch.randn(1, 4, n_cond, 3, 4, generator=g)
+        video = run(_Self(), video_length=T, prompt="p", height=24, width=32, condition_latents=cond0, n_vision_condition=n_cond,
+                    max_batch_num=shots, fix_condition_images=fixed, video_num_inference_steps=4)
+        out[f"{name}_cond0"] = cond0.numpy()
+        out[f"{name}_video"] = np.asarray(video)
+        for i, c in enumerate(calls):
+            out[f"{name}_call{i}_cond"] = c["cond"].numpy()
+            assert c["video_length"] == T
+    np.savez_compressed(os.path.join(HERE, "reference_multi_shot.npz"), **out)
+    print("multi shot:", {k: v.shape for k, v in out.items() if k.endswith("_video")})
+
+
 def gen_pipeline_signature():
     """the keyword list (names, order, literal defaults) of MusevControlNetPipeline.__call__ and of the predictor's shot loop call
     site, read from the reference's SOURCE with ast (the module itself imports the un-vendored diffusers pipeline base)"""
@@ -288,8 +352,15 @@ def gen_pipeline_signature():
 
 
 if __name__ == "__main__":
+    if "--case" in sys.argv:  # one UNet case by name
+        name = sys.argv[sys.argv.index("--case") + 1]
+        gen_unet({name: dict(UNET_CASES, **UNET_CASES_AT_SIZE, **UNET_CASES_AT_SIZE_CFG5)[name]})
+        sys.exit(0)
     if "--signature" in sys.argv:
         gen_pipeline_signature()
+        sys.exit(0)
+    if "--multi-shot" in sys.argv:
+        gen_multi_shot()
         sys.exit(0)
     if "--at-size" in sys.argv:  # the BASELINE-size UNet cases only (minutes of CPU, ~25 GB)
         gen_unet(UNET_CASES_AT_SIZE)
@@ -299,6 +370,7 @@ if __name__ == "__main__":
         gen_unet(UNET_CASES_AT_SIZE_CFG5)
         sys.exit(0)
     gen_pipeline_signature()
+    gen_multi_shot()
     gen_poseguider()
     gen_loop_utils()
     gen_context()

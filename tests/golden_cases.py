@@ -42,6 +42,14 @@ UNET_CASES = {
     # skip + the mid block (unet_3d_condition.py:1146-1156,1195), PoseGuider embedding after conv_in (:1011-1016); 24x16 latents
     "refnet_hipw_pose_controlnet": dict(flavour="musev_referencenet", arch=_HIPW3, b=2, t=4, h=24, w=16, n_cond=1, weight_seed=7,
                                         input_seed=18, timestep=701, controlnet=True, pose=True),
+    # IP-Adapter-FaceID (need_t2i_ip_adapter_face=True: a third attention over the face tokens in every text cross-attention,
+    # attention_processor.py:127-135,308-338) next to the IP-Adapter branch
+    # refer_self_attn_emb in "read" mode (attention.py:261-289): every spatial self-attention also attends to the tokens of a per-block
+    # reference embedding [b, c, t_ref, h_ref, w_ref] (here 1 x 4 x 4 reference tokens per block)
+    "musev_hipw_refer_self": dict(flavour="musev", arch=_HIPW, b=2, t=4, h=16, w=16, n_cond=1, weight_seed=13, input_seed=23, timestep=501,
+                                  refer_self=True),
+    "refnet_hipw_faceid": dict(flavour="musev_referencenet", arch=dict(_HIPW3, need_t2i_ip_adapter_face=True), b=2, t=4, h=16, w=16,
+                               n_cond=1, weight_seed=12, input_seed=22, timestep=301, face=True),
 }
 
 # ---- BASELINE-size cases: the full SD-1.5-width model on the tensors of BASELINE.json configs 2 and 3 --
@@ -94,6 +102,24 @@ def case_inputs(case: dict, cfg: dict):
         kw["mid_block_additional_residual"] = 0.1 * torch.randn(b * t, mid[0], mid[1], mid[2], generator=g)
     if case.get("pose"):
         kw["pose_guider_emb"] = 0.1 * torch.randn(b * t, cfg["block_out_channels"][0], h, w, generator=g)
+    if case.get("refer_self"):
+        # one embedding per spatial transformer block, in the sorted order of the blocks' module names: channel width of the block
+        widths = []
+        ch, L = cfg["block_out_channels"], cfg["layers_per_block"]
+        for i, bt in enumerate(cfg["down_block_types"]):
+            widths += [ch[i]] * (L if bt.startswith("CrossAttn") else 0)
+        widths += [ch[-1]]  # mid block
+        rev = list(reversed(ch))
+        ups = []
+        for i, bt in enumerate(cfg["up_block_types"]):
+            ups += [rev[i]] * ((L + 1) if bt.startswith("CrossAttn") else 0)
+        # sorted module names: down_blocks.* < mid_block < transformer_in (listed by the reference's get_attns quirk, never read) < up_blocks.*
+        tin = [ch[0]] if cfg["need_transformer_in"] else []
+        kw["refer_self_attn_emb"] = [0.5 * torch.randn(b, c, 1, 4, 4, generator=g) for c in widths + tin + ups]
+        kw["refer_self_attn_emb_mode"] = "read"
+    if case.get("face"):
+        kw["ip_adapter_face_emb"] = torch.randn(b, 4, cfg["cross_attention_dim"], generator=g)
+        kw["ip_adapter_face_scale"] = 0.6
     if case.get("skip_temporal_layers") is not None:
         kw["skip_temporal_layers"] = case["skip_temporal_layers"]
     return x, torch.tensor(case["timestep"]), ehs, kw
@@ -185,3 +211,23 @@ def loop_case_state_dict(case: dict):
     sd = unet3d.init_state_dict(cfg, case["weight_seed"])
     unet3d.calibrate_as_denoiser(sd, cfg)
     return cfg, sd
+
+
+# ---- the predictor's shot loop (pipeline_controlnet_predictor.py:356-745), pinned by executing its own source against a stub pipeline
+MULTI_SHOT_CASES = {
+    # name: (n_vision_condition, video_length, max_batch_num, fix_condition_images)
+    "n1": (1, 5, 3, False),
+    "n2": (2, 6, 3, False),
+    "n1_fixed": (1, 5, 3, True),
+    "one_shot": (1, 5, 1, False),
+}
+
+
+def multi_shot_stub_outputs(cond, video_length: int, call: int):
+    """the deterministic stand-in of one pipeline call, shared by the generator and the tests: frames that depend on the condition
+    latents handed in and on the call's ordinal, condition frames re-inserted in front"""
+    n, c, _, h, w = cond.shape
+    base = cond.mean(dim=2, keepdim=True)
+    t = torch.arange(1, video_length + 1, dtype=cond.dtype).view(1, 1, -1, 1, 1)
+    frames = base * (0.5 + 0.1 * call) + 0.01 * t * (call + 1) + 0.001 * torch.arange(h * w, dtype=cond.dtype).view(1, 1, 1, h, w)
+    return torch.cat([cond, frames.expand(n, c, video_length, h, w)], dim=2)

@@ -302,3 +302,44 @@ def test_euler_from_config_and_step_match_reference_steps():
     s.step(mo, s.timesteps[0], torch.zeros_like(mo, dtype=torch.float32), generator=g1)
     torch.randn(mo.shape, generator=g2, dtype=torch.float16)
     assert torch.equal(g1.get_state(), g2.get_state())
+
+
+# ---- the predictor's multi-shot loop, pinned against the reference function's own source -------------------------
+@pytest.mark.parametrize("name", ["n1", "n2", "n1_fixed", "one_shot"])
+def test_multi_shot_loop_matches_the_predictor_source(name, monkeypatch):
+    """tests/golden/reference_multi_shot.npz was recorded by executing DiffusersPipelinePredictor.run_pipe_text2video (cut out of
+    pipeline_controlnet_predictor.py with ast) against a stub pipeline; the oracle's multi_shot_loop and the product's
+    multi_shot_denoise, driven by the same stub in place of the denoise loop, must hand every shot the same condition latents and
+    return the same concatenation (the stub's video is its first three latent channels)."""
+    from golden_cases import MULTI_SHOT_CASES, multi_shot_stub_outputs
+    from oracle import pipeline as opipe
+    from musev_amd.pipelines.video import multi_shot_denoise
+    gold = np.load(os.path.join(GOLD, "reference_multi_shot.npz"))
+    n_cond, T, shots, fixed = MULTI_SHOT_CASES[name]
+    cond0 = torch.from_numpy(gold[f"{name}_cond0"])
+    want = torch.from_numpy(gold[f"{name}_video"])
+    noises = [torch.zeros(1, 4, T, 3, 4) for _ in range(shots)]
+
+    # oracle: denoise_loop replaced by the stub
+    calls = []
+
+    def stub_loop(unet_fn, noise, prompt_embeds, *, condition_latents=None, **kw):
+        calls.append(condition_latents.clone())
+        return multi_shot_stub_outputs(condition_latents, noise.shape[2], len(calls) - 1)
+    monkeypatch.setattr(opipe, "denoise_loop", stub_loop)
+    got = opipe.multi_shot_loop(None, noises, None, cond0, n_vision_condition=n_cond, fix_condition_images=fixed)
+    assert torch.equal(got[:, :3], want)
+    for i, c in enumerate(calls):
+        assert torch.equal(c, torch.from_numpy(gold[f"{name}_call{i}_cond"])), i
+
+    # product: the denoiser replaced by the stub
+    calls2 = []
+
+    def stub_denoiser(noise, prompt_embeds, *, condition_latents=None, **kw):
+        calls2.append(condition_latents.clone())
+        return multi_shot_stub_outputs(condition_latents, noise.shape[2], len(calls2) - 1)
+    lat, vid = multi_shot_denoise(stub_denoiser, lambda i: noises[i], None, condition_latents=cond0, n_vision_condition=n_cond,
+                                  max_batch_num=shots, fix_condition_images=fixed)
+    assert vid is None and torch.equal(lat[:, :3], want)
+    for i, c in enumerate(calls2):
+        assert torch.equal(c, torch.from_numpy(gold[f"{name}_call{i}_cond"])), i
