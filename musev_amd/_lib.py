@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmusev_hip.so")
+# MUSEV_HIP_LIBRARY: an alternative build of the library (developer A/B runs: another tile table, an experiment build)
+LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmusev_hip.so")
 
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1

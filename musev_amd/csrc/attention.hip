@@ -992,8 +992,8 @@ namespace {
 
 // kernel variants the library runs (Attn3Cfg: 1 = 16-deep contraction tail, 2 = 48-half rows with the ones column at d = 40);
 // chosen from the same-box A/B of tools/gpu_attn_bench.py (profiles/r03*_attn_variants.log)
-constexpr int kAttnVar40 = 7;  // r03a: 1.870 -> 1.715 ms (26 frames), 0.964 -> 0.809 ms (13 frames) at level 0
-constexpr int kAttnVar80 = 0;  // r03a: the 16-deep tail is 3-4 % slower at d = 80
+constexpr int kAttnVar40 = 15;  // r03a / r03g, level 0: var 0 1.870 ms -> var 7 1.715 (26 frames), 0.964 -> 0.809 (13 frames); var 15 a further -5.5 % / -1.5 %
+constexpr int kAttnVar80 = 8;   // r03g: eight waves -5 % at 13 frames (the two-stream default), +4 % at 26; the 16-deep tail is 3-4 % slower at d = 80
 
 template <int D, int VAR>
 int launch_attn3(const AttnArgs& a, dim3 grid1, hipStream_t s) {
