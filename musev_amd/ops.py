@@ -183,6 +183,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     return o
 
 
+def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], reps: int = 1) -> float:
+    """the two lists re-issued CONCURRENTLY, one per HIP stream (how the loop runs the two CFG halves); returns the elapsed device
+    milliseconds from the common start to the later of the two ends, over all reps"""
+    lib = _lib.load()
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=main.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    side.wait_stream(main)
+    for _ in range(reps):
+        for d, _keep, _nb in rec_b:
+            check(lib.mv_gemm_f16(C.byref(d), side.cuda_stream), "mv_gemm_f16(replay)")
+        for d, _keep, _nb in rec_a:
+            check(lib.mv_gemm_f16(C.byref(d), main.cuda_stream), "mv_gemm_f16(replay)")
+    main.wait_stream(side)
+    e1.record(main)
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
 # LayerNorm folding (env knob for A/B runs: MUSEV_LN_FOLD=0 keeps mv_layernorm_f16 + the plain projection everywhere)
 LN_FOLD: bool = os.environ.get("MUSEV_LN_FOLD", "1") == "1"
 _ln_fold_cache: dict = {}

@@ -57,6 +57,7 @@ def test_bench_main_dry_run(monkeypatch, capsys):
             return out
         monkeypatch.setattr(ops, name, f)
     monkeypatch.setattr(ops, "replay_gemms", lambda rec, reps=1: 0.01 * len(rec) * reps)
+    monkeypatch.setattr(ops, "replay_gemms_two_streams", lambda a, b, reps=1: 0.008 * (len(a) + len(b)) * reps)
 
     monkeypatch.setattr(bench, "build_unet", build_unet)
     monkeypatch.setattr(ParallelDenoiser, "_device_check", False)

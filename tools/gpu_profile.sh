@@ -1,30 +1,27 @@
 #!/usr/bin/env bash
-# Final measurement of a build: parity tests, smoke, the default bench line, rocprofv3 kernel trace + stats of the bench
-# command, and two PMC passes (FETCH_SIZE, WRITE_SIZE) over the GEMM launches for the roofline "traffic" figure.
+# Final measurement of a build (run through gpurun):  bash tools/gpu_profile.sh <tag>
+#   1. the bench line of the command the driver runs (python bench.py --steps 20 --warmup 5)
+#   2. rocprofv3 --kernel-trace --stats of THE SAME command (the profiler serialises the two HIP streams, so the per-kernel
+#      durations are the kernels' own -- what bench.py's one-stream roofline replay measures as well)
+#   3. two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel trace / stats only) for the roofline "traffic" figure:
+#      eager launches (MUSEV_NO_GRAPH=1), the loop's own stream setting (batch-1 launches, like the timed path)
+# Copy gpurun_out/<tag>_* summaries into profiles/ afterwards (tools/pmc_summary.py writes <tag>_pmc_summary.json).
 set -u
-TAG=${1:-r01f}
+TAG=${1:-r03z}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
-if [ "${SKIP_AB:-0}" != "1" ]; then
-  ( timeout 600 python tools/gpu_gemm_ab.py $TAG ${VARIANTS:-2} 2>&1 | tail -60 ) > $OUT/${TAG}_gemm_ab.log
-fi
-if [ "${PROFILE_ONLY:-0}" != "1" ]; then
-( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $OUT/${TAG}_pytest_gpu.log
-( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > $OUT/${TAG}_smoke.log
-( timeout 900 python bench.py 2>&1 | tail -2 ) > $OUT/${TAG}_bench.log
-fi
+( timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 ) > $OUT/${TAG}_bench.json
 cd /tmp
-# per-kernel durations are profiled on ONE stream (MUSEV_HALF_STREAMS=0), like bench.py's own instrumented roofline pass
-( MUSEV_HALF_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-config4 2>&1 | tail -3 ) > $OUT/${TAG}_rocprof.log
+( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -2 ) > $OUT/${TAG}_rocprof.log
 for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do
-  ( MUSEV_NO_GRAPH=1 MUSEV_HALF_STREAMS=0 timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-config4 2>&1 | tail -3 ) > $OUT/${TAG}_pmc_$c.log
+  ( MUSEV_NO_GRAPH=1 timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-config4 2>&1 | tail -2 ) > $OUT/${TAG}_pmc_$c.log
 done
 cd $ROOT
-find $OUT/${TAG}_prof -name "*kernel_trace.csv" -size +30M -delete
+find $OUT/${TAG}_prof -name "*kernel_trace.csv" -delete
+cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv 2>/dev/null
 python tools/pmc_summary.py $TAG > $OUT/${TAG}_pmc_summary.log 2>&1
-find $OUT -name "*counter_collection.csv" -size +20M -delete
-tail -30 $OUT/${TAG}_gemm_ab.log 2>/dev/null
-tail -3 $OUT/${TAG}_pytest_gpu.log; tail -2 $OUT/${TAG}_smoke.log; tail -1 $OUT/${TAG}_bench.log | cut -c1-2500; tail -30 $OUT/${TAG}_pmc_summary.log
+find $OUT -name "*counter_collection.csv" -delete
+cut -c1-1500 $OUT/${TAG}_bench.json; tail -2 $OUT/${TAG}_rocprof.log; head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-160; tail -25 $OUT/${TAG}_pmc_summary.log
