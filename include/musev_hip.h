@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 4
+#define MV_ABI_VERSION 5
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -84,6 +84,20 @@ typedef struct mv_gemm_desc {
     const float* ln_colbias; /* fp32 [N]: sum_k beta_k W[n][k] + bias_n (bias / rowbias must be NULL)                      */
     float ln_eps;            /* LayerNorm epsilon                                                                          */
     int32_t reserved0;
+    /* Statistics of the OUTPUT, formed by the epilogue from the fp16 values it stores, for the normalisation that reads the    */
+    /* tensor next (16-byte epilogue, one K slice, no GEGLU; mv_gemm_stats_layout says whether a launch can and how big):      */
+    /*   colstats[m / rows_per_tile][n] = {sum, sum of squares} over that row tile -> mv_groupnorm_cs_f16 (replaces the        */
+    /*   statistics pass of nn.GroupNorm over the conv / proj_out outputs: resnet.py:57-82, transformer_2d.py:260, unet blocks) */
+    float* colstats;         /* fp32 [ceil(M / rows_per_tile)][N][2], 8-byte aligned, or NULL                                   */
+    int64_t colstats_floats; /* capacity of colstats in floats                                                                 */
+    /*   rowstats[part][m] = {sum, sum of squares} of row m over the columns of wave-tile column `part` -> the LayerNorm-folded  */
+    /*   projection that reads the tensor next takes them as ln_rowstats / ln_parts and forms no statistics of its own         */
+    /*   (nn.LayerNorm norm1/2/3 behind proj_in / to_out, musev/models/attention.py:293-308,345-362,398-429)                   */
+    float* rowstats;         /* fp32 [row_parts][M][2], 8-byte aligned, or NULL                                                */
+    int64_t rowstats_floats; /* capacity of rowstats in floats                                                                 */
+    const float* ln_rowstats;/* with ln_colsum: the producer's rowstats of `a` ([ln_parts][M][2]) or NULL (statistics in-loop) */
+    int32_t ln_parts;
+    int32_t reserved1;
 } mv_gemm_desc;
 
 /* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K
@@ -94,6 +108,11 @@ int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
 int64_t mv_gemm_workspace_bytes(const mv_gemm_desc* d);
 /* the (tile configuration id, K slices) mv_gemm_f16 would use for this descriptor: introspection for tuners and tests */
 int mv_gemm_choice(const mv_gemm_desc* d, int32_t* cfg, int32_t* nsplit);
+/* output statistics this descriptor's launch can emit (d->colstats / d->rowstats themselves are ignored here):
+ * *col_rows_per_tile = rows per colstats row tile, *row_parts = partials per row of rowstats (0 = the launch cannot emit
+ * them: split K, GEGLU or the narrow epilogue), *col_floats / *row_floats = floats to allocate */
+int mv_gemm_stats_layout(const mv_gemm_desc* d, int32_t* col_rows_per_tile, int64_t* col_floats, int32_t* row_parts,
+                         int64_t* row_floats);
 
 /* tile-configuration catalogue of the implicit-GEMM kernel (block tile, waves, K depth, LDS stages), for the per-shape
  * tuner (tools/gpu_gemm_tune.py -> musev_amd/csrc/gemm_tuned.h).  mv_gemm_config_desc fills {block rows, block columns,
@@ -122,6 +141,14 @@ int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int
                      int64_t n_items, int64_t rows, int32_t num_groups, float eps,
                      const void* gamma, const void* beta, int32_t silu,
                      void* y, int32_t ldy, float* partial, int32_t nsplit, float* stat, void* stream);
+/* the same with the statistics folded from producer-side column statistics (mv_gemm_desc.colstats) instead of a pass over x:
+ * cs1 = colstats of the launch that wrote x1 (its N == c1, row tiles of rpt1 rows, rows %% rpt1 == 0), cs2 / rpt2 those of
+ * x2 (required when x2 != NULL).  Two launches: fold (one block per (item, group)), apply.  Slabs small enough for the
+ * one-launch kernel of mv_groupnorm_f16 still take it (the column statistics are then unused). */
+int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
+                        int64_t n_items, int64_t rows, int32_t num_groups, float eps,
+                        const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
+                        const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, void* stream);
 /* scratch size (in floats) of `partial` for the call above */
 int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_groups, int32_t nsplit);
 int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c);

@@ -10,6 +10,7 @@ typedef _Float16 half_t;
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef short short4v __attribute__((ext_vector_type(4)));

@@ -32,6 +32,10 @@ struct GnArgs {
     int silu;
     int groups;
     float eps;
+    // producer-side column statistics (mv_groupnorm_cs_f16): [rows / rpt][c][2] per source
+    const float* cs1;
+    const float* cs2;
+    int rpt1, rpt2;
 };
 
 __device__ __forceinline__ const half_t* gn_src(const GnArgs& a, long item, long row, int o) {
@@ -144,6 +148,62 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a) {
         const double n = (double)cpg * (double)a.rows;
         const double mean = ts / n;
         double var = tss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a.stat[(item * a.groups + gI) * 2] = (float)mean;
+        a.stat[(item * a.groups + gI) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
+// statistics from the producers' column statistics: one block per (item, group) walks the [row tile][channel] pairs of the group
+// (of either source; a group may straddle the two) with all of its loads independent, double per-thread sums, a fixed xor tree
+// per wave and a fixed-order fold of the waves: bit-reproducible.  Pairs per block: 64 row tiles x 10 channels at level 0 per
+// frame, 832 x 10 for a temporal norm (statistics over T*H*W) -> the launcher sizes the block to ~8 pairs per thread.
+__global__ void gn_finalize_cs_kernel(const GnArgs a) {
+    __shared__ double red[16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const long item = blockIdx.x / a.groups;
+    const int gI = (int)(blockIdx.x - item * a.groups);
+    const int cpg = a.oc * 8 / a.groups;
+    const int c0 = gI * cpg;
+    double ts = 0.0, tss = 0.0;
+#pragma unroll
+    for (int src = 0; src < 2; ++src) {
+        const float* cs = src ? a.cs2 : a.cs1;
+        const int cb = src ? a.c1 : 0, cn = src ? a.c2 : a.c1;  // channels [cb, cb + cn) of the concatenation
+        const int lo = c0 > cb ? c0 : cb, hi = (c0 + cpg < cb + cn) ? c0 + cpg : cb + cn;
+        if (!cs || lo >= hi) continue;
+        const int rpt = src ? a.rpt2 : a.rpt1;
+        const long tiles = a.rows / rpt;
+        const int w = hi - lo;
+        const float* base = cs + (item * tiles * cn + (lo - cb)) * 2;
+        const long total = tiles * w;
+        for (long k = tid; k < total; k += nthr) {
+            const long tile = k / w;
+            const int c = (int)(k - tile * w);
+            const float2v v = *reinterpret_cast<const float2v*>(base + (tile * cn + c) * 2);
+            ts += (double)v[0];
+            tss += (double)v[1];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ts += __shfl_xor(ts, o, 64);
+        tss += __shfl_xor(tss, o, 64);
+    }
+    if (lane == 0) {
+        red[wave][0] = ts;
+        red[wave][1] = tss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0, ss = 0.0;
+        for (int w2 = 0; w2 < (nthr >> 6); ++w2) {
+            s += red[w2][0];
+            ss += red[w2][1];
+        }
+        const double n = (double)cpg * (double)a.rows;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
         if (var < 0.0) var = 0.0;
         a.stat[(item * a.groups + gI) * 2] = (float)mean;
         a.stat[(item * a.groups + gI) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -401,30 +461,39 @@ extern "C" int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_grou
     return n_items * (int64_t)nsplit * 2 * num_groups;
 }
 
-extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
-                                int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
-                                const void* beta, int32_t silu, void* y, int32_t ldy, float* partial, int32_t nsplit,
-                                float* stat, void* stream) {
-    MV_REQUIRE(x1 && y && gamma && beta && partial && stat, "mv_groupnorm_f16: null pointer");
+namespace {
+// shared by mv_groupnorm_f16 (cs1 == nullptr: statistics by a pass over x) and mv_groupnorm_cs_f16
+int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2, int64_t n_items,
+              int64_t rows, int32_t num_groups, float eps, const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
+              float* partial, int32_t nsplit, float* stat, const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, void* stream) {
+    MV_REQUIRE(x1 && y && gamma && beta && stat && (partial || cs1), "%s: null pointer", who);
     if (!x2) c2 = 0;
     const int C = c1 + c2;
-    MV_REQUIRE(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "mv_groupnorm_f16: channels must be multiples of 8 (c1=%d c2=%d)", c1, c2);
-    MV_REQUIRE(num_groups > 0 && C % num_groups == 0, "mv_groupnorm_f16: C=%d not divisible by groups=%d", C, num_groups);
-    MV_REQUIRE(ld1 % 8 == 0 && (c2 == 0 || ld2 % 8 == 0) && ldy % 8 == 0, "mv_groupnorm_f16: leading dims must be multiples of 8");
-    MV_REQUIRE(n_items > 0 && rows > 0 && nsplit > 0 && nsplit <= 65535 && n_items <= 65535, "mv_groupnorm_f16: bad sizes");
+    MV_REQUIRE(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "%s: channels must be multiples of 8 (c1=%d c2=%d)", who, c1, c2);
+    MV_REQUIRE(num_groups > 0 && C % num_groups == 0, "%s: C=%d not divisible by groups=%d", who, C, num_groups);
+    MV_REQUIRE(ld1 % 8 == 0 && (c2 == 0 || ld2 % 8 == 0) && ldy % 8 == 0, "%s: leading dims must be multiples of 8", who);
+    MV_REQUIRE(n_items > 0 && rows > 0 && nsplit > 0 && nsplit <= 65535 && n_items <= 65535, "%s: bad sizes", who);
     MV_REQUIRE((reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0,
-               "mv_groupnorm_f16: gamma / beta must be 16-byte aligned");
+               "%s: gamma / beta must be 16-byte aligned", who);
+    if (cs1) {
+        MV_REQUIRE(rpt1 > 0 && rows % rpt1 == 0 && (reinterpret_cast<uintptr_t>(cs1) & 7) == 0,
+                   "%s: rows=%ld is not a whole number of the producer's %d-row statistic tiles", who, (long)rows, rpt1);
+        MV_REQUIRE(c2 == 0 || (cs2 && rpt2 > 0 && rows % rpt2 == 0 && (reinterpret_cast<uintptr_t>(cs2) & 7) == 0),
+                   "%s: the second source needs column statistics too (rows %% rpt2 == 0)", who);
+        MV_REQUIRE(n_items * num_groups <= 0x7fffffffL, "%s: too many (item, group) pairs", who);
+    }
     const int oc = C / 8;
-    MV_REQUIRE(oc <= 1024, "mv_groupnorm_f16: C=%d too large", C);
+    MV_REQUIRE(oc <= 1024, "%s: C=%d too large", who, C);
     int rl = 256 / oc;
     if (rl < 1) rl = 1;
     const int bs = oc * rl;
-    MV_REQUIRE(bs >= num_groups, "mv_groupnorm_f16: C=%d too small for %d groups", C, num_groups);
+    MV_REQUIRE(bs >= num_groups, "%s: C=%d too small for %d groups", who, C, num_groups);
     GnArgs a;
     a.x1 = (const half_t*)x1; a.x2 = (const half_t*)x2; a.c1 = c1; a.c2 = c2; a.ld1 = ld1; a.ld2 = ld2;
     a.rows = rows; a.nsplit = nsplit; a.oc = oc; a.rl = rl; a.partial = partial; a.stat = stat; a.n_items = n_items;
     a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta; a.y = (half_t*)y; a.ldy = ldy; a.silu = silu;
     a.groups = num_groups; a.eps = eps;
+    a.cs1 = cs1; a.cs2 = c2 ? cs2 : nullptr; a.rpt1 = rpt1; a.rpt2 = rpt2;
     hipStream_t s = (hipStream_t)stream;
     {   // small slabs: one launch (see gn_small_kernel)
         const int cpg = C / num_groups;
@@ -442,15 +511,43 @@ extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int3
             return MV_OK;
         }
     }
-    // LDS: [rl][C][2] floats = 64 bytes per thread for the row-lane fold
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), (size_t)bs * 16 * sizeof(float), s, a);
-    MV_CHECK_LAUNCH("mv_groupnorm_f16(stats)");
     const long pairs = (long)num_groups * n_items;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a);
-    MV_CHECK_LAUNCH("mv_groupnorm_f16(finalize)");
+    if (cs1) {
+        // ~8 (row tile, channel) pairs per thread
+        const int cpg = C / num_groups;
+        const long per_block = (rows / rpt1) * (long)cpg;
+        const int threads = per_block <= 512 ? 64 : per_block <= 2048 ? 256 : 1024;
+        hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3((unsigned)pairs), dim3(threads), 0, s, a);
+        MV_CHECK_LAUNCH("mv_groupnorm_cs_f16(fold)");
+    } else {
+        // LDS: [rl][C][2] floats = 64 bytes per thread for the row-lane fold
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), (size_t)bs * 16 * sizeof(float), s, a);
+        MV_CHECK_LAUNCH("mv_groupnorm_f16(stats)");
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a);
+        MV_CHECK_LAUNCH("mv_groupnorm_f16(finalize)");
+    }
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(apply)");
     return MV_OK;
+}
+}  // namespace
+
+extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
+                                int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
+                                const void* beta, int32_t silu, void* y, int32_t ldy, float* partial, int32_t nsplit,
+                                float* stat, void* stream) {
+    MV_REQUIRE(partial, "mv_groupnorm_f16: null pointer");
+    return gn_launch("mv_groupnorm_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, partial,
+                     nsplit, stat, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
+                                   int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
+                                   const void* beta, int32_t silu, void* y, int32_t ldy, const float* cs1, int32_t rpt1,
+                                   const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, void* stream) {
+    MV_REQUIRE(cs1, "mv_groupnorm_cs_f16: null column statistics");
+    return gn_launch("mv_groupnorm_cs_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, nullptr,
+                     nsplit, stat, cs1, rpt1, cs2, rpt2, stream);
 }
 
 extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t c,

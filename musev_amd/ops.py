@@ -47,9 +47,41 @@ GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
 
 
-def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = ()) -> None:
+# Producer-side GroupNorm statistics (env knob for A/B runs: MUSEV_COLSTATS=0 keeps the statistics pass of mv_groupnorm_f16):
+# the convolutions / proj_out launches whose output a GroupNorm reads next also emit per-row-tile column sums from their epilogue
+# (mv_gemm_desc.colstats); the buffer rides on the output tensor OBJECT (`_mv_colstats`), so a view, a copy or any tensor produced
+# some other way simply has none and `groupnorm` takes its own statistics pass.
+COLSTATS: bool = os.environ.get("MUSEV_COLSTATS", "1") == "1"
+COLSTATS_HITS: int = 0   # GroupNorm calls served from producer statistics (tests / reports)
+
+
+# Producer-side LayerNorm statistics (MUSEV_ROWSTATS=0: the folded projections form the row statistics in their K loop, as in
+# round 3's first form): proj_in / to_out launches also emit per-row partial sums (mv_gemm_desc.rowstats, riding on the output tensor
+# object as `_mv_rowstats`), and the LayerNorm-folded projection behind them takes those (ln_rowstats) -- its K loop is then the
+# plain one, on the plain projection's tile.  With them the GEGLU projection folds its LayerNorm too (MUSEV_LN_GEGLU_FOLD=0: not).
+ROWSTATS: bool = os.environ.get("MUSEV_ROWSTATS", "1") == "1"
+LN_GEGLU_FOLD: bool = os.environ.get("MUSEV_LN_GEGLU_FOLD", "1") == "1"
+
+
+def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None,
+                 rowstats_for: Optional[torch.Tensor] = None) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
+    want_cs = colstats_for is not None and COLSTATS
+    want_rs = rowstats_for is not None and ROWSTATS
+    if want_cs or want_rs:
+        rpt, nfl, parts, rfl = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
+        check(lib.mv_gemm_stats_layout(C.byref(d), C.byref(rpt), C.byref(nfl), C.byref(parts), C.byref(rfl)), what)
+        if want_cs and rpt.value > 0:
+            cs = torch.empty(nfl.value, dtype=torch.float32, device=dev)
+            d.colstats, d.colstats_floats = cs.data_ptr(), nfl.value
+            colstats_for._mv_colstats = (cs, rpt.value)
+            keep = keep + (cs,)
+        if want_rs and parts.value > 0:
+            rs = torch.empty(rfl.value, dtype=torch.float32, device=dev)
+            d.rowstats, d.rowstats_floats = rs.data_ptr(), rfl.value
+            rowstats_for._mv_rowstats = (rs, parts.value)
+            keep = keep + (rs,)
     need = lib.mv_gemm_workspace_bytes(C.byref(d))
     if need < 0:
         check(1, what)
@@ -141,8 +173,12 @@ def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_group: int = 0, residual=None, alpha=None, act: int = MV_ACT_NONE, geglu: bool = False,
-         out: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None,
+         colstats: bool = False, rowstats: bool = False) -> torch.Tensor:
     """out = act(|alpha| * ([a | a2] @ w.T + bias + rowbias[row // rows_per_group])) + residual   (fp16, fp32 accumulate).
+    ``colstats``: the output feeds a GroupNorm next -- emit its column statistics from the epilogue (see COLSTATS).
+    ``rowstats``: the output feeds a LayerNorm-folded projection next -- emit its row statistics (see ROWSTATS); with ``ln``, the
+    row statistics ``a``'s producer left on it are used instead of in-loop ones.
 
     ``w`` is [N, K] (torch Linear layout).  With ``geglu`` the rows of ``w`` / ``bias`` must be packed by
     :func:`pack_geglu` and the result has N/2 columns: value * gelu(gate).
@@ -179,7 +215,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if bias is not None or rowbias is not None or a2 is not None:
             raise ValueError("gemm(ln=...): the bias is part of colbias; no rowbias / second source")
         d.ln_colsum, d.ln_colbias, d.ln_eps = cs.data_ptr(), cb.data_ptr(), float(eps)
-    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha, ln))
+        rs = getattr(a, "_mv_rowstats", None) if ROWSTATS else None
+        if rs is not None:
+            d.ln_rowstats, d.ln_parts = rs[0].data_ptr(), rs[1]
+            ln = ln + (rs[0],)
+    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha, ln), o if colstats and not geglu else None,
+                 o if rowstats and not geglu else None)
     return o
 
 
@@ -208,13 +249,14 @@ LN_FOLD: bool = os.environ.get("MUSEV_LN_FOLD", "1") == "1"
 _ln_fold_cache: dict = {}
 
 
-def ln_fold_applies(M: int, N: int, K: int, geglu: bool) -> bool:
+def ln_fold_applies(M: int, N: int, K: int, geglu: bool, have_rowstats: bool = False) -> bool:
     """whether ``gemm(..., ln=)`` is the better form of LayerNorm + projection for this problem: it is wherever the plain
     projection runs as ONE K slice (the folded kernel needs the whole row in one block's K loop); the small-M / long-K problems
     the library splits over K keep mv_layernorm_f16 + the split GEMM."""
-    if not LN_FOLD or K % 64 != 0 or geglu:
-        # (GEGLU: the gate's epilogue already bounds that launch -- folded it measured 4-11 % SLOWER than LayerNorm + GEMM at every
-        # level, profiles/r03e_ln_fold_variants.log; the q / k / v projections gain 5-44 %)
+    if not LN_FOLD or K % 64 != 0 or (geglu and not (have_rowstats and ROWSTATS and LN_GEGLU_FOLD)):
+        # (GEGLU with in-loop statistics: every one of the N / BN column tiles re-forms them and the gate's epilogue already bounds
+        # that launch -- folded it measured 4-11 % SLOWER than LayerNorm + GEMM at every level, profiles/r03e_ln_fold_variants.log;
+        # the q / k / v projections gain 5-44 %.  With the producer's row statistics nothing is re-formed.)
         return False
     key = (M, N, K, bool(geglu))
     hit = _ln_fold_cache.get(key)
@@ -275,7 +317,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2
     d.mode, d.stride, d.upsample = MV_GEMM_CONV3X3, stride, int(upsample)
     d.hin, d.win, d.hout, d.wout = h, w_, ho, wo
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, None, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device, (x, x2, w, o, bias, rowbias, residual))
+    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device, (x, x2, w, o, bias, rowbias, residual), o)
     return o
 
 
@@ -297,7 +339,7 @@ def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=No
     d.M, d.N, d.K = M, N, K
     d.mode, d.t, d.hw = MV_GEMM_TCONV3, t, hw
     _fill_epilogue(d, N, M, bias, None, 0, residual, alpha, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device, (x, w, o, bias, residual, alpha))
+    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device, (x, w, o, bias, residual, alpha), o)
     return o
 
 
@@ -320,10 +362,23 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
     if (gamma.data_ptr() | beta.data_ptr()) & 15:
         raise ValueError("groupnorm: gamma / beta must be 16-byte aligned")
     nsplit = lib.mv_groupnorm_default_nsplit(n_items, rows, c)
+    o = _out(out, n_items * rows, c, x)
+    cs1 = getattr(x, "_mv_colstats", None) if COLSTATS else None
+    cs2 = getattr(x2, "_mv_colstats", None) if (COLSTATS and x2 is not None) else None
+    if cs1 is not None and rows % cs1[1] == 0 and (x2 is None or (cs2 is not None and rows % cs2[1] == 0)):
+        # the producers of x (and x2) left column statistics behind: fold those instead of reading the tensors once more
+        global COLSTATS_HITS
+        COLSTATS_HITS += 1
+        stat = torch.empty(n_items * 2 * groups, dtype=torch.float32, device=x.device)
+        check(lib.mv_groupnorm_cs_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
+                                      n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
+                                      o.data_ptr(), o.stride(0), cs1[0].data_ptr(), cs1[1],
+                                      cs2[0].data_ptr() if cs2 is not None else None, cs2[1] if cs2 is not None else 0,
+                                      nsplit, stat.data_ptr(), _stream()), "mv_groupnorm_cs_f16")
+        return o
     scratch = torch.empty(n_items * nsplit * 2 * groups + n_items * 2 * groups, dtype=torch.float32, device=x.device)
     partial_ptr = scratch.data_ptr()
     stat_ptr = partial_ptr + 4 * n_items * nsplit * 2 * groups
-    o = _out(out, n_items * rows, c, x)
     check(lib.mv_groupnorm_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
                                n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
                                o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _stream()), "mv_groupnorm_f16")

@@ -201,6 +201,7 @@ static inline T sim_lane_read(T v, int src_lane) {
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int) { return sim_lane_read(v, (int)(threadIdx.x & 63) ^ mask); }
 template <typename T> static inline T __shfl(T v, int src, int) { return sim_lane_read(v, src); }
+template <typename T> static inline T __shfl_down(T v, int off, int) { const int l = (int)(threadIdx.x & 63); return sim_lane_read(v, l + off < 64 ? l + off : l); }
 static inline int __any(int pred) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     sim_xchg[wave][lane] = pred ? 1.0 : 0.0;
