@@ -90,14 +90,6 @@ typedef struct mv_gemm_desc {
     /*   statistics pass of nn.GroupNorm over the conv / proj_out outputs: resnet.py:57-82, transformer_2d.py:260, unet blocks) */
     float* colstats;         /* fp32 [ceil(M / rows_per_tile)][N][2], 8-byte aligned, or NULL                                   */
     int64_t colstats_floats; /* capacity of colstats in floats                                                                 */
-    /*   rowstats[part][m] = {sum, sum of squares} of row m over the columns of wave-tile column `part` -> the LayerNorm-folded  */
-    /*   projection that reads the tensor next takes them as ln_rowstats / ln_parts and forms no statistics of its own         */
-    /*   (nn.LayerNorm norm1/2/3 behind proj_in / to_out, musev/models/attention.py:293-308,345-362,398-429)                   */
-    float* rowstats;         /* fp32 [row_parts][M][2], 8-byte aligned, or NULL                                                */
-    int64_t rowstats_floats; /* capacity of rowstats in floats                                                                 */
-    const float* ln_rowstats;/* with ln_colsum: the producer's rowstats of `a` ([ln_parts][M][2]) or NULL (statistics in-loop) */
-    int32_t ln_parts;
-    int32_t reserved1;
 } mv_gemm_desc;
 
 /* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K
@@ -108,11 +100,9 @@ int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
 int64_t mv_gemm_workspace_bytes(const mv_gemm_desc* d);
 /* the (tile configuration id, K slices) mv_gemm_f16 would use for this descriptor: introspection for tuners and tests */
 int mv_gemm_choice(const mv_gemm_desc* d, int32_t* cfg, int32_t* nsplit);
-/* output statistics this descriptor's launch can emit (d->colstats / d->rowstats themselves are ignored here):
- * *col_rows_per_tile = rows per colstats row tile, *row_parts = partials per row of rowstats (0 = the launch cannot emit
- * them: split K, GEGLU or the narrow epilogue), *col_floats / *row_floats = floats to allocate */
-int mv_gemm_stats_layout(const mv_gemm_desc* d, int32_t* col_rows_per_tile, int64_t* col_floats, int32_t* row_parts,
-                         int64_t* row_floats);
+/* output statistics this descriptor's launch can emit (d->colstats itself is ignored here): *col_rows_per_tile = rows per
+ * colstats row tile (0 = the launch cannot emit them: split K, GEGLU or the narrow epilogue), *col_floats = floats to allocate */
+int mv_gemm_stats_layout(const mv_gemm_desc* d, int32_t* col_rows_per_tile, int64_t* col_floats);
 
 /* tile-configuration catalogue of the implicit-GEMM kernel (block tile, waves, K depth, LDS stages), for the per-shape
  * tuner (tools/gpu_gemm_tune.py -> musev_amd/csrc/gemm_tuned.h).  mv_gemm_config_desc fills {block rows, block columns,

@@ -36,8 +36,6 @@ class GemmDesc(C.Structure):
         ("cfg", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("ln_colsum", C.c_void_p), ("ln_colbias", C.c_void_p), ("ln_eps", C.c_float), ("reserved0", C.c_int32),
         ("colstats", C.c_void_p), ("colstats_floats", C.c_int64),
-        ("rowstats", C.c_void_p), ("rowstats_floats", C.c_int64), ("ln_rowstats", C.c_void_p), ("ln_parts", C.c_int32),
-        ("reserved1", C.c_int32),
     ]
 
 
@@ -68,7 +66,7 @@ SIGNATURES = {
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "mv_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
     "mv_gemm_choice": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
-    "mv_gemm_stats_layout": (_i32, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp]),
+    "mv_gemm_stats_layout": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
     "mv_gemm_num_configs": (_i32, []),
     "mv_gemm_config_desc": (_i32, [_i32, _vp]),
     "mv_gemm_tile_order": (_i32, [_i32, _i32, _i32, _vp, _vp]),

@@ -57,12 +57,6 @@ struct GemmArgs {
     // the sum and the sum of squares of the fp16 values it stores, per column over its 16 TM rows, and writes them to
     // colstats[mw0 / (16 TM)][n][2] -- mv_groupnorm_cs_f16 folds them instead of re-reading the tensor
     float* colstats;
-    // row statistics of the OUTPUT for the LayerNorm that reads it next: every wave adds the sum / sum of squares of the fp16
-    // values it stores per row over its W = 16 TN columns and writes rowstats[nw0 / W][m][2]; a LayerNorm-folded launch that is
-    // handed them (ln_rowstats, ln_parts partials per row) skips its in-loop statistics
-    float* rowstats;
-    const float* ln_rowstats;
-    int ln_parts;
 };
 
 template <int TM, int TN>
@@ -320,7 +314,6 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
     };
     // column statistics (see GemmArgs::colstats): this lane's 8 columns over the rows it stores
     const bool cs_on = !GEGLU && p.colstats != nullptr;
-    const bool rs_on = !GEGLU && p.rowstats != nullptr;  // row statistics (see GemmArgs::rowstats)
     float cs1[GEGLU ? 1 : 8], cs2[GEGLU ? 1 : 8];
     if constexpr (!GEGLU) {
 #pragma unroll
@@ -397,26 +390,6 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
                         cs2[e] = fmaf(f, f, cs2[e]);
                     }
                 }
-                if (rs_on) {  // (wave-uniform; every lane takes part in the shuffles, lanes without a valid chunk add zeros)
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = (float)o[e];
-                        s1 += f;
-                        s2 = fmaf(f, f, s2);
-                    }
-                    // the CPR lanes of a row are consecutive: segmented shift-down tree, the row total lands in the lane of chunk 0
-#pragma unroll
-                    for (int off = 1; off < CPR; off <<= 1) {
-                        const float t1 = __shfl_down(s1, off, 64), t2 = __shfl_down(s2, off, 64);
-                        if (ch + off < CPR) {
-                            s1 += t1;
-                            s2 += t2;
-                        }
-                    }
-                    if (valid && ch == 0)
-                        *reinterpret_cast<float2v*>(p.rowstats + ((long)(nw0 / W) * p.M + (mw0 + 16 * i + row)) * 2) = float2v{s1, s2};
-                }
             }
         }
         asm volatile("" ::: "memory");
@@ -476,9 +449,9 @@ __device__ unsigned long long mv_tl_buf[kTlBlocks * 8];
 #define MV_TL_FLUSH() ((void)0)
 #endif
 
-template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, int LNF = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
-    static_assert(LNF == 0 || MODE == MV_GEMM_LINEAR, "LayerNorm folding is a LINEAR-mode feature");
+    static_assert(!LNF || MODE == MV_GEMM_LINEAR, "LayerNorm folding is a LINEAR-mode feature");
     static_assert((WGN & (WGN - 1)) == 0, "the k-step deal of the row statistics needs a power-of-two WGN");
     constexpr int NW = WGM * WGN;
     // SCHED: 0 = two LDS stages behind __syncthreads (two blocks per CU overlap each other's stalls);
@@ -565,10 +538,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     // (l15, g) holds columns 16 j + 4 g .. + 3 of rows 16 i + l15 (GEGLU: the packed [value tile | gate tile] column order is the
     // accumulator's own).  The narrow epilogue adds them itself.
     float4v acc[TM][TN];
-    // LNF 1: per-lane partial row sums / sums of squares of the A rows 16 i + l15, formed in the K loop from the fragments;
-    // LNF 2: the producer of A left per-row partials behind (GemmArgs::ln_rowstats): part wn + WGN g of row 16 i + l15 is requested
-    //        with the bias loads below (ln_parts <= 4 WGN) and meets the others in the epilogue exactly like the in-loop partials
-    float ln_s1[LNF ? TM : 1], ln_s2[LNF ? TM : 1];
+    float ln_s1[LNF ? TM : 1], ln_s2[LNF ? TM : 1];  // LNF: per-lane partial row sums / sums of squares of the A rows 16 i + l15
 #pragma unroll
     for (int i = 0; i < (LNF ? TM : 1); ++i) ln_s1[i] = ln_s2[i] = 0.f;
     auto init_acc = [&]() __attribute__((always_inline)) {
@@ -596,18 +566,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
                         const half4v b = *reinterpret_cast<const half4v*>(rbp + 16 * j);
                         acc[i][j] += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
                     }
-                }
-            }
-        }
-        if constexpr (LNF == 2) {
-            const int part = wn + WGN * g;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * 16 * TM + 16 * i + l15;
-                if (part < p.ln_parts && m < Mi) {
-                    const float2v v = *reinterpret_cast<const float2v*>(p.ln_rowstats + ((long)part * p.M + m) * 2);
-                    ln_s1[i] = v[0];
-                    ln_s2[i] = v[1];
                 }
             }
         }
@@ -708,7 +666,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int swz = l15 & 7;
 
     auto mma_stage = [&](int st, int kt) __attribute__((always_inline)) {
-        if constexpr (LNF == 1) mma_tile_ln<TM, TN, WGN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g, ln_s1, ln_s2, 2 * kt, wn);
+        if constexpr (LNF) mma_tile_ln<TM, TN, WGN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g, ln_s1, ln_s2, 2 * kt, wn);
         else mma_tile<TM, TN>(sA + st * (BM * BK), sB + st * (BN * BK), acc, a_row0, b_row0, swz, g);
     };
     if constexpr (SCHED == 3) {
@@ -845,11 +803,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         half_t* stg = reinterpret_cast<half_t*>(smem);  // (the launcher sizes the dynamic LDS as max(operand stages, staging area))
         const bool full = m0 + BM <= Mi && n0 + BN <= p.N;
         if (p.geglu) {
-            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, false, LNF != 0>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
+            if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, false, LNF>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         } else if (p.residual) {
-            epilogue_staged<TM, TN, false, true, LNF != 0>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
+            epilogue_staged<TM, TN, false, true, LNF>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         } else {
-            epilogue_staged<TM, TN, false, false, LNF != 0>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
+            epilogue_staged<TM, TN, false, false, LNF>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         }
         MV_TL(4);
         MV_TL_FLUSH();
@@ -910,7 +868,7 @@ int mv_num_cus() {
     return n;
 }
 
-template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, int LNF = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
     constexpr int smem_ops = (SCHED == 3 ? 3 * 64 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
@@ -1002,19 +960,7 @@ inline int gemm_ln_cfg(int id) {
 int launch_ln_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
     switch (id) {
 #define MV_X(cid, tm, tn, wgm, wgn, sched) \
-    case cid: if constexpr (!(tm == 8 && tn == 5) && !(cid == 4 || cid == 5 || cid == 8)) return launch_cfg2s<MV_GEMM_LINEAR, tm, tn, wgm, wgn, sched, 1>(a, stream); else break;
-        MV_GEMM_CFGS(MV_X)
-#undef MV_X
-    }
-    mv_set_error("mv_gemm_f16: tile configuration %d has no LayerNorm-folded form", id);
-    return MV_ERR_INVALID;
-}
-
-// LayerNorm-folded launches fed by the producer's row statistics: no in-loop statistics, every catalogue entry
-int launch_ln2_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
-    switch (id) {
-#define MV_X(cid, tm, tn, wgm, wgn, sched) \
-    case cid: if constexpr (!(tm == 8 && tn == 5) && !(cid == 4 || cid == 5 || cid == 8)) return launch_cfg2s<MV_GEMM_LINEAR, tm, tn, wgm, wgn, sched, 2>(a, stream); else break;
+    case cid: if constexpr (!(tm == 8 && tn == 5) && !(cid == 4 || cid == 5 || cid == 8)) return launch_cfg2s<MV_GEMM_LINEAR, tm, tn, wgm, wgn, sched, true>(a, stream); else break;
         MV_GEMM_CFGS(MV_X)
 #undef MV_X
     }
@@ -1187,13 +1133,7 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     a.tiles_m = a.tiles_n = 0;
     a.nsplit = 1; a.kt_per_split = 0; a.ws = nullptr;
     a.ln_colsum = d->ln_colsum; a.ln_colbias = d->ln_colbias; a.ln_eps = d->ln_eps;
-    a.colstats = nullptr; a.rowstats = nullptr;  // (set by mv_gemm_f16 once the choice is known to support them)
-    a.ln_rowstats = nullptr; a.ln_parts = 0;
-    if (d->ln_rowstats) {
-        MV_REQUIRE(d->ln_colsum && d->ln_parts > 0 && (reinterpret_cast<uintptr_t>(d->ln_rowstats) & 7) == 0,
-                   "%s: ln_rowstats needs LayerNorm folding (ln_colsum), ln_parts > 0 and 8-byte alignment", who);
-        a.ln_rowstats = d->ln_rowstats; a.ln_parts = d->ln_parts;
-    }
+    a.colstats = nullptr;  // (set by mv_gemm_f16 once the choice is known to support it)
     if (d->ln_colsum || d->ln_colbias) {
         MV_REQUIRE(d->ln_colsum && d->ln_colbias && d->ln_eps > 0.f, "%s: LayerNorm folding needs ln_colsum, ln_colbias and ln_eps > 0", who);
         MV_REQUIRE(d->mode == MV_GEMM_LINEAR && !d->a2 && !d->bias && !d->rowbias && d->K % 64 == 0,
@@ -1228,34 +1168,10 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
 
 }  // namespace
 
-// choice of a descriptor: tile configuration, K slices and the LayerNorm mode (0 none, 1 statistics in the K loop, 2 from the
-// producer's row statistics).  Both folded modes run on the same tile (the epilogue's column vectors need the registers either
-// way: the plain projection's 256x320 choice spills with them); mode 2 needs the partials of a row dealt one per (wave column,
-// lane group): ln_parts <= 4 WGN, otherwise the launch forms the statistics itself.
-struct GemmPlan { GemmChoice ch; int ln_mode; };
-inline GemmPlan plan_launch(const mv_gemm_desc* d, GemmArgs2& b) {
-    const GemmChoice ch = choose_config(d->mode, b.g, d->cfg, d->splitk);
-    int mode = b.g.ln_colsum ? 1 : 0;
-    if (mode && b.g.ln_rowstats && b.g.ln_parts <= 4 * kGemmCfgs[ch.cfg].wgn) mode = 2;
-    if (mode != 2) {
-        b.g.ln_rowstats = nullptr;
-        b.g.ln_parts = 0;
-    }
-    return GemmPlan{ch, mode};
-}
-
-// output statistics a launch can emit: the staged (16-byte) epilogue of an unsplit, non-GEGLU launch
-inline bool stats_capable(const GemmArgs2& b, const GemmChoice& ch) { return b.wide && ch.nsplit == 1 && !b.g.geglu; }
-inline int colstats_rows_per_tile(const GemmArgs2& b, const GemmChoice& ch) { return stats_capable(b, ch) ? 16 * kGemmCfgs[ch.cfg].tm : 0; }
-inline int rowstats_parts(const GemmArgs2& b, const GemmChoice& ch) {
-    const int w = 16 * kGemmCfgs[ch.cfg].tn;
-    return stats_capable(b, ch) ? (b.g.N + w - 1) / w : 0;
-}
-
 extern "C" int64_t mv_gemm_workspace_bytes(const mv_gemm_desc* d) {
     GemmArgs2 b;
     if (gemm_prepare(d, b, "mv_gemm_workspace_bytes") != MV_OK) return -1;
-    const GemmChoice ch = plan_launch(d, b).ch;
+    const GemmChoice ch = choose_config(d->mode, b.g, d->cfg, d->splitk);
     return ch.nsplit > 1 ? (int64_t)ch.nsplit * b.g.M * b.g.N * 4 : 0;
 }
 
@@ -1263,44 +1179,37 @@ extern "C" int mv_gemm_choice(const mv_gemm_desc* d, int32_t* cfg, int32_t* nspl
     GemmArgs2 b;
     if (int rc = gemm_prepare(d, b, "mv_gemm_choice")) return rc;
     MV_REQUIRE(cfg && nsplit, "mv_gemm_choice: null output");
-    const GemmChoice ch = plan_launch(d, b).ch;
+    const GemmChoice ch = choose_config(d->mode, b.g, d->cfg, d->splitk);
     *cfg = ch.cfg;
     *nsplit = ch.nsplit;
     return MV_OK;
 }
 
-extern "C" int mv_gemm_stats_layout(const mv_gemm_desc* d, int32_t* col_rows_per_tile, int64_t* col_floats, int32_t* row_parts,
-                                    int64_t* row_floats) {
+// output statistics a launch can emit: the staged (16-byte) epilogue of an unsplit, non-GEGLU launch
+inline bool stats_capable(const GemmArgs2& b, const GemmChoice& ch) { return b.wide && ch.nsplit == 1 && !b.g.geglu; }
+inline int colstats_rows_per_tile(const GemmArgs2& b, const GemmChoice& ch) { return stats_capable(b, ch) ? 16 * kGemmCfgs[ch.cfg].tm : 0; }
+
+extern "C" int mv_gemm_stats_layout(const mv_gemm_desc* d, int32_t* col_rows_per_tile, int64_t* col_floats) {
     GemmArgs2 b;
     if (int rc = gemm_prepare(d, b, "mv_gemm_stats_layout")) return rc;
-    MV_REQUIRE(col_rows_per_tile && col_floats && row_parts && row_floats, "mv_gemm_stats_layout: null output");
-    const GemmPlan pl = plan_launch(d, b);
-    const int rpt = colstats_rows_per_tile(b, pl.ch), parts = rowstats_parts(b, pl.ch);
+    MV_REQUIRE(col_rows_per_tile && col_floats, "mv_gemm_stats_layout: null output");
+    const GemmChoice ch = choose_config(d->mode, b.g, d->cfg, d->splitk);
+    const int rpt = colstats_rows_per_tile(b, ch);
     *col_rows_per_tile = rpt;
     *col_floats = rpt ? ((b.g.M + rpt - 1) / rpt) * (int64_t)b.g.N * 2 : 0;
-    *row_parts = parts;
-    *row_floats = (int64_t)parts * b.g.M * 2;
     return MV_OK;
 }
 
 extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
     GemmArgs2 b;
     if (int rc = gemm_prepare(d, b, "mv_gemm_f16")) return rc;
-    const GemmPlan pl = plan_launch(d, b);
-    const GemmChoice ch = pl.ch;
+    const GemmChoice ch = choose_config(d->mode, b.g, d->cfg, d->splitk);
     if (d->colstats) {
         const int rpt = colstats_rows_per_tile(b, ch);
         MV_REQUIRE(rpt > 0, "mv_gemm_f16: this launch cannot emit column statistics (split K, GEGLU or narrow epilogue): ask mv_gemm_stats_layout first");
         MV_REQUIRE(d->colstats_floats >= ((b.g.M + rpt - 1) / rpt) * (int64_t)b.g.N * 2 && (reinterpret_cast<uintptr_t>(d->colstats) & 7) == 0,
                    "mv_gemm_f16: colstats needs %ld floats (8-byte aligned), got %ld", (long)(((b.g.M + rpt - 1) / rpt) * (int64_t)b.g.N * 2), (long)d->colstats_floats);
         b.g.colstats = d->colstats;
-    }
-    if (d->rowstats) {
-        const int parts = rowstats_parts(b, ch);
-        MV_REQUIRE(parts > 0, "mv_gemm_f16: this launch cannot emit row statistics (split K, GEGLU or narrow epilogue): ask mv_gemm_stats_layout first");
-        MV_REQUIRE(d->rowstats_floats >= (int64_t)parts * b.g.M * 2 && (reinterpret_cast<uintptr_t>(d->rowstats) & 7) == 0,
-                   "mv_gemm_f16: rowstats needs %ld floats (8-byte aligned), got %ld", (long)((int64_t)parts * b.g.M * 2), (long)d->rowstats_floats);
-        b.g.rowstats = d->rowstats;
     }
     if (ch.nsplit > 1) {
         const int64_t need = (int64_t)ch.nsplit * b.g.M * b.g.N * 4;
@@ -1311,9 +1220,9 @@ extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
         b.g.ws = (float*)d->workspace;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (pl.ln_mode) {
+    if (d->ln_colsum) {
         MV_REQUIRE(ch.nsplit == 1, "mv_gemm_f16: LayerNorm folding cannot be combined with a forced K split");
-        return pl.ln_mode == 2 ? launch_ln2_by_id(b, s, ch.cfg) : launch_ln_by_id(b, s, ch.cfg);
+        return launch_ln_by_id(b, s, ch.cfg);
     }
     if (d->mode == MV_GEMM_CONV3X3) return launch_by_id<MV_GEMM_CONV3X3>(b, s, ch.cfg);
     if (d->mode == MV_GEMM_TCONV3) return launch_by_id<MV_GEMM_TCONV3>(b, s, ch.cfg);

@@ -71,7 +71,7 @@ def ln_linear(mod: HipModule, key: str, x: torch.Tensor, norm: nn.LayerNorm, w_b
     w = mod.packed(key, w_builder)
     bias = mod.packed(key + "/bias", bias_builder) if bias_builder is not None else None
     M, K = x.shape
-    if ops.ln_fold_applies(M, w.shape[0], K, geglu, getattr(x, "_mv_rowstats", None) is not None):
+    if ops.ln_fold_applies(M, w.shape[0], K, geglu):
         wf, cs, cb = mod.packed(key + "/ln", lambda: ops.fold_layernorm(w, bias, w16(norm.weight), w16(norm.bias)))
         return ops.gemm(x, wf, ln=(cs, cb, norm.eps), geglu=geglu, residual=residual)
     h = ops.layernorm(x, w16(norm.weight), w16(norm.bias), norm.eps)
@@ -232,6 +232,5 @@ class IPAttention(HipModule):
     def w_kv_face(self) -> torch.Tensor:
         return self.packed("kv_face", lambda: torch.cat([lin_w(self.ip_adapter_face_to_k_ip), lin_w(self.ip_adapter_face_to_v_ip)], 0).contiguous())
 
-    def project_out(self, a: torch.Tensor, residual: torch.Tensor, rowstats: bool = True) -> torch.Tensor:
-        """to_out[0](a) + residual; ``rowstats``: a LayerNorm (norm2 / norm3) reads the result next"""
-        return ops.gemm(a, lin_w(self.to_out[0]), bias=lin_b(self.to_out[0]), residual=residual, rowstats=rowstats)
+    def project_out(self, a: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        return ops.gemm(a, lin_w(self.to_out[0]), bias=lin_b(self.to_out[0]), residual=residual)

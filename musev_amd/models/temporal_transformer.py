@@ -52,7 +52,7 @@ class TransformerTemporalModel(HipModule):
         fproj = ctx.proj_for(self)  # [B*T, C] column slice of the batched embedding projection
         if fproj is None:
             fproj = ops.gemm(ctx.femb_act, lin_w(self.frame_emb_proj), bias=lin_b(self.frame_emb_proj))
-        h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowbias=fproj, rows_per_group=geo.hw, rowstats=True)
+        h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowbias=fproj, rows_per_group=geo.hw)
         for blk in self.transformer_blocks:
             h = blk.hip_forward_temporal(h, geo)
         return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, alpha=self.alpha(), colstats=True)

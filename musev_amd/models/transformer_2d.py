@@ -41,7 +41,7 @@ class Transformer2DModel(HipModule):
     def hip_forward(self, x: torch.Tensor, ctx: Ctx, geo: Geo) -> torch.Tensor:
         h = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.n, geo.hw, eps=self.norm.eps, silu=False,
                           groups=self.norm.num_groups)
-        h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowstats=True)
+        h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in))
         for blk in self.transformer_blocks:
             h = blk.hip_forward_spatial(h, ctx, geo, self.reference_only, self.ip_adapter_cross_attn)
         return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, colstats=True)

@@ -55,33 +55,17 @@ COLSTATS: bool = os.environ.get("MUSEV_COLSTATS", "1") == "1"
 COLSTATS_HITS: int = 0   # GroupNorm calls served from producer statistics (tests / reports)
 
 
-# Producer-side LayerNorm statistics (MUSEV_ROWSTATS=0: the folded projections form the row statistics in their K loop, as in
-# round 3's first form): proj_in / to_out launches also emit per-row partial sums (mv_gemm_desc.rowstats, riding on the output tensor
-# object as `_mv_rowstats`), and the LayerNorm-folded projection behind them takes those (ln_rowstats) -- its K loop is then the
-# plain one, on the plain projection's tile.  With them the GEGLU projection folds its LayerNorm too (MUSEV_LN_GEGLU_FOLD=0: not).
-ROWSTATS: bool = os.environ.get("MUSEV_ROWSTATS", "1") == "1"
-LN_GEGLU_FOLD: bool = os.environ.get("MUSEV_LN_GEGLU_FOLD", "1") == "1"
-
-
-def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None,
-                 rowstats_for: Optional[torch.Tensor] = None) -> None:
+def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
-    want_cs = colstats_for is not None and COLSTATS
-    want_rs = rowstats_for is not None and ROWSTATS
-    if want_cs or want_rs:
-        rpt, nfl, parts, rfl = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
-        check(lib.mv_gemm_stats_layout(C.byref(d), C.byref(rpt), C.byref(nfl), C.byref(parts), C.byref(rfl)), what)
-        if want_cs and rpt.value > 0:
+    if colstats_for is not None and COLSTATS:
+        rpt, nfl = C.c_int32(), C.c_int64()
+        check(lib.mv_gemm_stats_layout(C.byref(d), C.byref(rpt), C.byref(nfl)), what)
+        if rpt.value > 0:
             cs = torch.empty(nfl.value, dtype=torch.float32, device=dev)
             d.colstats, d.colstats_floats = cs.data_ptr(), nfl.value
             colstats_for._mv_colstats = (cs, rpt.value)
             keep = keep + (cs,)
-        if want_rs and parts.value > 0:
-            rs = torch.empty(rfl.value, dtype=torch.float32, device=dev)
-            d.rowstats, d.rowstats_floats = rs.data_ptr(), rfl.value
-            rowstats_for._mv_rowstats = (rs, parts.value)
-            keep = keep + (rs,)
     need = lib.mv_gemm_workspace_bytes(C.byref(d))
     if need < 0:
         check(1, what)
@@ -174,11 +158,9 @@ def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_group: int = 0, residual=None, alpha=None, act: int = MV_ACT_NONE, geglu: bool = False,
          out: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None,
-         colstats: bool = False, rowstats: bool = False) -> torch.Tensor:
+         colstats: bool = False) -> torch.Tensor:
     """out = act(|alpha| * ([a | a2] @ w.T + bias + rowbias[row // rows_per_group])) + residual   (fp16, fp32 accumulate).
     ``colstats``: the output feeds a GroupNorm next -- emit its column statistics from the epilogue (see COLSTATS).
-    ``rowstats``: the output feeds a LayerNorm-folded projection next -- emit its row statistics (see ROWSTATS); with ``ln``, the
-    row statistics ``a``'s producer left on it are used instead of in-loop ones.
 
     ``w`` is [N, K] (torch Linear layout).  With ``geglu`` the rows of ``w`` / ``bias`` must be packed by
     :func:`pack_geglu` and the result has N/2 columns: value * gelu(gate).
@@ -215,12 +197,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if bias is not None or rowbias is not None or a2 is not None:
             raise ValueError("gemm(ln=...): the bias is part of colbias; no rowbias / second source")
         d.ln_colsum, d.ln_colbias, d.ln_eps = cs.data_ptr(), cb.data_ptr(), float(eps)
-        rs = getattr(a, "_mv_rowstats", None) if ROWSTATS else None
-        if rs is not None:
-            d.ln_rowstats, d.ln_parts = rs[0].data_ptr(), rs[1]
-            ln = ln + (rs[0],)
-    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha, ln), o if colstats and not geglu else None,
-                 o if rowstats and not geglu else None)
+    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha, ln), o if colstats and not geglu else None)
     return o
 
 
@@ -249,14 +226,15 @@ LN_FOLD: bool = os.environ.get("MUSEV_LN_FOLD", "1") == "1"
 _ln_fold_cache: dict = {}
 
 
-def ln_fold_applies(M: int, N: int, K: int, geglu: bool, have_rowstats: bool = False) -> bool:
+def ln_fold_applies(M: int, N: int, K: int, geglu: bool) -> bool:
     """whether ``gemm(..., ln=)`` is the better form of LayerNorm + projection for this problem: it is wherever the plain
     projection runs as ONE K slice (the folded kernel needs the whole row in one block's K loop); the small-M / long-K problems
     the library splits over K keep mv_layernorm_f16 + the split GEMM."""
-    if not LN_FOLD or K % 64 != 0 or (geglu and not (have_rowstats and ROWSTATS and LN_GEGLU_FOLD)):
-        # (GEGLU with in-loop statistics: every one of the N / BN column tiles re-forms them and the gate's epilogue already bounds
-        # that launch -- folded it measured 4-11 % SLOWER than LayerNorm + GEMM at every level, profiles/r03e_ln_fold_variants.log;
-        # the q / k / v projections gain 5-44 %.  With the producer's row statistics nothing is re-formed.)
+    if not LN_FOLD or K % 64 != 0 or geglu:
+        # (GEGLU: the gate's epilogue already bounds that launch -- folded it measured 4-11 % SLOWER than LayerNorm + GEMM at every
+        # level, profiles/r03e_ln_fold_variants.log; the q / k / v projections gain 5-44 %.  Row statistics emitted by the PRODUCER's
+        # epilogue instead of the in-loop ones -- which would also let the GEGLU launch fold -- measured +0.6 ms per step:
+        # profiles/r03o_rowstats_ab.log, commit 35438ca; not kept.)
         return False
     key = (M, N, K, bool(geglu))
     hit = _ln_fold_cache.get(key)

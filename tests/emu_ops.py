@@ -95,7 +95,7 @@ def _epilogue(acc, *, bias, rowbias, rows_per_group, residual, alpha, act, geglu
     return acc
 
 
-def ln_fold_applies(M, N, K, geglu, have_rowstats=False):
+def ln_fold_applies(M, N, K, geglu):
     """the emulation folds wherever the kernel could (K % 64 == 0): the wiring of the folded form is what these tests exercise"""
     return K % 64 == 0
 
@@ -109,7 +109,7 @@ def fold_layernorm(w, bias, gamma, beta):
 
 
 def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=None, act=MV_ACT_NONE,
-         geglu=False, out=None, ln=None, colstats=False, rowstats=False):
+         geglu=False, out=None, ln=None, colstats=False):
     _mat(a, "a")
     _mat(w, "w")
     _req(w.is_contiguous(), "w must be contiguous [N, K]")

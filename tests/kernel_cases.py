@@ -110,68 +110,6 @@ def case_gemm_ln(M=1000, N=960, K=320, seed=20, geglu=False, residual=False, off
     return _cmp(f"gemm LN-folded M{M} N{N} K{K} geglu={geglu} res={residual} offset={offset} cfg={cfg}", got, ref, atol=5e-3)
 
 
-def case_rowstats_ln(M=1000, C=320, N=960, Kp=320, geglu=False, residual=False, offset=0.0, pcfg=None, ccfg=None, seed=400,
-                     expect_from_rowstats=True, runs=1):
-    """producer-side LayerNorm statistics: a projection launched with ``rowstats=True`` leaves per-row partial {sum, sum of squares}
-    of the fp16 rows it stores (mv_gemm_desc.rowstats); the LayerNorm-folded projection that reads those rows next takes them
-    (ln_rowstats) instead of forming statistics in its K loop.  Checked: the partials against torch row sums of the stored output,
-    the consumer against nn.LayerNorm + Linear in fp32 on that output, and -- by poisoning the partials -- that the consumer
-    really read them (or, with more partials than its tile can deal, fell back to in-loop statistics)."""
-    from musev_amd import ops
-    x0 = _rand((M, Kp), seed) * 1.3
-    wpj = _rand((C, Kp), seed + 1, 1.0 / math.sqrt(Kp))
-    bpj = _rand((C,), seed + 2, 0.3) + offset
-    rpj = _rand((M, C), seed + 3)
-    old = ops.GEMM_CFG
-    try:
-        if pcfg is not None:
-            ops.GEMM_CFG = pcfg
-        x = ops.gemm(x0, wpj, bias=bpj, residual=rpj, rowstats=True)
-    finally:
-        ops.GEMM_CFG = old
-    rs = getattr(x, "_mv_rowstats", None)
-    if rs is None:
-        return {"name": f"rowstats pcfg{pcfg}", "ok": False, "max_abs_err": float("nan"), "detail": "producer emitted no row statistics"}
-    buf, parts = rs
-    xf = x.float()
-    tot = buf.reshape(parts, M, 2).sum(0)
-    results = [_cmp(f"rowstats pcfg{pcfg} parts{parts}", tot, torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=-1), atol=2e-3 * C * max(1.0, offset * offset), rtol=1e-4)]
-    gamma = 1.0 + 0.3 * _rand((C,), seed + 4)
-    beta = 0.2 * _rand((C,), seed + 5)
-    w = _rand((N, C), seed + 6, 1.0 / math.sqrt(C))
-    b = _rand((N,), seed + 7, 0.3)
-    res = _rand((M, N), seed + 8) if residual else None
-    ref = F.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
-    if geglu:
-        wq, bq = ops.pack_geglu(w, b)
-        wf, cs, cb = ops.fold_layernorm(wq, bq, gamma, beta)
-        ref = ref[:, :N // 2] * F.gelu(ref[:, N // 2:])
-    else:
-        wf, cs, cb = ops.fold_layernorm(w, b, gamma, beta)
-    if res is not None:
-        ref = ref.half().float() + res.float()
-    try:
-        if ccfg is not None:
-            ops.GEMM_CFG = ccfg
-        got = ops.gemm(x, wf, ln=(cs, cb, 1e-5), geglu=geglu, residual=res)
-        same = all(torch.equal(got, ops.gemm(x, wf, ln=(cs, cb, 1e-5), geglu=geglu, residual=res)) for _ in range(runs - 1))
-        keep = buf.clone()
-        buf.fill_(float("nan"))
-        poisoned = ops.gemm(x, wf, ln=(cs, cb, 1e-5), geglu=geglu, residual=res)
-        buf.copy_(keep)
-    finally:
-        ops.GEMM_CFG = old
-    results.append(_cmp(f"gemm LN from rowstats M{M} C{C} N{N} geglu={geglu} res={residual} pcfg={pcfg} ccfg={ccfg}", got, ref, atol=5e-3))
-    out = _all_ok(results)
-    out["from_rowstats"] = bool(torch.isnan(poisoned.float()).any())
-    out["runs_equal"] = same
-    out["ok"] = out["ok"] and same
-    if expect_from_rowstats is not None and out["from_rowstats"] != expect_from_rowstats:
-        out["ok"] = False
-        out["detail"] = f"consumer read the producer's row statistics: {out['from_rowstats']}, expected {expect_from_rowstats}"
-    return out
-
-
 def case_gemm_ln_repeatable(M=53248, N=320, K=320, runs=12, seed=30):
     """the folded launch must be bit-reproducible: round 3 found hipcc's packed-fp32 form of the row affine (v_pk_mul_f32 / v_pk_fma_f32
     with op_sel swizzles) returning sporadically wrong LOW results on lanes 48-63 of the MI355X -- one element of one 16 x 16 tile in
@@ -664,12 +602,6 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("gemm_ln_geglu", lambda: case_gemm_ln(M=500, N=2560, K=320, geglu=True, seed=22)),
     ("gemm_ln_large_mean", lambda: case_gemm_ln(M=300, N=640, K=1280, offset=12.0, seed=23)),
     ("gemm_ln_every_tile", lambda: _all_ok([case_gemm_ln(M=300, N=640, K=320, seed=24 + c, cfg=c) for c in range(19)])),
-    ("rowstats_ln", case_rowstats_ln),
-    ("rowstats_ln_geglu", lambda: case_rowstats_ln(M=500, C=320, N=2560, geglu=True, seed=410)),
-    ("rowstats_ln_residual_large_mean", lambda: case_rowstats_ln(M=777, C=640, N=640, residual=True, offset=6.0, seed=420)),
-    ("rowstats_ln_too_many_parts", lambda: case_rowstats_ln(M=300, C=1280, N=320, pcfg=3, ccfg=13, seed=430, expect_from_rowstats=False)),
-    ("rowstats_every_producer_tile", lambda: _all_ok([case_rowstats_ln(M=300, C=320, N=320, seed=440 + c, pcfg=c, expect_from_rowstats=None) for c in range(19)])),
-    ("rowstats_every_consumer_tile", lambda: _all_ok([case_rowstats_ln(M=300, C=320, N=640, seed=460 + c, ccfg=c, expect_from_rowstats=None) for c in range(19)])),
     ("conv3x3", case_conv3x3),
     ("conv3x3_two_src", lambda: case_conv3x3(c1=128, c2=64, cout=160, seed=21)),
     ("conv3x3_stride2", lambda: case_conv3x3(stride=2, seed=22)),
@@ -754,9 +686,6 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("gemm_l1_ln_qkv", lambda: case_gemm_ln(M=26624, N=1920, K=640, seed=243)),
     ("gemm_l0_ln_repeatable", case_gemm_ln_repeatable),
     ("gemm_l0_ln_repeatable_batch2", lambda: case_gemm_ln_repeatable(M=106496, runs=12, seed=31)),
-    ("rowstats_l0_qkv_half_repeatable", lambda: case_rowstats_ln(M=53248, C=320, N=960, seed=470, runs=8)),      # proj_in -> norm1 -> QKV
-    ("rowstats_l0_geglu_half", lambda: case_rowstats_ln(M=53248, C=320, N=2560, geglu=True, seed=471, runs=4)),  # to_out -> norm3 -> FF1
-    ("rowstats_l1_q_half", lambda: case_rowstats_ln(M=13312, C=640, N=640, Kp=640, seed=472, expect_from_rowstats=None)),
     ("colstats_l0_conv_half", lambda: case_colstats_groupnorm(n=13, h=64, w=64, cin=320, c=320, seed=480)),
     ("colstats_l0_conv_two_src_half", lambda: case_colstats_groupnorm(n=13, h=64, w=64, cin=320, c=640, c2=320, seed=481)),
     ("colstats_l0_tconv_half", lambda: case_colstats_groupnorm(kind="tconv", n=13, h=64, w=64, c=320, seed=482)),

@@ -25,10 +25,6 @@ CASES = {
     "gemm_ln": "kc.case_gemm_ln(M=150, N=320, K=320, residual=True)",
     "gemm_ln_geglu": "kc.case_gemm_ln(M=77, N=512, K=64, geglu=True, offset=5.0)",
     "gemm_ln_every_tile": "kc._all_ok([kc.case_gemm_ln(M=70, N=256, K=128, seed=24 + c, cfg=c) for c in range(19)])",
-    "rowstats_ln": "kc.case_rowstats_ln(M=150, C=128, N=192, Kp=64, residual=True)",
-    "rowstats_ln_geglu": "kc.case_rowstats_ln(M=77, C=64, N=256, Kp=64, geglu=True, offset=4.0)",
-    "rowstats_every_producer_tile": "kc._all_ok([kc.case_rowstats_ln(M=70, C=128, N=128, Kp=64, seed=440 + c, pcfg=c, expect_from_rowstats=None) for c in range(19)])",
-    "rowstats_every_consumer_tile": "kc._all_ok([kc.case_rowstats_ln(M=70, C=128, N=256, Kp=64, seed=460 + c, ccfg=c, expect_from_rowstats=None) for c in range(19)])",
     "colstats_conv": "kc.case_colstats_groupnorm(n=2, h=8, w=16, cin=64, c=64)",
     "colstats_conv_two_src_seam": "kc.case_colstats_groupnorm(n=2, h=8, w=16, cin=64, c=64, c2=32)",
     "colstats_tconv": "kc.case_colstats_groupnorm(kind='tconv', n=3, h=8, w=16, c=64)",
@@ -84,7 +80,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "rowstats_ln", "rowstats_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self",
+    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
