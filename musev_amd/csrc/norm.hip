@@ -383,60 +383,91 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnArgs a) {
 // ---- LayerNorm: one wave per group of R rows, up to 3 octets per lane and row (C <= 1536) ----
 // All R rows' loads are issued before any is reduced: with one row per wave a lane had a single 16-byte load in flight
 // (C = 320) and the kernel ran at half the HBM rate.  Per row the arithmetic (and its order) is unchanged.
+// Round 3: the R rows of a wave are reduced TOGETHER -- R independent xor trees step by step, gamma / beta requested with the rows
+// -- instead of one row after the other (each row's two dependent 6-step shuffle trees + its own gamma / beta loads made a wave's
+// 8 rows a ~25 us serial chain: 34 us per level-0 launch = 2.0 TB/s, against 15.6 us for GroupNorm's apply pass over the same
+// bytes; trace profiles/r03k).  Per row the arithmetic and its order are unchanged (bit-identical results).
 template <int NO, int kLnRows>  // kLnRows = R: 8 at C <= 512 (one octet per lane), else 4
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, half_t* y, int ldy, long rows, int c,
                                                         const half_t* gamma, const half_t* beta, float eps) {
+    constexpr int R = kLnRows;
     const int lane = threadIdx.x & 63;
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kLnRows;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
     const int oc = c >> 3;
-    half8v v[kLnRows][NO];
+    half8v v[R][NO], gm[NO], bt[NO];
 #pragma unroll
-    for (int q = 0; q < kLnRows; ++q) {
+    for (int q = 0; q < R; ++q) {
         const long row = row0 + q;
 #pragma unroll
         for (int k = 0; k < NO; ++k) {
             const int o = lane + 64 * k;
+            v[q][k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
             if (o < oc && row < rows) v[q][k] = *reinterpret_cast<const half8v*>(x + row * ldx + o * 8);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < kLnRows; ++q) {
-        const long row = row0 + q;
-        if (row >= rows) break;  // wave-uniform
+    for (int k = 0; k < NO; ++k) {
+        const int o = lane + 64 * k;
+        gm[k] = bt[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+        if (o < oc) {
+            gm[k] = *reinterpret_cast<const half8v*>(gamma + o * 8);
+            bt[k] = *reinterpret_cast<const half8v*>(beta + o * 8);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < NO; ++k) {
-            const int o = lane + 64 * k;
-            if (o < oc) {
+            if (lane + 64 * k < oc) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += (float)v[q][k][j];
             }
         }
-        const float mean = wave_sum(sum) / (float)c;
+        acc[q] = sum;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+    }
+    float mean[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        mean[q] = acc[q] / (float)c;
         float sq = 0.f;
 #pragma unroll
         for (int k = 0; k < NO; ++k) {
-            const int o = lane + 64 * k;
-            if (o < oc) {
+            if (lane + 64 * k < oc) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float d = (float)v[q][k][j] - mean;
+                    const float d = (float)v[q][k][j] - mean[q];
                     sq += d * d;
                 }
             }
         }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)c + eps);
+        acc[q] = sq;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const long row = row0 + q;
+        if (row >= rows) break;  // wave-uniform
+        const float rstd = rsqrtf(acc[q] / (float)c + eps);
 #pragma unroll
         for (int k = 0; k < NO; ++k) {
             const int o = lane + 64 * k;
             if (o < oc) {
-                half8v gm = *reinterpret_cast<const half8v*>(gamma + o * 8);
-                half8v bt = *reinterpret_cast<const half8v*>(beta + o * 8);
                 half8v w;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = (half_t)(((float)v[q][k][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+                for (int j = 0; j < 8; ++j) w[j] = (half_t)(((float)v[q][k][j] - mean[q]) * rstd * (float)gm[k][j] + (float)bt[k][j]);
                 *reinterpret_cast<half8v*>(y + row * ldy + o * 8) = w;
             }
         }

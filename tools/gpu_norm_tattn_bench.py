@@ -44,7 +44,7 @@ def main():
         us = timeit(lambda: ops.groupnorm(x, gm, bt, n, rows, eps=1e-5, silu=True))
         mb = n * rows * c * 2 * 3 / 1e6
         print(f"groupnorm n{n} rows{rows} c{c}: {us:.1f} us  {mb:.1f} MB (read twice + write)  {mb / us:.2f} TB/s", flush=True)
-    for rows, c in ((26 * 4096, 320), (26 * 1024, 640), (26 * 256, 1280), (26 * 64, 1280)):
+    for rows, c in ((26 * 4096, 320), (13 * 4096, 320), (26 * 1024, 640), (13 * 1024, 640), (26 * 256, 1280), (13 * 256, 1280), (26 * 64, 1280)):
         x = torch.randn(rows, c, device="cuda").half()
         gm, bt = torch.ones(c, device="cuda").half(), torch.zeros(c, device="cuda").half()
         us = timeit(lambda: ops.layernorm(x, gm, bt, 1e-5))
