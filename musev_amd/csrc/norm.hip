@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnArgs a) {
 // -- instead of one row after the other (each row's two dependent 6-step shuffle trees + its own gamma / beta loads made a wave's
 // 8 rows a ~25 us serial chain: 34 us per level-0 launch = 2.0 TB/s, against 15.6 us for GroupNorm's apply pass over the same
 // bytes; trace profiles/r03k).  Per row the arithmetic and its order are unchanged (bit-identical results).
-template <int NO, int kLnRows>  // kLnRows = R: 8 at C <= 512 (one octet per lane), else 4
+template <int NO, int kLnRows>  // kLnRows = R rows per wave (the launcher's choice: 2, or 1 at C > 1024)
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, half_t* y, int ldy, long rows, int c,
                                                         const half_t* gamma, const half_t* beta, float eps) {
     constexpr int R = kLnRows;
@@ -588,17 +588,48 @@ extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy
     MV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && rows > 0, "mv_layernorm_f16: bad leading dims / rows");
     hipStream_t s = (hipStream_t)stream;
     const int oc = c / 8;
-    // rows per wave (4 waves per block): at C = 320 only 40 of a wave's 64 lanes hold an octet, so a wave keeps 8 rows = 8 loads
-    // per lane in flight (4 rows left the kernel at ~4 TB/s on the 106 496 x 320 level-0 tensors)
-    const int rpw = oc <= 64 ? 8 : 4;
+    // rows per wave (4 waves per block).  Measured on the config-2 shapes, inputs cycled through > 256 MB of buffers and right behind
+    // a producer (tools/gpu_ln_bench.py, profiles/r03s_ln_variants.log): with the rows of a wave reduced together, FEWER rows per wave
+    // win -- more waves in flight beat more loads per lane -- 53 248 x 320: 8 rows 21.4 us, 4 rows 18.2, 2 rows 17.4, 1 row 19.0;
+    // 13 312 x 640: 4 rows 12.4, 2 rows 10.4; 3 328 x 1280: 4 rows 7.9, 2 rows 6.6, 1 row 6.1.
+    const int rpw = oc <= 128 ? 2 : 1;
     const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
     const half_t* xp = (const half_t*)x;
     half_t* yp = (half_t*)y;
     const half_t* g = (const half_t*)gamma;
     const half_t* b = (const half_t*)beta;
-    if (oc <= 64) hipLaunchKernelGGL((layernorm_kernel<1, 8>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
-    else if (oc <= 128) hipLaunchKernelGGL((layernorm_kernel<2, 4>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
-    else hipLaunchKernelGGL((layernorm_kernel<3, 4>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    if (oc <= 64) hipLaunchKernelGGL((layernorm_kernel<1, 2>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    else if (oc <= 128) hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<3, 1>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps);
     MV_CHECK_LAUNCH("mv_layernorm_f16");
     return MV_OK;
 }
+
+#ifdef MV_EXPERIMENT
+// experiment builds only (tools/gpu_ln_bench.py): the one-shot kernel with `rows_per_wave` in {1, 2, 4, 8, 16} (0 = the product's choice).
+// A persistent form (fixed grid of waves walking the row groups, next group's loads requested before the current one is reduced) was
+// measured as well (profiles/r03r_ln_variants.log: equal or slower than the one-shot form at every size) and is not kept.
+extern "C" int mv_layernorm_f16_var(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t c, const void* gamma,
+                                    const void* beta, float eps, int32_t rows_per_wave, void* stream) {
+    if (rows_per_wave == 0) return mv_layernorm_f16(x, ldx, y, ldy, rows, c, gamma, beta, eps, stream);
+    hipStream_t s = (hipStream_t)stream;
+    const int oc = c / 8, r = rows_per_wave;
+    MV_REQUIRE(oc <= 192 && (r == 1 || r == 2 || r == 4 || ((r == 8 || r == 16) && oc <= 64)), "mv_layernorm_f16_var: unsupported rows per wave %d at C=%d", r, c);
+    const half_t* xp = (const half_t*)x;
+    half_t* yp = (half_t*)y;
+    const half_t* g = (const half_t*)gamma;
+    const half_t* b = (const half_t*)beta;
+    const unsigned grid = (unsigned)((rows + 4 * r - 1) / (4 * r));
+#define MV_LN_LAUNCH(NO, R) hipLaunchKernelGGL((layernorm_kernel<NO, R>), dim3(grid), dim3(256), 0, s, xp, ldx, yp, ldy, (long)rows, c, g, b, eps)
+    if (oc <= 64) {
+        if (r == 1) MV_LN_LAUNCH(1, 1); else if (r == 2) MV_LN_LAUNCH(1, 2); else if (r == 4) MV_LN_LAUNCH(1, 4); else if (r == 8) MV_LN_LAUNCH(1, 8); else MV_LN_LAUNCH(1, 16);
+    } else if (oc <= 128) {
+        if (r == 1) MV_LN_LAUNCH(2, 1); else if (r == 2) MV_LN_LAUNCH(2, 2); else MV_LN_LAUNCH(2, 4);
+    } else {
+        if (r == 1) MV_LN_LAUNCH(3, 1); else if (r == 2) MV_LN_LAUNCH(3, 2); else MV_LN_LAUNCH(3, 4);
+    }
+#undef MV_LN_LAUNCH
+    MV_CHECK_LAUNCH("mv_layernorm_f16_var");
+    return MV_OK;
+}
+#endif
