@@ -714,4 +714,28 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("groupnorm_l0_tconv", lambda: case_groupnorm(n=2, rows=13 * 4096, c1=320, seed=231)),       # statistics over T*H*W
     ("layernorm_l0", lambda: case_layernorm(rows=106496, c=320, seed=232)),
     ("temporal_attention_l0", lambda: case_temporal_attention(b=2, t=13, hw=4096, d=40, seed=233)),
+    # ---- config 5 (768 x 768 -> 96 x 96 latents, 12 + 1 frames): M = 119 808 / 29 952 / 7 488 / 1 872 rows per CFG half (the batch-1
+    # launches of the two-stream step), 239 616 / 59 904 / 14 976 / 3 744 for both halves; the table is consulted by nearest M
+    ("cfg5_gemm_l0_out_res_half", lambda: case_gemm(M=119808, N=320, K=320, seed=500)),
+    ("cfg5_gemm_l0_out_res", lambda: case_gemm(M=239616, N=320, K=320, seed=501)),
+    ("cfg5_gemm_l0_ln_qkv_half", lambda: case_gemm_ln(M=119808, N=960, K=320, seed=502)),
+    ("cfg5_gemm_l0_geglu_half", lambda: case_gemm_geglu(M=119808, C=320)),
+    ("cfg5_gemm_l0_ff2_half", lambda: case_gemm(M=119808, N=320, K=1280, seed=503)),
+    ("cfg5_gemm_l1_out_res_half", lambda: case_gemm(M=29952, N=640, K=640, seed=504)),
+    ("cfg5_gemm_l1_out_res", lambda: case_gemm(M=59904, N=640, K=640, seed=505)),
+    ("cfg5_gemm_l2_qkv_half", lambda: case_gemm(M=7488, N=3840, K=1280, epilogue=False, seed=506)),
+    ("cfg5_gemm_l2_out_res", lambda: case_gemm(M=14976, N=1280, K=1280, seed=507)),
+    ("cfg5_gemm_l3_out_res_half", lambda: case_gemm(M=1872, N=1280, K=1280, seed=508)),
+    ("cfg5_gemm_l3_ff2", lambda: case_gemm(M=3744, N=1280, K=5120, seed=509)),
+    ("cfg5_conv_l0_half", lambda: case_conv3x3(n=13, h=96, w=96, c1=320, cout=320, seed=510)),
+    ("cfg5_conv_l1_two_src_half", lambda: case_conv3x3(n=13, h=48, w=48, c1=640, c2=640, cout=640, seed=511)),
+    ("cfg5_conv_l1_down_half", lambda: case_conv3x3(n=13, h=96, w=96, c1=320, cout=320, stride=2, seed=512)),
+    ("cfg5_conv_l3_half", lambda: case_conv3x3(n=13, h=12, w=12, c1=1280, cout=1280, seed=513)),
+    ("cfg5_tconv_l0_half", lambda: case_tconv3(b=1, t=13, hw=9216, c=320, seed=514)),
+    ("cfg5_tconv_l3", lambda: case_tconv3(b=2, t=13, hw=144, c=1280, seed=515)),
+    ("cfg5_colstats_conv_l0_half", lambda: case_colstats_groupnorm(n=13, h=96, w=96, cin=320, c=320, seed=516)),
+    ("cfg5_groupnorm_l0_tconv_half", lambda: case_groupnorm(n=1, rows=13 * 9216, c1=320, seed=517)),
+    ("cfg5_layernorm_l0_half", lambda: case_layernorm(rows=119808, c=320, seed=518)),
+    ("cfg5_attention_level0", lambda: case_attention_self(d=40, b=1, t=2, lq=9216, cond_idx=0, seed=519)),   # Lq 9216 x Lkv 18 432
+    ("cfg5_temporal_attention_l0_half", lambda: case_temporal_attention(b=1, t=13, hw=9216, d=40, seed=520)),
 ]
