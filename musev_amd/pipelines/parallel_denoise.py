@@ -74,7 +74,14 @@ class ParallelDenoiser:
         # the two CFG halves of a window as two batch-1 forwards on two HIP streams (+2.7 % frames/s at config 2,
         # profiles/r01j): MUSEV_HALF_STREAMS=0 restores the single batch-2 forward (per-kernel profiling)
         self.half_streams = os.environ.get("MUSEV_HALF_STREAMS", "1") == "1"
+        # A rank with an ODD number of units (24 units over 8 GPUs = 3) owns one two-half window and one lone half.  Run one after
+        # the other the lone batch-1 forward has the GPU to itself at ~0.65 of a pair's time; run CONCURRENTLY with the neighbouring
+        # pair (its graph replayed on a third stream) three half-forwards share the GPU like a pair and a half.  Used from the second
+        # executed step of a call on (every signature captured by then), with graphs, without a ControlNet (whose per-length static
+        # control-frame buffer is shared by the groups).  MUSEV_ODD_UNIT_LANE=0 keeps the groups one after the other.
+        self.odd_unit_lane = os.environ.get("MUSEV_ODD_UNIT_LANE", "1") == "1"
         self._side = {}
+        self._lane = {}
         self._t_bufs: Dict[str, torch.Tensor] = {}
         self._warm: Dict[tuple, bool] = {}  # signatures whose lazily built caches (packed weights, K/V projections) are filled
         self.scheduler = scheduler or DDIMScheduler()
@@ -222,6 +229,7 @@ class ParallelDenoiser:
             # align_repeat_tensor_single_dim(prompt_embeds, (b t)) (:1242-1246): one row of text per frame, per CFG half
             text_rep_by_len = {n: embeds.repeat_interleave(n_cond + n, dim=0).contiguous() for n in sub_idx_by_len}
 
+        steps_done = 0  # steps executed by THIS call (the first one captures / warms every signature: groups one after the other)
         for step, t in enumerate(timesteps):
             if max_steps is not None and step >= max_steps:
                 break
@@ -236,19 +244,26 @@ class ParallelDenoiser:
             lat_in = lat if in_scale == 1.0 else lat * in_scale
             slot = 0
             works = []
-            cn, cn_on = None, False
+            cn_on = False
             if controlnet is not None:
                 cond_scale = float(controlnet_conditioning_scale) * cn_keep[step]   # :1229-1236
                 cn_on = cond_scale != 0.0  # a zero scale makes every residual zero: adding them is a no-op, skip the network
-            for wi, hs in my_groups:
+
+            def run_group(wi, hs):
                 wl = len(wins[wi])
                 tw = n_cond + wl
                 x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs))
+                cn_ = None
                 if controlnet is not None and cn_on:
                     ctrl_bufs[wl].copy_(ctrl_frames[wi])
-                    cn = (controlnet, ctrl_bufs[wl], text_rep_by_len[wl], cond_scale, bool(guess_mode))
-                eps = self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx_by_len[wl], vis_idx, motion_speed,
-                                      unet_kwargs, cn)
+                    cn_ = (controlnet, ctrl_bufs[wl], text_rep_by_len[wl], cond_scale, bool(guess_mode))
+                return self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx_by_len[wl], vis_idx, motion_speed,
+                                       unet_kwargs, cn_)
+
+            def consume(wi, hs, eps):
+                nonlocal slot
+                wl = len(wins[wi])
+                tw = n_cond + wl
                 if not exchange:
                     for k, hf in enumerate(hs):
                         ops.window_scatter_add(eps[k * tw * hw:(k + 1) * tw * hw], idx_dev[wi], n_cond, 1, hf, eps_acc, counter, False)
@@ -260,6 +275,31 @@ class ParallelDenoiser:
                         works.append(torch.distributed.all_gather_into_tensor(recv[slot].view(-1), send[slot].view(-1), group=group,
                                                                               async_op=True))
                         slot += 1
+
+            lanes_ok = (self.odd_unit_lane and self.use_graphs and lat.is_cuda and controlnet is None and halves == 2 and
+                        steps_done > 0 and hasattr(torch.cuda, "CUDAGraph"))
+            gi = 0
+            while gi < len(my_groups):
+                wi, hs = my_groups[gi]
+                nxt = my_groups[gi + 1] if gi + 1 < len(my_groups) else None
+                if lanes_ok and nxt is not None and {len(hs), len(nxt[1])} == {1, 2}:
+                    # a pair and a lone half next to each other: the lone forward on the lane stream, concurrently with the pair
+                    lone, pair = ((wi, hs), nxt) if len(hs) == 1 else (nxt, (wi, hs))
+                    main = torch.cuda.current_stream()
+                    lane = self._lane_stream(dev)
+                    lane.wait_stream(main)
+                    with torch.cuda.stream(lane):
+                        eps_lone = run_group(*lone)
+                    eps_pair = run_group(*pair)
+                    main.wait_stream(lane)
+                    eps_lone.record_stream(main)
+                    for g_, e_ in (((wi, hs), eps_lone if len(hs) == 1 else eps_pair), (nxt, eps_pair if len(hs) == 1 else eps_lone)):
+                        consume(g_[0], g_[1], e_)
+                    gi += 2
+                    continue
+                consume(wi, hs, run_group(wi, hs))
+                gi += 1
+            steps_done += 1
             if exchange:
                 for k in range(slot, max_units):  # a rank with fewer units still takes part in every slot's collective
                     works.append(torch.distributed.all_gather_into_tensor(recv[k].view(-1), send[k].view(-1), group=group, async_op=True))
@@ -357,6 +397,12 @@ class ParallelDenoiser:
     def graph_replays(self) -> int:
         """hipGraph replays issued so far by this object's captured forwards (bench.py asserts the timed steps were replays)"""
         return sum(g.replays for g in self._graphs.values())
+
+    def _lane_stream(self, dev):
+        key = str(dev)
+        if key not in self._lane:
+            self._lane[key] = torch.cuda.Stream(device=dev)
+        return self._lane[key]
 
     def _side_stream(self, dev):
         key = str(dev)

@@ -309,6 +309,39 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden():
     assert max(forced) < 1e-2, forced
 
 
+def test_odd_unit_lane_is_bit_identical_to_running_the_groups_in_turn(monkeypatch):
+    """a rank with three units (24 units over 8 GPUs) replays the lone half's graph on a third stream concurrently with the neighbouring
+    pair from the second step on (ParallelDenoiser.odd_unit_lane): the same kernels on the same inputs, so the latents must be
+    bit-identical to the groups run one after the other -- for a (pair, lone) and a (lone, pair) rank, over 4 steps."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines import parallel_denoise as pd
+    cfg = unet3d.flavour_config("musev", **ARCH)
+    sd = unet3d.calibrate_as_denoiser(unet3d.init_state_dict(cfg, 3), cfg)
+    g = torch.Generator().manual_seed(13)
+    T = 14
+    latents = torch.randn(1, 4, T, 8, 8, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, 8, 8, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    dev = torch.device("cuda", 0)
+    unet = load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **ARCH).to(dev)
+    keep = []
+    for units in ([pd.Unit(0, 0), pd.Unit(0, 1), pd.Unit(1, 0)], [pd.Unit(0, 1), pd.Unit(1, 0), pd.Unit(1, 1)]):
+        monkeypatch.setattr(pd, "shard_units", lambda n, hv, world, units=units: [units])
+        outs = {}
+        for lane in (False, True):
+            den = pd.ParallelDenoiser(unet, context_frames=6, context_overlap=2)
+            den.odd_unit_lane = lane
+            keep.append(den)
+            outs[lane] = den(latents.to(dev), prompt.to(dev), num_inference_steps=20, max_steps=4, guidance_scale=3.5,
+                             condition_latents=cond.to(dev), motion_speed=8.0)
+            torch.cuda.synchronize()
+            assert den.graph_replays() >= 6
+        assert torch.isfinite(outs[True]).all()
+        assert torch.equal(outs[False], outs[True]), (outs[False].float() - outs[True].float()).abs().max().item()
+
+
 def test_uniform_v2_unequal_windows_on_the_gpu():
     """`uniform_v2` (the CLI default schedule): T = 16, window 6, overlap 2 -> windows of 6, 6, 6 and a short last one; HIP loop
     (one captured graph per window length) against the oracle loop over the first 2 steps"""
