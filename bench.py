@@ -423,6 +423,24 @@ def main():
             ops.replay_gemms_two_streams(ha, hb, 1)
             ms2 = ops.replay_gemms_two_streams(ha, hb, reps) / reps
             two_stream = {"family_ms_per_step": ms2, "tflops": fam_flops / (ms2 * 1e-3) / 1e12, "frac": fam_flops / (ms2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS}
+        # and the same step as ONE batch-2 forward per window on one stream (MUSEV_HALF_STREAMS=0): the launches round 2's roofline
+        # timed (its timed path was the two-stream one as well, but the per-launch pass ran the batch-2 forward) -- info, for
+        # round-over-round comparison
+        batch2 = None
+        if den.half_streams and world == 1:
+            ops.GEMM_RECORD = []
+            den.use_graphs, den.half_streams = False, False
+            sync_all()
+            run_steps(1)
+            sync_all()
+            rec_b2, ops.GEMM_RECORD = ops.GEMM_RECORD, None
+            den.use_graphs, den.half_streams = True, True
+            ops.replay_gemms(rec_b2, 1)
+            ms_b2 = ops.replay_gemms(rec_b2, reps) / reps
+            fl_b2 = sum(2.0 * d.M * d.N * d.K for d, _k, _b in rec_b2)
+            batch2 = {"family_ms_per_step": ms_b2, "tflops": fl_b2 / (ms_b2 * 1e-3) / 1e12, "frac": fl_b2 / (ms_b2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                      "launches_per_step": len(rec_b2)}
+            del rec_b2
         del rec_all
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {
@@ -439,6 +457,7 @@ def main():
             "family_ms_per_step": fam_ms,
             "by_mode": by_mode,
             "two_streams": two_stream,
+            "batch2_one_stream": batch2,
             "whole_step": {"algorithmic_tflop_per_rank_step": per_rank_flops / 1e12,
                            "achieved_tflops_per_gpu": per_rank_flops / (ms_per_step * 1e-3) / 1e12,
                            "frac_of_mfma_peak": per_rank_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
