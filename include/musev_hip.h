@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 5
+#define MV_ABI_VERSION 6
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -164,6 +164,11 @@ typedef struct mv_attn_seg {
     int32_t ldk, ldv;
     int32_t len;       /* keys per batch item                                                          */
     int32_t div, mul, add;
+    /* softmax groups (d = 40 / 80): a segment with new_group = 1 starts its own softmax; the output is                */
+    /*   sum_g group_scale_g * softmax_g(Q K_g^T) V_g  -- the text cross-attention + ip_adapter_scale * image-prompt  */
+    /*   attention (+ FaceID) of attention_processor.py:258-300 in ONE launch.  All zero = one group of weight 1.      */
+    int32_t new_group; /* segment 0: 1 = group_scale applies to the first group (else 1.0)                      */
+    float group_scale;
 } mv_attn_seg;
 
 typedef struct mv_attn_desc {

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "l
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 5
+MV_ABI_VERSION = 6
 
 
 class MuseVHipError(RuntimeError):
@@ -44,6 +44,7 @@ class AttnSeg(C.Structure):
         ("k", C.c_void_p), ("v", C.c_void_p),
         ("ldk", C.c_int32), ("ldv", C.c_int32), ("len", C.c_int32),
         ("div", C.c_int32), ("mul", C.c_int32), ("add", C.c_int32),
+        ("new_group", C.c_int32), ("group_scale", C.c_float),
     ]
 
 

@@ -28,6 +28,8 @@ struct SegArgs {
     const half_t* k;
     const half_t* v;
     int ldk, ldv, len, div, mul, add;
+    int new_group;   // 1: this segment starts a new softmax group (its own normalisation); segment 0 always starts one
+    float gscale;    // weight of the group this segment starts in the output sum (read for group starts only)
 };
 
 struct AttnArgs {
@@ -447,8 +449,12 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
 //          the hardware's lane groups (80-byte rows: 2-way on both).
 //   4  (d = 40) register budget of four waves per SIMD (128 VGPRs) instead of three
 //   8  eight waves = 256 query rows per block share every K / V tile (half the L2 -> LDS traffic and half the barriers per MFMA)
+//  16  softmax GROUPS: a segment flagged new_group closes the running softmax -- O / row sum, times the group's weight, is added to
+//      a second accumulator -- and starts a fresh one: out = sum_g gscale_g * softmax_g(Q K_g^T) V_g in ONE launch (text
+//      cross-attention + IP-Adapter (+ FaceID) image-prompt attention: Q read once, the output written once, no read-modify-write)
 template <int D, int VAR>
 struct Attn3Cfg {
+    static constexpr bool GRP = (VAR & 16) != 0;
     static constexpr bool TAIL16 = (VAR & 1) != 0 && (D % 32) != 0 && (D % 32) <= 16;
     static constexpr bool PADR = (VAR & 2) != 0 && D == 40;
     static constexpr int CH = D / 8;                   // 16-byte chunks of data per row
@@ -543,6 +549,21 @@ void attn3_kernel(const AttnArgs p) {
         for (int dt = 0; dt < C::NDT; ++dt) acc_o[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
     }
     float m_ref[C::QT] = {0.f, 0.f};  // reference of the exponents (log2 domain)
+    // GRP: the finished groups' weighted outputs; a group is closed by dividing its O by its row sum (see the epilogue)
+    float4v acc_t[C::GRP ? C::QT : 1][C::GRP ? C::NDT : 1];
+    float gscale = p.seg[0].gscale;
+    if constexpr (C::GRP) {
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt) acc_t[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+    auto row_sum = [&](int qt) __attribute__((always_inline)) -> float {
+        // row 0 of the ones-fragment product (lane group g = 0, register 0), or output row D of P.V (ONES: d-tile D / 16, row
+        // D % 16 = 4 g' + r' -> lane group g', register r')
+        if constexpr (C::ONES) return __shfl(acc_o[qt][D / 16][(D % 16) % 4], 16 * ((D % 16) / 4) + l15, 64);
+        else return __shfl(acc_l[qt][0], l15, 64);
+    };
 
     __syncthreads();  // the zero fill (and the ones column) is complete before the first DMA may land
     bool first = true;    // no tile processed yet (the first tile sets the reference unconditionally)
@@ -551,6 +572,23 @@ void attn3_kernel(const AttnArgs p) {
     // lanes' chunk offsets -- is computed here once instead of per tile) ----
 #pragma unroll 1
     for (int seg = 0; seg < p.nseg; ++seg) {
+        if constexpr (C::GRP) {
+            if (seg > 0 && ATTN_SEG_FIELD(p, seg, new_group)) {  // block-uniform: close the running group, start a fresh softmax
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) {
+                    const float w = gscale / row_sum(qt);
+#pragma unroll
+                    for (int dt = 0; dt < C::NDT; ++dt) {
+                        acc_t[qt][dt] += acc_o[qt][dt] * w;
+                        acc_o[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
+                    }
+                    acc_l[qt] = float4v{0.f, 0.f, 0.f, 0.f};
+                    m_ref[qt] = 0.f;
+                }
+                first = true;
+                gscale = ATTN_SEG_FIELD(p, seg, gscale);
+            }
+        }
         const int len = ATTN_SEG_FIELD(p, seg, len);
         const int ldk = ATTN_SEG_FIELD(p, seg, ldk), ldv = ATTN_SEG_FIELD(p, seg, ldv);
         const int sdiv = ATTN_SEG_FIELD(p, seg, div), smul = ATTN_SEG_FIELD(p, seg, mul), sadd = ATTN_SEG_FIELD(p, seg, add);
@@ -738,12 +776,7 @@ void attn3_kernel(const AttnArgs p) {
     // ---- epilogue: O^T[d = 16 dt + 4 g + r][q = l15] / row sum ----
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
-        // row sums: row 0 of the ones-fragment product (lane group g = 0, register 0), or output row D of P.V (ONES: d-tile D / 16,
-        // row D % 16 = 4 g' + r' -> lane group g', register r')
-        float l;
-        if constexpr (C::ONES) l = __shfl(acc_o[qt][D / 16][(D % 16) % 4], 16 * ((D % 16) / 4) + l15, 64);
-        else l = __shfl(acc_l[qt][0], l15, 64);
-        const float inv = 1.0f / l;
+        const float inv = (C::GRP ? gscale : 1.0f) / row_sum(qt);
         const int qr = q0 + 16 * qt + l15;
         if (qr >= p.lq) continue;
         half_t* orow = p.out + ((long)n * p.lq + qr) * p.ldo + h * D;
@@ -752,6 +785,7 @@ void attn3_kernel(const AttnArgs p) {
             const int dcol = 16 * dt + 4 * g;
             if (dcol >= D) continue;
             float4v o = acc_o[qt][dt] * inv;
+            if constexpr (C::GRP) o += acc_t[qt][dt];
             if (p.accumulate) {
                 half4v prev = *reinterpret_cast<const half4v*>(orow + dcol);
                 o = float4v{(float)prev[0], (float)prev[1], (float)prev[2], (float)prev[3]} + o * p.out_scale;
@@ -1022,16 +1056,20 @@ int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) 
     a.nb = d->nb; a.lq = d->lq; a.heads = d->heads;
     a.scale_log2e = d->scale * 1.4426950408889634f;
     a.nseg = d->nseg; a.accumulate = d->accumulate; a.out_scale = d->out_scale;
+    bool grouped = false;
     for (int s = 0; s < MV_ATTN_MAX_SEG; ++s) {
         if (s < d->nseg) {
             const mv_attn_seg& g = d->seg[s];
             MV_REQUIRE(g.k && g.v && g.len > 0 && g.div > 0, "mv_attention_f16: bad segment %d", s);
             MV_REQUIRE(g.ldk % 8 == 0 && g.ldv % 8 == 0, "mv_attention_f16: segment %d ldk/ldv %% 8", s);
-            a.seg[s] = SegArgs{(const half_t*)g.k, (const half_t*)g.v, g.ldk, g.ldv, g.len, g.div, g.mul, g.add};
+            a.seg[s] = SegArgs{(const half_t*)g.k, (const half_t*)g.v, g.ldk, g.ldv, g.len, g.div, g.mul, g.add, (s > 0 && g.new_group) ? 1 : 0,
+                               g.new_group ? g.group_scale : 1.0f};
+            grouped = grouped || (s > 0 && g.new_group) || (s == 0 && g.new_group && g.group_scale != 1.0f);
         } else {
-            a.seg[s] = SegArgs{nullptr, nullptr, 0, 0, 0, 1, 0, 0};
+            a.seg[s] = SegArgs{nullptr, nullptr, 0, 0, 0, 1, 0, 0, 0, 1.0f};
         }
     }
+    MV_REQUIRE(!grouped || d->d == 40 || d->d == 80, "mv_attention_f16: softmax groups are built for head dims 40 and 80 (d=%d: one launch per group with accumulate)", d->d);
     const int qb = d->d > 80 ? 64 : 128;  // AttnCfg<D>::QB
     dim3 grid((unsigned)((d->lq + qb - 1) / qb), (unsigned)d->heads, (unsigned)d->nb);
     hipStream_t s = (hipStream_t)stream;
@@ -1045,7 +1083,10 @@ int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) 
                        "mv_attention_f16: segment %d spans 2 GiB or more per key batch", sg);
         const dim3 grid1((unsigned)(((d->lq + 127) / 128) * d->heads * d->nb));  // 1-D: the kernel maps ids to (q block, head, frame)
         int rc = MV_OK;
-        if (d->d == 40) {
+        if (grouped) {
+            // (three waves per SIMD at d = 40: the second accumulator does not fit the 128-register budget of variant bit 4)
+            rc = d->d == 40 ? launch_attn3<40, 27>(a, grid1, s) : launch_attn3<80, 24>(a, grid1, s);
+        } else if (d->d == 40) {
 #ifdef MV_EXPERIMENT
             if (var40 == 0) rc = launch_attn3<40, 0>(a, grid1, s);
             else if (var40 == 1) rc = launch_attn3<40, 1>(a, grid1, s);

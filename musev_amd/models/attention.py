@@ -72,16 +72,23 @@ class BasicTransformerBlock(HipModule):
         cache = a2._cache()
         # K/V of the prompt: constant over the denoise loop -> projected once per (prompt tensor, weights)
         tkv = cache.setdefault("text_kv", SourceCache()).get(ctx.text_src, lambda _s: ops.gemm(ctx.text, a2.w_kv()))
-        att = ops.attention(q, [(tkv[:, :c], tkv[:, c:], ctx.text_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale)
+        # text cross-attention + ip_adapter_scale * image-prompt attention (+ face_scale * FaceID attention, attention_processor.py:
+        # 258-300, 308-338): every term its own softmax of the same queries.  Head dims 40 / 80: ONE launch with softmax groups (the
+        # queries read once, the output written once); d = 160: one launch per term, accumulated into the output.
+        terms = [((tkv[:, :c], tkv[:, c:], ctx.text_len, geo.t, 1, 0), 1.0)]
         if use_ip and a2.cross_attn_temporal_cond and ctx.clip is not None and ctx.ip_scale > 0:
             ikv = cache.setdefault("clip_kv", SourceCache()).get(ctx.clip_src, lambda _s: ops.gemm(ctx.clip, a2.w_kv_ip()))
-            ops.attention(q, [(ikv[:, :c], ikv[:, c:], ctx.clip_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale,
-                          out=att, accumulate=True, out_scale=ctx.ip_scale)
+            terms.append(((ikv[:, :c], ikv[:, c:], ctx.clip_len, geo.t, 1, 0), float(ctx.ip_scale)))
         if a2.need_t2i_ip_adapter_face and ctx.face is not None and ctx.face_scale > 0:
-            # IP-Adapter-FaceID (attention_processor.py:308-338): a third attention of the same queries over the face tokens
             fkv = cache.setdefault("face_kv", SourceCache()).get(ctx.face_src, lambda _s: ops.gemm(ctx.face, a2.w_kv_face()))
-            ops.attention(q, [(fkv[:, :c], fkv[:, c:], ctx.face_len, geo.t, 1, 0)], geo.n, geo.hw, h, d, a2.scale,
-                          out=att, accumulate=True, out_scale=ctx.face_scale)
+            terms.append(((fkv[:, :c], fkv[:, c:], ctx.face_len, geo.t, 1, 0), float(ctx.face_scale)))
+        if len(terms) == 1 or (d in (40, 80) and getattr(ops, "ATTN_GROUPS", True)):
+            att = ops.attention(q, [sg for sg, _w in terms], geo.n, geo.hw, h, d, a2.scale,
+                                group_scales=[w for _sg, w in terms] if len(terms) > 1 else None)
+        else:
+            att = ops.attention(q, [terms[0][0]], geo.n, geo.hw, h, d, a2.scale)
+            for sg, w in terms[1:]:
+                ops.attention(q, [sg], geo.n, geo.hw, h, d, a2.scale, out=att, accumulate=True, out_scale=w)
         x = a2.project_out(att, residual=x)
         return self.ff.hip_forward(x, residual=x, norm=self.norm3)
 

@@ -376,12 +376,18 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 Seg = Tuple[torch.Tensor, torch.Tensor, int, int, int, int]  # (k, v, len, div, mul, add)
+# MUSEV_ATTN_GROUPS=0 (A/B runs): the image-prompt terms of the cross-attention as separate accumulate launches, as in round 2
+ATTN_GROUPS: bool = os.environ.get("MUSEV_ATTN_GROUPS", "1") == "1"
 
 
 def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int, d: int, scale: float, *,
-              out: Optional[torch.Tensor] = None, accumulate: bool = False, out_scale: float = 1.0) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, accumulate: bool = False, out_scale: float = 1.0,
+              group_scales: Optional[Sequence[Optional[float]]] = None) -> torch.Tensor:
     """Multi-segment softmax attention.  q = [nb*lq, heads*d]; each segment (k, v, len, div, mul, add) holds 2-D
-    key/value matrices whose row (kvb*len + j) is key j of key batch kvb = (n // div) * mul + add for query batch n."""
+    key/value matrices whose row (kvb*len + j) is key j of key batch kvb = (n // div) * mul + add for query batch n.
+    ``group_scales`` (one entry per segment, head dims 40 / 80): a float starts a new softmax GROUP of that weight at the segment,
+    ``None`` continues the group of the segment before: out = sum_g scale_g * softmax_g(q K_g^T) V_g in one launch -- the text
+    cross-attention plus ip_adapter_scale * the image-prompt attention (attention_processor.py:258-300).  Default: one group."""
     q = _mat(q, "q")
     if q.shape[0] != nb * lq or q.shape[1] != heads * d:
         raise ValueError("attention: q shape mismatch")
@@ -401,6 +407,11 @@ def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int
             raise ValueError(f"attention: segment {i} does not cover key batch {max_kvb}")
         s = ds.seg[i]
         s.k, s.v, s.ldk, s.ldv, s.len, s.div, s.mul, s.add = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), ln, div, mul, add_
+        if group_scales is not None:
+            if len(group_scales) != len(segs) or group_scales[0] is None:
+                raise ValueError("attention: group_scales needs one entry per segment, the first one a weight")
+            if group_scales[i] is not None:
+                s.new_group, s.group_scale = 1, float(group_scales[i])
     check(_lib.load().mv_attention_f16(C.byref(ds), _stream()), "mv_attention_f16")
     return o
 

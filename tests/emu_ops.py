@@ -227,7 +227,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return _store(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps), out)
 
 
-def attention(q, segs, nb, lq, heads, d, scale, *, out=None, accumulate=False, out_scale=1.0):
+def attention(q, segs, nb, lq, heads, d, scale, *, out=None, accumulate=False, out_scale=1.0, group_scales=None):
     c = heads * d
     _mat(q, "q")
     _req(tuple(q.shape) == (nb * lq, c) and 1 <= len(segs) <= 4, "attention: q shape / segment count")
@@ -246,11 +246,18 @@ def attention(q, segs, nb, lq, heads, d, scale, *, out=None, accumulate=False, o
         nkb = k.shape[0] // ln
         ks.append(k.float()[: nkb * ln].reshape(nkb, ln, c)[kvb])
         vs.append(v.float()[: nkb * ln].reshape(nkb, ln, c)[kvb])
-    kk, vv = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
     qh = q.float().reshape(nb, lq, heads, d).transpose(1, 2)
-    kh = kk.reshape(nb, -1, heads, d).transpose(1, 2)
-    vh = vv.reshape(nb, -1, heads, d).transpose(1, 2)
-    o = (torch.softmax((qh @ kh.transpose(-1, -2)) * scale, dim=-1) @ vh).transpose(1, 2).reshape(nb * lq, c)
+    if group_scales is None:
+        group_scales = [1.0] + [None] * (len(segs) - 1)
+    _req(len(group_scales) == len(segs) and group_scales[0] is not None, "attention: group_scales: one entry per segment, the first a weight")
+    _req(all(g is None for g in group_scales[1:]) or d in (40, 80) or not STRICT_WIDTHS, "attention: softmax groups need head dim 40 / 80")
+    starts = [i for i, g in enumerate(group_scales) if g is not None] + [len(segs)]
+    o = 0.0
+    for a_, b_ in zip(starts[:-1], starts[1:]):
+        kk, vv = torch.cat(ks[a_:b_], dim=1), torch.cat(vs[a_:b_], dim=1)
+        kh = kk.reshape(nb, -1, heads, d).transpose(1, 2)
+        vh = vv.reshape(nb, -1, heads, d).transpose(1, 2)
+        o = o + float(group_scales[a_]) * (torch.softmax((qh @ kh.transpose(-1, -2)) * scale, dim=-1) @ vh).transpose(1, 2).reshape(nb * lq, c)
     if accumulate:
         o = out.float() + out_scale * o
     return _store(o, out)

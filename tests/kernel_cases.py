@@ -336,6 +336,37 @@ def case_attention_cross(d=80, nb=6, t=3, lq=130, lk=77, seed=70, with_ip=True):
     return _cmp(f"attention cross d{d} nb{nb} lq{lq} lk{lk} ip{int(with_ip)}", got, ref, atol=3e-3)
 
 
+def case_attention_groups(d=40, nb=6, t=3, lq=130, lk=77, seed=75, spike=False):
+    """text cross attention + 0.7 x IP-Adapter attention (4 tokens) + 0.4 x FaceID attention (16 tokens) of the same queries in ONE
+    launch (softmax groups: every term its own normalisation), the text keys as TWO segments of one group; against the sum of the
+    three softmax attentions in fp32.  ``spike``: a late key of the text group dominates (rescale inside a group) and the IP group's
+    scores sit far below the text group's (the reference must restart with the group)."""
+    from musev_amd import ops
+    heads = 8
+    c = heads * d
+    b = nb // t
+    q = _rand((nb * lq, c), seed)
+    kv = _rand((b * lk, 2 * c), seed + 1)
+    if spike:
+        kv[lk - 3, :c] *= 6.0
+    k, v = kv[:, :c], kv[:, c:]
+    kvi = _rand((b * 4, 2 * c), seed + 2) * (0.05 if spike else 1.0)
+    kvf = _rand((b * 16, 2 * c), seed + 3)
+    scale = d ** -0.5
+    bidx = [n // t for n in range(nb)]
+    l1 = 40  # the text keys in two segments: rows [0, 40) and [40, lk) of every key batch
+    k3, v3 = k.reshape(b, lk, c), v.reshape(b, lk, c)
+    ka, va = k3[:, :l1].reshape(b * l1, c).contiguous(), v3[:, :l1].reshape(b * l1, c).contiguous()
+    kb, vb = k3[:, l1:].reshape(b * (lk - l1), c).contiguous(), v3[:, l1:].reshape(b * (lk - l1), c).contiguous()
+    segs = [(ka, va, l1, t, 1, 0), (kb, vb, lk - l1, t, 1, 0), (kvi[:, :c], kvi[:, c:], 4, t, 1, 0), (kvf[:, :c], kvf[:, c:], 16, t, 1, 0)]
+    got = ops.attention(q, segs, nb, lq, heads, d, scale, group_scales=[1.0, None, 0.7, 0.4])
+    q3 = q.reshape(nb, lq, c)
+    ref = (_attn_ref(q3, k3[bidx], v3[bidx], heads, d, scale)
+           + 0.7 * _attn_ref(q3, kvi[:, :c].reshape(b, 4, c)[bidx], kvi[:, c:].reshape(b, 4, c)[bidx], heads, d, scale)
+           + 0.4 * _attn_ref(q3, kvf[:, :c].reshape(b, 16, c)[bidx], kvf[:, c:].reshape(b, 16, c)[bidx], heads, d, scale))
+    return _cmp(f"attention groups d{d} nb{nb} lq{lq} lk{lk} spike{int(spike)}", got, ref, atol=3e-3)
+
+
 def case_attention_spike(d=40):
     """forces online-softmax rescales: one key per 64-key tile has a much larger score than everything before it."""
     from musev_amd import ops
@@ -631,6 +662,9 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_cross_d80", case_attention_cross),
     ("attention_cross_d40", lambda: case_attention_cross(d=40, seed=71)),
     ("attention_cross_d160", lambda: case_attention_cross(d=160, lq=64, seed=72)),
+    ("attention_groups_d40", case_attention_groups),
+    ("attention_groups_d80", lambda: case_attention_groups(d=80, lq=100, seed=76)),
+    ("attention_groups_d40_spike", lambda: case_attention_groups(d=40, lq=300, lk=200, seed=77, spike=True)),
     ("attention_spike", case_attention_spike),
     ("temporal_attention", case_temporal_attention),
     ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),
@@ -710,6 +744,8 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("tconv_l3", lambda: case_tconv3(b=2, t=13, hw=64, c=1280, seed=222)),                       # M 1664, K 3840: split-K
     ("tconv_l3_half", lambda: case_tconv3(b=1, t=13, hw=64, c=1280, seed=223)),
     ("attention_level0", case_attention_level0),
+    ("attention_groups_l0_half", lambda: case_attention_groups(d=40, nb=13, t=13, lq=4096, seed=78)),   # level-0 cross attention, one CFG half
+    ("attention_groups_l1_half", lambda: case_attention_groups(d=80, nb=13, t=13, lq=1024, seed=79)),
     ("groupnorm_l0", lambda: case_groupnorm(n=26, rows=4096, c1=320, seed=230)),
     ("groupnorm_l0_tconv", lambda: case_groupnorm(n=2, rows=13 * 4096, c1=320, seed=231)),       # statistics over T*H*W
     ("layernorm_l0", lambda: case_layernorm(rows=106496, c=320, seed=232)),
