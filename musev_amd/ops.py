@@ -152,6 +152,8 @@ def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> 
     o = _mat(out, "out")
     if o.shape[0] != M or o.shape[1] != cols:
         raise ValueError(f"out: expected {(M, cols)}, got {tuple(o.shape)}")
+    if hasattr(o, "_mv_colstats"):  # the tensor is about to be overwritten: statistics of its previous contents do not follow
+        del o._mv_colstats
     return o
 
 
