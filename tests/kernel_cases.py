@@ -1,5 +1,5 @@
 """Per-kernel parity cases: each HIP entry point (through the C ABI) against a plain PyTorch fp32 reference of the
-same op on the same seeded inputs.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and by tools/gpu_report.py
+same op on the same seeded inputs.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and by tools/gpu_report.py / tools/gpu_gemm_ab.py
 (one-shot report that does not stop at the first failure).
 
 Tolerances: inputs/outputs are fp16, accumulation fp32 -> |err| <= atol + rtol*|ref| with rtol = 2^-9 (two fp16
