@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="N = 1 default run: skip the short config-4 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-gemm-launches", default=None, metavar="PATH",
+                    help="write the implicit-GEMM launches of one eager step, in launch order, as JSON (mode, M, N, K, geglu, ln, residual, "
+                         "tile configuration, K slices, algorithmic bytes): tools/pmc_by_problem.py joins them with per-dispatch PMC rows")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a 1-GPU box: every rank uses cuda:0, collectives over gloo "
@@ -382,6 +385,27 @@ def main():
     graphs = den.use_graphs and den.graph_replays() > 0
     if den.use_graphs and dev.type == "cuda" and not graphs:
         raise SystemExit("bench.py: the timed steps did not replay a hipGraph")
+
+    if args.dump_gemm_launches and rank == 0:
+        import ctypes as C
+        from musev_amd import _lib
+        ops.GEMM_RECORD = []
+        den.use_graphs = False
+        sync_all()
+        run_steps(1)
+        sync_all()
+        rec, ops.GEMM_RECORD = ops.GEMM_RECORD, None
+        den.use_graphs = True
+        rows = []
+        for d, _keep, nb in rec:
+            cfg, ns = C.c_int32(), C.c_int32()
+            _lib.load().mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns))
+            rows.append({"mode": int(d.mode), "M": int(d.M), "N": int(d.N), "K": int(d.K), "geglu": int(d.geglu), "ln": int(bool(d.ln_colsum)),
+                         "residual": int(bool(d.residual)), "colstats": int(bool(d.colstats)), "cfg": cfg.value, "nsplit": ns.value,
+                         "algorithmic_bytes": nb})
+        with open(args.dump_gemm_launches, "w") as f:
+            json.dump(rows, f)
+        del rec
 
     roofline = None
     if not args.no_roofline:

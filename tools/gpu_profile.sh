@@ -23,5 +23,12 @@ cd $ROOT
 find $OUT/${TAG}_prof -name "*kernel_trace.csv" -delete
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv 2>/dev/null
 python tools/pmc_summary.py $TAG > $OUT/${TAG}_pmc_summary.log 2>&1
+# per-dispatch rows of the implicit-GEMM kernels (small) stay, for tools/pmc_by_problem.py; the full counter tables do not
+for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do
+  f=$(find $OUT/${TAG}_pmc_$c -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && ( head -1 "$f"; grep -E "gemm2_kernel|splitk_reduce" "$f" ) > $OUT/${TAG}_pmc_${c}_gemm_rows.csv
+done
+( MUSEV_NO_GRAPH=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-config4 --dump-gemm-launches $OUT/${TAG}_gemm_launches.json 2>&1 | tail -1 ) > /dev/null
+python tools/pmc_by_problem.py $TAG > $OUT/${TAG}_pmc_by_problem.log 2>&1
 find $OUT -name "*counter_collection.csv" -delete
 cut -c1-1500 $OUT/${TAG}_bench.json; tail -2 $OUT/${TAG}_rocprof.log; head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-160; tail -25 $OUT/${TAG}_pmc_summary.log
