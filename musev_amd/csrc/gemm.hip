@@ -576,64 +576,111 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int kt0 = (int)blockIdx.y * p.kt_per_split;
     const int nk = (kt0 + p.kt_per_split < nk_all) ? (kt0 + p.kt_per_split) : nk_all;  // one past the last K tile of this block
     const bool ragged = (p.K & (BK - 1)) != 0;
-    unsigned a_off[AI];  // current byte offsets (valid for the current tap / source)
-    // (tap, channel) cursor of the next tile to issue; a slice starts in the middle of the walk (cin % 64 == 0 for conv modes)
-    int kc, tap;
+    unsigned a_off[AI];  // current byte offsets (valid for the tile about to be issued)
+    // K walk.  LINEAR: k tile j = columns [64 j, 64 j + 64).  Convolutions: CHANNEL-major with the taps innermost -- k tile j is
+    // (64-channel chunk j / TAPS, tap j % TAPS) -- so that the 9 (3) shifted views of one 64-channel slab of the activations are
+    // fetched back to back while the slab is still in the XCD's L2 (tap-major, the walk of rounds 1-3, re-fetched every tap from the
+    // fabric: the ~32 blocks of an XCD stream ~10 MB between two taps of the same block; profiles/r03ah_pmc_by_problem.log: 3.5-7.6 x
+    // the algorithmic bytes on the convolutions).  The weights stay packed tap-major ([N][taps][cin]): tile (chunk, tap) reads their
+    // columns tap * cin + 64 chunk.  A tap moves a lane's source row by a UNIFORM number of rows (per lane with the fused upsample:
+    // the parity of its output pixel decides), so a tile's offsets are the centre-tap offsets + a shift, masked by the lane's
+    // per-tap validity bits (halo / frame range) -- no division or bounds arithmetic inside the walk.
+    constexpr int TAPS = MODE == MV_GEMM_CONV3X3 ? 9 : MODE == MV_GEMM_TCONV3 ? 3 : 1;
+    int chunk = 0, tap = 0;   // cursor of the next tile to issue (conv modes; cin % 64 == 0)
+    int kc = 0;               // LINEAR: channel cursor
     if (MODE == MV_GEMM_LINEAR) {
         kc = kt0 * BK;
-        tap = 0;
     } else {
-        tap = (kt0 * BK) / p.cin;
-        kc = kt0 * BK - tap * p.cin;
+        chunk = kt0 / TAPS;
+        tap = kt0 - chunk * TAPS;
     }
-    bool rebuild = true;   // the lane offsets must be (re)built before the next issue
+    // conv modes: per piece the centre-tap source row, the validity bits of the taps and (upsample) the output pixel's parities
+    int a_rowc[AI];
+    unsigned a_mask[AI];
+    unsigned a_base[AI];      // centre-tap byte offsets for the CURRENT source
+    if (MODE != MV_GEMM_LINEAR) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            unsigned m = 0;
+            if (MODE == MV_GEMM_CONV3X3) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int iy = a_y[i] + tp / 3 - 1, ix = a_x[i] + tp % 3 - 1;
+                    const bool ok = p.upsample ? (iy >= 0 && iy < 2 * p.hin && ix >= 0 && ix < 2 * p.win)
+                                               : (iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win);
+                    m |= (a_ok[i] && ok) ? (1u << tp) : 0u;
+                }
+                a_rowc[i] = p.upsample ? a_row[i] + (a_y[i] >> 1) * p.win + (a_x[i] >> 1) : a_row[i] + a_y[i] * p.win + a_x[i];
+            } else {
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp) {
+                    const int tt = a_y[i] + tp - 1;
+                    m |= (a_ok[i] && tt >= 0 && tt < p.t) ? (1u << tp) : 0u;
+                }
+                a_rowc[i] = a_row[i];
+            }
+            a_mask[i] = m;
+            a_base[i] = 0;
+        }
+    }
+    bool rebuild = true;   // the centre-tap offsets must be (re)built before the next issue (start, source switch)
+    bool cur_second = false;
 
     bool sec = false;      // source of the tile about to be issued
     unsigned soa = 0;      // its scalar byte offset inside a source row
+    unsigned sob = 0;      // scalar byte offset of its weight columns inside a weight row
 
     // cursor step (the only branchy part of the K loop): fixes (source, offsets) of the next tile to issue
     auto prepare = [&]() {
-        const bool second = (p.a2 != nullptr) && (kc >= p.c1);
-        if (rebuild || kc == 0 || (second && kc == p.c1)) {  // tap or source changed: rebuild the lane offsets (wave-uniform branch)
-            rebuild = false;
-            const unsigned ldb = (unsigned)(second ? p.lda2 : p.lda) * 2u;
-            int dy = 0, dx = 0;
-            if (MODE == MV_GEMM_CONV3X3) {
-                dy = tap / 3 - 1;
-                dx = tap - (tap / 3) * 3 - 1;
-            } else if (MODE == MV_GEMM_TCONV3) {
-                dy = tap - 1;
-            }
+        if (MODE == MV_GEMM_LINEAR) {
+            const bool second = (p.a2 != nullptr) && (kc >= p.c1);
+            if (rebuild || (second && kc == p.c1)) {  // source changed: rebuild the lane offsets (wave-uniform branch)
+                rebuild = false;
+                const unsigned ldb = (unsigned)(second ? p.lda2 : p.lda) * 2u;
 #pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                bool ok = a_ok[i];
-                int row;
-                if (MODE == MV_GEMM_LINEAR) {
-                    row = a_row[i];
-                } else if (MODE == MV_GEMM_CONV3X3) {
-                    int iy = a_y[i] + dy, ix = a_x[i] + dx;
-                    if (p.upsample) {
-                        ok = ok && iy >= 0 && iy < 2 * p.hin && ix >= 0 && ix < 2 * p.win;
-                        iy >>= 1;
-                        ix >>= 1;
-                    } else {
-                        ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
-                    }
-                    row = a_row[i] + iy * p.win + ix;
-                } else {
-                    const int tt = a_y[i] + dy;
-                    ok = ok && tt >= 0 && tt < p.t;
-                    row = a_row[i] + dy * p.hw;
-                }
-                a_off[i] = ok ? (unsigned)row * ldb + lsl * 16u : kOOB;
+                for (int i = 0; i < AI; ++i) a_off[i] = a_ok[i] ? (unsigned)a_row[i] * ldb + lsl * 16u : kOOB;
             }
+            sec = second;
+            soa = (unsigned)(second ? kc - p.c1 : kc) * 2u;
+            sob = (unsigned)kc * 2u;
+            kc += BK;
+            return;
+        }
+        const int c0 = chunk * BK;  // first channel of the tile (of the concatenation)
+        const bool second = (p.a2 != nullptr) && (c0 >= p.c1);
+        const int ldh = second ? p.lda2 : p.lda;
+        if (rebuild || second != cur_second) {  // (wave-uniform branch)
+            rebuild = false;
+            cur_second = second;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) a_base[i] = (unsigned)a_rowc[i] * (unsigned)(ldh * 2) + lsl * 16u;
+        }
+        int dy = 0, dx = 0;
+        if (MODE == MV_GEMM_CONV3X3) {
+            dy = tap / 3 - 1;
+            dx = tap - (tap / 3) * 3 - 1;
+        } else {
+            dy = tap - 1;
+        }
+        const int ushift = (MODE == MV_GEMM_CONV3X3 ? dy * p.win + dx : dy * p.hw) * (ldh * 2);  // uniform row shift in bytes
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            int sh = ushift;
+            if (MODE == MV_GEMM_CONV3X3 && p.upsample) {
+                // ((oy + dy) >> 1) - (oy >> 1): -1 for dy = -1 on an even oy, +1 for dy = +1 on an odd oy, else 0 (same in x)
+                const int py = a_y[i] & 1, px = a_x[i] & 1;
+                const int sy = dy < 0 ? py - 1 : dy > 0 ? py : 0;
+                const int sx = dx < 0 ? px - 1 : dx > 0 ? px : 0;
+                sh = (sy * p.win + sx) * (ldh * 2);
+            }
+            a_off[i] = ((a_mask[i] >> tap) & 1u) ? (unsigned)((int)a_base[i] + sh) : kOOB;
         }
         sec = second;
-        soa = (unsigned)(second ? kc - p.c1 : kc) * 2u;
-        kc += BK;
-        if (MODE != MV_GEMM_LINEAR && kc >= p.cin) {
-            kc -= p.cin;
-            ++tap;
+        soa = (unsigned)(second ? c0 - p.c1 : c0) * 2u;
+        sob = (unsigned)(tap * p.cin + c0) * 2u;
+        if (++tap == TAPS) {
+            tap = 0;
+            ++chunk;
         }
     };
     // branch-free issue of LDS-DMA piece d (0 .. AI+BI-1) of tile kt into stage `buf`
@@ -652,8 +699,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
             if ((CB % NW) != 0 && c >= CB) return;
             const unsigned vo = kcut ? kOOB : b_off[j];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rW, (__attribute__((address_space(3))) void*)(sB + buf * (BN * BK) + c * (RP * BK)), 16, (int)vo,
-                (int)((unsigned)kt * (BK * 2u)), 0, 0);
+                rW, (__attribute__((address_space(3))) void*)(sB + buf * (BN * BK) + c * (RP * BK)), 16, (int)vo, (int)sob, 0, 0);
         }
     };
     auto issue = [&](int buf, int kt) {
