@@ -425,7 +425,7 @@ class ParallelDenoiser:
 
 
 _PER_HALF_KWARGS = ("down_block_refer_embs", "mid_block_refer_emb", "vision_clip_emb", "down_block_additional_residuals",
-                    "mid_block_additional_residual", "pose_guider_emb", "ip_adapter_face_emb")
+                    "mid_block_additional_residual", "pose_guider_emb", "ip_adapter_face_emb", "refer_self_attn_emb")
 
 
 def _ident(v) -> tuple:

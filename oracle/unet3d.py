@@ -27,6 +27,19 @@ from einops import rearrange, repeat
 
 Tensor = torch.Tensor
 
+# Numerical-experiment hook (tools/gpu_error_attribution.py): HOOK(kind, tensor) -> tensor is called at every point where an fp16
+# implementation of this network rounds a value ("gemm": a projection / convolution output incl. its fused bias / row bias / gate;
+# "gn" / "ln": a normalisation output; "stream_outer": the sum of a residual add on the network's identity path (resnet, temporal
+# conv, Transformer2DModel / TransformerTemporalModel outer residual, ReferEmbFuseAttention); "stream_inner": the residual adds inside
+# a BasicTransformerBlock; "attn_q" / "attn_p" / "attn_o": pre-scaled queries, unnormalised probabilities, attention output;
+# "conv_in"; "emb").  None (the default) = the oracle proper: no call, the arithmetic below is untouched.
+HOOK = None
+
+
+def _h(kind: str, x: Tensor) -> Tensor:
+    return x if HOOK is None else HOOK(kind, x)
+
+
 # --------------------------------------------------------------------------------------------------------
 # configuration: the three shipped flavours, musev/models/unet_loader.py:232-268
 # --------------------------------------------------------------------------------------------------------
@@ -308,25 +321,25 @@ def timesteps_sincos(t: Tensor, dim: int) -> Tensor:
 
 def timestep_embedding_mlp(sd, p: str, x: Tensor) -> Tensor:
     x = F.linear(x, sd[p + ".linear_1.weight"], sd[p + ".linear_1.bias"])
-    x = F.silu(x)
-    return F.linear(x, sd[p + ".linear_2.weight"], sd[p + ".linear_2.bias"])
+    x = _h("emb", F.silu(x))
+    return _h("emb", F.linear(x, sd[p + ".linear_2.weight"], sd[p + ".linear_2.bias"]))
 
 
 def resnet_block_2d(sd, p: str, x: Tensor, temb: Tensor, cfg) -> Tensor:
     """diffusers ResnetBlock2D (time_embedding_norm="default", pre_norm, groups 32, eps norm_eps, scale 1)."""
     g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     h = F.group_norm(x, g, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
-    h = F.silu(h)
+    h = _h("gn", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
-    t = temb if cfg["resnet_2d_skip_time_act"] else F.silu(temb)
-    t = F.linear(t, sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])[:, :, None, None]
-    h = h + t
+    t = temb if cfg["resnet_2d_skip_time_act"] else _h("emb", F.silu(temb))
+    t = _h("emb", F.linear(t, sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"]))[:, :, None, None]
+    h = _h("gemm", h + t)
     h = F.group_norm(h, g, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
-    h = F.silu(h)
-    h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    h = _h("gn", F.silu(h))
+    h = _h("gemm", F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1))
     if (p + ".conv_shortcut.weight") in sd:
-        x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
-    return x + h
+        x = _h("gemm", F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"]))
+    return _h("stream_outer", x + h)
 
 
 def _heads(x: Tensor, heads: int) -> Tensor:  # [B, L, H*d] -> [B, H, L, d]
@@ -343,17 +356,22 @@ def sdp_attention(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
     per = max(1, (1 << 28) // max(1, qh.shape[1] * qh.shape[2] * kh.shape[2]))
     outs = []
     for b0 in range(0, qh.shape[0], per):
-        s = torch.matmul(qh[b0:b0 + per], kh[b0:b0 + per].transpose(-1, -2)) * scale
-        outs.append(torch.matmul(torch.softmax(s, dim=-1), vh[b0:b0 + per]))
+        if HOOK is None:
+            s = torch.matmul(qh[b0:b0 + per], kh[b0:b0 + per].transpose(-1, -2)) * scale
+            outs.append(torch.matmul(torch.softmax(s, dim=-1), vh[b0:b0 + per]))
+        else:  # the same attention with the rounding points of a flash-style fp16 kernel exposed
+            s = torch.matmul(_h("attn_q", qh[b0:b0 + per] * scale), kh[b0:b0 + per].transpose(-1, -2))
+            pr = _h("attn_p", torch.exp(s - s.amax(dim=-1, keepdim=True)))
+            outs.append(torch.matmul(pr, vh[b0:b0 + per]) / pr.sum(dim=-1, keepdim=True))
     o = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
     b, h, l, d = o.shape
-    return o.transpose(1, 2).reshape(b, l, h * d)
+    return _h("attn_o", o.transpose(1, 2).reshape(b, l, h * d))
 
 
 def feed_forward_geglu(sd, p: str, x: Tensor) -> Tensor:
     h = F.linear(x, sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"])
     a, gate = h.chunk(2, dim=-1)
-    return F.linear(a * F.gelu(gate), sd[p + ".net.2.weight"], sd[p + ".net.2.bias"])
+    return _h("gemm", F.linear(_h("gemm", a * F.gelu(gate)), sd[p + ".net.2.weight"], sd[p + ".net.2.bias"]))
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -376,9 +394,11 @@ def temporal_conv_layer(sd, p: str, x: Tensor, num_frames: int) -> Tensor:
     identity = h
     for i, ci in ((1, 2), (2, 3), (3, 3), (4, 3)):
         h = F.group_norm(h, 32, sd[f"{p}.conv{i}.0.weight"], sd[f"{p}.conv{i}.0.bias"], 1e-5)
-        h = F.silu(h)
+        h = _h("gn", F.silu(h))
         h = F.conv3d(h, sd[f"{p}.conv{i}.{ci}.weight"], sd[f"{p}.conv{i}.{ci}.bias"], padding=(1, 0, 0))
-    h = identity + torch.abs(sd[p + ".temporal_weight"]) * h
+        if i != 4:
+            h = _h("gemm", h)
+    h = _h("stream_outer", identity + _h("gemm", torch.abs(sd[p + ".temporal_weight"]) * h))
     return rearrange(h, "b c t h w -> (b t) c h w")
 
 
@@ -400,42 +420,42 @@ def attn_self_reference_only(sd, p: str, x: Tensor, heads: int, num_frames: int,
             r = align_repeat(r, num_frames, dim=1)
             e = torch.cat([e, r], dim=2)
         ehs = rearrange(e, "b t hw c -> (b t) hw c")
-    q = F.linear(x, sd[p + ".to_q.weight"])
-    k = F.linear(ehs, sd[p + ".to_k.weight"])
-    v = F.linear(ehs, sd[p + ".to_v.weight"])
+    q = _h("gemm", F.linear(x, sd[p + ".to_q.weight"]))
+    k = _h("gemm", F.linear(ehs, sd[p + ".to_k.weight"]))
+    v = _h("gemm", F.linear(ehs, sd[p + ".to_v.weight"]))
     o = sdp_attention(q, k, v, heads)
-    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+    return _h("gemm", F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]))
 
 
 def attn_cross(sd, p: str, x: Tensor, ehs: Tensor, heads: int, vision_clip_emb: Optional[Tensor], ip_scale: float,
                use_ip: bool, face_emb: Optional[Tensor] = None, face_scale: float = 0.0) -> Tensor:
     """text cross-attention; with use_ip the T2IReferencenetIPAdapterXFormersAttnProcessor branch
     (attention_processor.py:176-359), else diffusers' default processor (same math, no IP term)."""
-    q = F.linear(x, sd[p + ".to_q.weight"])
+    q = _h("gemm", F.linear(x, sd[p + ".to_q.weight"]))
     e = align_repeat(ehs, x.shape[0], dim=0)
-    o = sdp_attention(q, F.linear(e, sd[p + ".to_k.weight"]), F.linear(e, sd[p + ".to_v.weight"]), heads)
+    o = sdp_attention(q, _h("gemm", F.linear(e, sd[p + ".to_k.weight"])), _h("gemm", F.linear(e, sd[p + ".to_v.weight"])), heads)
     if use_ip and ip_scale > 0 and vision_clip_emb is not None:
         batch = ehs.shape[0]  # attention_processor.py:212-216: batch_size is taken from encoder_hidden_states
-        ik = align_repeat(F.linear(vision_clip_emb, sd[p + ".to_k_ip.weight"]), batch, dim=0)
-        iv = align_repeat(F.linear(vision_clip_emb, sd[p + ".to_v_ip.weight"]), batch, dim=0)
+        ik = align_repeat(_h("gemm", F.linear(vision_clip_emb, sd[p + ".to_k_ip.weight"])), batch, dim=0)
+        iv = align_repeat(_h("gemm", F.linear(vision_clip_emb, sd[p + ".to_v_ip.weight"])), batch, dim=0)
         o = o + ip_scale * sdp_attention(q, ik, iv, heads)
     if face_emb is not None and face_scale > 0:   # IP-Adapter-FaceID, attention_processor.py:308-338
         batch = ehs.shape[0]
-        fk = align_repeat(F.linear(face_emb, sd[p + ".ip_adapter_face_to_k_ip.weight"]), batch, dim=0)
-        fv = align_repeat(F.linear(face_emb, sd[p + ".ip_adapter_face_to_v_ip.weight"]), batch, dim=0)
+        fk = align_repeat(_h("gemm", F.linear(face_emb, sd[p + ".ip_adapter_face_to_k_ip.weight"])), batch, dim=0)
+        fv = align_repeat(_h("gemm", F.linear(face_emb, sd[p + ".ip_adapter_face_to_v_ip.weight"])), batch, dim=0)
         o = o + face_scale * sdp_attention(q, fk, fv, heads)
-    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+    return _h("gemm", F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]))
 
 
 def attn_plain_self(sd, p: str, x: Tensor, heads: int) -> Tensor:
-    q = F.linear(x, sd[p + ".to_q.weight"])
-    k = F.linear(x, sd[p + ".to_k.weight"])
-    v = F.linear(x, sd[p + ".to_v.weight"])
-    return F.linear(sdp_attention(q, k, v, heads), sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+    q = _h("gemm", F.linear(x, sd[p + ".to_q.weight"]))
+    k = _h("gemm", F.linear(x, sd[p + ".to_k.weight"]))
+    v = _h("gemm", F.linear(x, sd[p + ".to_v.weight"]))
+    return _h("gemm", F.linear(sdp_attention(q, k, v, heads), sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]))
 
 
 def _ln(sd, p, x):
-    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+    return _h("ln", F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5))
 
 
 def basic_block_spatial(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dict) -> Tensor:
@@ -445,33 +465,33 @@ def basic_block_spatial(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dic
     refer_emb = None
     if ctx.get("refer_self_attn_emb") is not None:   # attention.py:261-289: indexed by the block's spatial_self_attn_idx
         refer_emb = ctx["refer_self_attn_emb"][ctx["spatial_idx"][p]]
-    x = attn_self_reference_only(sd, p + ".attn1", n, heads, ctx["num_frames"], ctx["vis_idx"], refer_emb) + x
+    x = _h("stream_inner", attn_self_reference_only(sd, p + ".attn1", n, heads, ctx["num_frames"], ctx["vis_idx"], refer_emb) + x)
     n = _ln(sd, p + ".norm2", x)
-    x = attn_cross(sd, p + ".attn2", n, ehs, heads, ctx["vision_clip_emb"], ctx["ip_adapter_scale"], ctx["use_ip"],
-                   ctx.get("ip_adapter_face_emb"), ctx.get("ip_adapter_face_scale", 0.0)) + x
+    x = _h("stream_inner", attn_cross(sd, p + ".attn2", n, ehs, heads, ctx["vision_clip_emb"], ctx["ip_adapter_scale"], ctx["use_ip"],
+                                      ctx.get("ip_adapter_face_emb"), ctx.get("ip_adapter_face_scale", 0.0)) + x)
     n = _ln(sd, p + ".norm3", x)
-    return feed_forward_geglu(sd, p + ".ff", n) + x
+    return _h("stream_inner", feed_forward_geglu(sd, p + ".ff", n) + x)
 
 
 def basic_block_temporal(sd, p: str, x: Tensor, heads: int) -> Tensor:
     """same class with double_self_attention=True: attn1 and attn2 are self-attention over T (attention.py:80-81,
     345-366; default SDPA processor, temporal_transformer.py:50-52)."""
-    x = attn_plain_self(sd, p + ".attn1", _ln(sd, p + ".norm1", x), heads) + x
-    x = attn_plain_self(sd, p + ".attn2", _ln(sd, p + ".norm2", x), heads) + x
-    return feed_forward_geglu(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x
+    x = _h("stream_inner", attn_plain_self(sd, p + ".attn1", _ln(sd, p + ".norm1", x), heads) + x)
+    x = _h("stream_inner", attn_plain_self(sd, p + ".attn2", _ln(sd, p + ".norm2", x), heads) + x)
+    return _h("stream_inner", feed_forward_geglu(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x)
 
 
 def transformer_2d(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dict) -> Tensor:
     """musev/models/transformer_2d.py:172-445, continuous-input branch; GroupNorm eps 1e-6 (diffusers ctor)."""
     b, c, h, w = x.shape
     res = x
-    y = F.group_norm(x, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
-    y = F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    y = _h("gn", F.group_norm(x, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
+    y = _h("gemm", F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"]))
     y = y.permute(0, 2, 3, 1).reshape(b, h * w, c)
     y = basic_block_spatial(sd, p + ".transformer_blocks.0", y, ehs, heads, ctx)
     y = y.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
-    y = F.conv2d(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
-    return y + res
+    y = _h("gemm", F.conv2d(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]))
+    return _h("stream_outer", y + res)
 
 
 def transformer_temporal(sd, p: str, x: Tensor, femb: Tensor, heads: int, num_frames: int) -> Tensor:
@@ -480,15 +500,15 @@ def transformer_temporal(sd, p: str, x: Tensor, femb: Tensor, heads: int, num_fr
     b = bt // num_frames
     y = rearrange(x, "(b t) c h w -> b c t h w", b=b)
     res = y
-    y = F.group_norm(y, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
+    y = _h("gn", F.group_norm(y, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
     y = rearrange(y, "b c t h w -> (b h w) t c")
     y = F.linear(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
-    f = F.linear(F.silu(femb), sd[p + ".frame_emb_proj.weight"], sd[p + ".frame_emb_proj.bias"])  # [b, t, c]
-    y = y + align_repeat(f, y.shape[0], dim=0)
+    f = _h("emb", F.linear(_h("emb", F.silu(femb)), sd[p + ".frame_emb_proj.weight"], sd[p + ".frame_emb_proj.bias"]))  # [b, t, c]
+    y = _h("gemm", y + align_repeat(f, y.shape[0], dim=0))
     y = basic_block_temporal(sd, p + ".transformer_blocks.0", y, heads)
     y = F.linear(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
     y = rearrange(y, "(b h w) t c -> b c t h w", b=b, h=h, w=w)
-    out = res + torch.abs(sd[p + ".temporal_weight"]) * y
+    out = _h("stream_outer", res + _h("gemm", torch.abs(sd[p + ".temporal_weight"]) * y))
     return rearrange(out, "b c t h w -> (b t) c h w")
 
 
@@ -501,11 +521,11 @@ def refer_emb_fuse_attention(sd, p: str, x: Tensor, ref: Tensor, heads: int, num
     e = repeat(e, "b n c -> (b t) n c", t=t1)
     y = rearrange(y, "b c t h w -> (b t) (h w) c")
     e = torch.cat([e, y], dim=1)
-    q = F.linear(y, sd[p + ".to_q.weight"])
-    o = sdp_attention(q, F.linear(e, sd[p + ".to_k.weight"]), F.linear(e, sd[p + ".to_v.weight"]), heads)
-    o = F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+    q = _h("gemm", F.linear(y, sd[p + ".to_q.weight"]))
+    o = sdp_attention(q, _h("gemm", F.linear(e, sd[p + ".to_k.weight"])), _h("gemm", F.linear(e, sd[p + ".to_v.weight"])), heads)
+    o = _h("gemm", F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]))
     o = rearrange(o, "bt (h w) c -> bt c h w", h=h, w=w)
-    return o + residual
+    return _h("stream_outer", o + residual)
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -585,6 +605,7 @@ def unet3d_forward(
     x = F.conv2d(x, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
     if pose_guider_emb is not None:
         x = x + pose_guider_emb
+    x = _h("conv_in", x)
     rec("conv_in", x)
     if cfg["need_transformer_in"]:
         x = tattn("transformer_in", x)
@@ -614,7 +635,7 @@ def unet3d_forward(
             skips.append(x)
             rec(f"{p}.out{j}", x)
         if not final:
-            x = F.conv2d(x, sd[f"{p}.downsamplers.0.conv.weight"], sd[f"{p}.downsamplers.0.conv.bias"], stride=2, padding=1)
+            x = _h("gemm", F.conv2d(x, sd[f"{p}.downsamplers.0.conv.weight"], sd[f"{p}.downsamplers.0.conv.bias"], stride=2, padding=1))
             if refer is not None:
                 x = refer_emb_fuse_attention(sd, f"{p}.refer_emb_attns.{L}", x, refer[L], heads, num_frames)
             skips.append(x)
@@ -647,11 +668,11 @@ def unet3d_forward(
                 x = tattn(f"{p}.temp_attentions.{j}", x)
         if i != len(ch) - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = F.conv2d(x, sd[f"{p}.upsamplers.0.conv.weight"], sd[f"{p}.upsamplers.0.conv.bias"], padding=1)
+            x = _h("gemm", F.conv2d(x, sd[f"{p}.upsamplers.0.conv.weight"], sd[f"{p}.upsamplers.0.conv.bias"], padding=1))
         rec(p, x)
 
     # 6. post-process (:1258-1263)
     x = F.group_norm(x, cfg["norm_num_groups"], sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], cfg["norm_eps"])
-    x = F.silu(x)
+    x = _h("gn_out", F.silu(x))
     x = F.conv2d(x, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
     return rearrange(x, "(b t) c h w -> b c t h w", t=num_frames)

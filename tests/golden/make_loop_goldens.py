@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates tests/golden/reference_loop_<case>.npz: per-step latents of the denoise loop at BASELINE config-2 size.
 
-    python tests/golden/make_loop_goldens.py            (needs /root/reference; ~2 CPU-minutes per step on 8 cores, ~30 GB)
+    python tests/golden/make_loop_goldens.py [--case NAME ...] [--threads N]   (needs /root/reference; minutes per step, ~30 GB)
 
 The UNet inside the loop is the REFERENCE'S OWN ``UNet3DConditionModel`` (/root/reference/musev, third-party packages replaced
 by tests/golden/refshim.py as in make_reference_goldens.py); the loop around it is oracle/pipeline.py:denoise_loop (the reference's
@@ -29,14 +29,22 @@ import refshim  # noqa: E402
 refshim.install("/root/reference")
 logging.disable(logging.CRITICAL)
 
-from golden_cases import FLAVOUR_CTOR_KWARGS, LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict  # noqa: E402
+from golden_cases import (FLAVOUR_CTOR_KWARGS, LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict,  # noqa: E402
+                          loop_case_unet_kwargs)
 from oracle import pipeline as opipe  # noqa: E402
 
 
 def main():
     from musev.models.unet_3d_condition import UNet3DConditionModel
-    torch.set_num_threads(os.cpu_count() or 1)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", action="append", default=None, help="case name(s) of golden_cases.LOOP_CASES_AT_SIZE (default: all)")
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
     for name, case in LOOP_CASES_AT_SIZE.items():
+        if args.case and name not in args.case:
+            continue
         cfg, sd = loop_case_state_dict(case)
         ctor = dict(FLAVOUR_CTOR_KWARGS[case["flavour"]])
         ctor.update(block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg["layers_per_block"],
@@ -46,6 +54,7 @@ def main():
         model.load_state_dict(sd, strict=True)
         del sd
         latents, cond, prompt = loop_case_inputs(case)
+        side = loop_case_unet_kwargs(case, cfg)
         t0 = [time.time()]
 
         def unet_fn(x, t, ehs, **kw):
@@ -53,13 +62,22 @@ def main():
             print(f"  forward {tuple(x.shape)} t={int(t)} {time.time() - t0[0]:.0f} s", flush=True)
             return out
 
-        rec = []
+        path = os.path.join(HERE, f"reference_loop_{name}.npz")
+
+        class _Rec(list):  # a 20-step run is hours of CPU: the file is rewritten after every step
+            def append(self, r):
+                super().append(r)
+                np.savez_compressed(path + ".part.npz", **{f"latents_step{i + 1}": v.numpy().astype(np.float32) for i, v in enumerate(self)})
+                print(f"  step {len(self)} |latent|max {float(r.abs().max()):.3f} {time.time() - t0[0]:.0f} s", flush=True)
+
+        rec = _Rec()
         with torch.no_grad():
             opipe.denoise_loop(unet_fn, latents, prompt, num_inference_steps=case["num_inference_steps"], max_steps=case["steps"],
                                guidance_scale=case["guidance_scale"], condition_latents=cond, context_frames=case["context_frames"],
-                               context_overlap=case["context_overlap"], motion_speed=8.0, record_latents=rec)
-        out = {f"latents_step{i + 1}": r.numpy().astype(np.float32) for i, r in enumerate(rec)}
-        np.savez_compressed(os.path.join(HERE, f"reference_loop_{name}.npz"), **out)
+                               context_overlap=case["context_overlap"], motion_speed=8.0, record_latents=rec, unet_kwargs=side)
+            out = {f"latents_step{i + 1}": r.numpy().astype(np.float32) for i, r in enumerate(rec)}
+        np.savez_compressed(path, **out)
+        os.remove(path + ".part.npz")
         print("loop", name, [f"{float(r.abs().max()):.3f}" for r in rec], f"{time.time() - t0[0]:.0f} s", flush=True)
 
 

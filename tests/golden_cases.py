@@ -194,6 +194,13 @@ UNET_CASES_AT_SIZE_CFG5 = {
 LOOP_CASES_AT_SIZE = {
     "musev_cfg2_loop": dict(flavour="musev", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=8, latent_seed=30, cond_seed=31,
                             prompt_seed=32, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12, context_overlap=4),
+    # the WHOLE 20-step schedule of config 2: same seeds as the 4-step case, every step's latents recorded
+    "musev_cfg2_loop20": dict(flavour="musev", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=8, latent_seed=30, cond_seed=31,
+                              prompt_seed=32, guidance_scale=3.5, num_inference_steps=20, steps=20, context_frames=12, context_overlap=4),
+    # config 3 (musev_referencenet + IP-Adapter image tokens + ReferenceNet features), first 4 of 20 steps
+    "refnet_cfg3_loop": dict(flavour="musev_referencenet", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=9, latent_seed=33, cond_seed=34,
+                             prompt_seed=35, side_seed=36, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
+                             context_overlap=4),
 }
 
 
@@ -203,6 +210,21 @@ def loop_case_inputs(case: dict):
     cond = 0.18215 * torch.randn(1, 4, c["n_cond"], c["h"], c["w"], generator=torch.Generator().manual_seed(c["cond_seed"])) if c["n_cond"] else None
     prompt = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(c["prompt_seed"]))
     return latents, cond, prompt
+
+
+def loop_case_unet_kwargs(case: dict, cfg: dict) -> dict:
+    """loop-constant side inputs of the referencenet flavour (ReferenceNet features of the condition frame, IP-Adapter image tokens),
+    batched over the CFG halves [uncond, cond] as the pipeline hands them over (pipeline_controlnet.py:2045-2067)"""
+    if not cfg["need_refer_emb"]:
+        return {}
+    g = torch.Generator().manual_seed(case["side_seed"])
+    shapes, mid = refer_shapes(cfg, case["h"], case["w"])
+    kw = dict(down_block_refer_embs=[torch.randn(1, c, 1, a, b_, generator=g).repeat(2, 1, 1, 1, 1) for c, a, b_ in shapes],
+              mid_block_refer_emb=torch.randn(1, mid[0], 1, mid[1], mid[2], generator=g).repeat(2, 1, 1, 1, 1))
+    if cfg["ip_adapter_cross_attn"]:
+        kw["vision_clip_emb"] = torch.randn(2, 4, cfg["cross_attention_dim"], generator=g)
+        kw["ip_adapter_scale"] = 0.8
+    return kw
 
 
 def loop_case_state_dict(case: dict):

@@ -196,6 +196,41 @@ def test_denoise_loop_over_the_module(scheduler, emulated):
     assert torch.equal(got[:, :, 0].float(), want[:, :, 0])
 
 
+@pytest.mark.parametrize("one_half_per_forward", [True, False])
+def test_denoise_loop_slices_refer_self_attn_emb_per_cfg_half(one_half_per_forward, emulated):
+    """refer_self_attn_emb ("read", attention.py:261-289) is a list of [2 b, c, t, h, w] tensors batched over the CFG halves: the loop
+    must hand each batch-1 half-forward (the default: one half per stream) its own slice, like the other per-half conditioning
+    (the keyword was missing from the per-half list and the batch-1 forward raised)."""
+    from oracle import pipeline as opipe
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines import parallel_denoise as pdn
+    case = UNET_CASES["musev_hipw_refer_self"]
+    _widths(emulated, case["arch"])
+    cfg = case_config(case)
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    _x, _t, _ehs, ckw = case_inputs(case, cfg)
+    refer = [r + 0.25 * torch.arange(2, dtype=r.dtype).view(2, 1, 1, 1, 1) for r in ckw["refer_self_attn_emb"]]  # halves differ
+    g = torch.Generator().manual_seed(3)
+    T, win, ov, h, w = 6, 4, 2, 16, 16
+    latents = torch.randn(1, 4, T, h, w, generator=g)
+    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g)
+    prompt = torch.randn(2, 77, 768, generator=g)
+    kw = dict(num_inference_steps=20, max_steps=1, guidance_scale=3.5, condition_latents=cond, motion_speed=8.0)
+    ukw = dict(refer_self_attn_emb=refer, refer_self_attn_emb_mode="read")
+    want = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt,
+                              context_frames=win, context_overlap=ov, unet_kwargs=ukw, **kw)
+    unet = _cpu(load_unet_by_name("musev", sd_unet_model=sd, dtype=torch.float16, **case["arch"]))
+    unet.insert_spatial_self_attn_idx()
+    if one_half_per_forward:  # what the two-stream default, a sharded rank's lone half and the odd-unit lane do on the GPU
+        emulated.setattr(pdn, "group_units", lambda units: [(u.window, [u.half]) for u in units])
+    den = pdn.ParallelDenoiser(unet, context_frames=win, context_overlap=ov)
+    den._device_check = False
+    got = den(latents, prompt, unet_kwargs=ukw, **kw)
+    err = (got.float() - want).abs().max().item()
+    assert err < TOL, f"|delta latent|max = {err}"
+
+
 def test_referencenet_cfg_glue_feeds_distinct_halves(emulated):
     """pipeline glue (pipeline_controlnet.py:838-859, 867-964): the CFG halves share the reference latents but see different
     cross-attention tokens ([proj(zeros), proj(clip(image))]), so ReferenceNet runs on batch 2 and each half of the UNet gets
