@@ -246,6 +246,9 @@ def main():
     ap.add_argument("--dump-gemm-launches", default=None, metavar="PATH",
                     help="write the implicit-GEMM launches of one eager step, in launch order, as JSON (mode, M, N, K, geglu, ln, residual, "
                          "tile configuration, K slices, algorithmic bytes): tools/pmc_by_problem.py joins them with per-dispatch PMC rows")
+    ap.add_argument("--gemm-by-problem", default=None, metavar="PATH",
+                    help="roofline pass: also time every distinct recorded implicit-GEMM problem on its own (+ torch.matmul of the same "
+                         "M, N, K as a library yardstick for the linear ones) and write the table as JSON")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a 1-GPU box: every rank uses cuda:0, collectives over gloo "
@@ -465,6 +468,40 @@ def main():
             batch2 = {"family_ms_per_step": ms_b2, "tflops": fl_b2 / (ms_b2 * 1e-3) / 1e12, "frac": fl_b2 / (ms_b2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                       "launches_per_step": len(rec_b2)}
             del rec_b2
+        if args.gemm_by_problem and rank == 0:
+            probs = {}
+            for r in rec_all:
+                d = r[0]
+                key = (names[int(d.mode)], int(d.M), int(d.N), int(d.K), "geglu" if d.geglu else "ln" if d.ln_colsum else "res" if d.residual else "-",
+                       int(bool(d.colstats)), int(bool(d.a2)))
+                probs.setdefault(key, []).append(r)
+            rows = []
+            for key, lst in probs.items():
+                one = lst[:1]
+                ops.replay_gemms(one, 2)
+                us = ops.replay_gemms(one, 10) / 10 * 1e3
+                d = one[0][0]
+                fl = 2.0 * d.M * d.N * d.K
+                row = {"mode": key[0], "M": key[1], "N": key[2], "K": key[3], "epilogue": key[4], "colstats": key[5], "two_source": key[6],
+                       "launches_per_step": len(lst), "us": us, "tflops": fl / us / 1e6, "algorithmic_GBps": one[0][2] / us / 1e3,
+                       "ms_per_step": us * len(lst) / 1e3}
+                if key[0] == "linear":
+                    a_ = torch.randn(key[1], key[3], device=dev, dtype=torch.float16)
+                    w_ = torch.randn(key[2], key[3], device=dev, dtype=torch.float16)
+                    for _ in range(2):
+                        torch.matmul(a_, w_.t())
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        torch.matmul(a_, w_.t())
+                    e1.record()
+                    e1.synchronize()
+                    row["torch_matmul_us"] = e0.elapsed_time(e1) / 10 * 1e3
+                    del a_, w_
+                rows.append(row)
+            rows.sort(key=lambda r_: -r_["ms_per_step"])
+            with open(args.gemm_by_problem, "w") as f:
+                json.dump(rows, f, indent=0)
         del rec_all
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {

@@ -199,8 +199,9 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                  guidance_scale_method: str = "linear", controlnet_fn: Optional[Callable[..., tuple]] = None,
                  control_image: Optional[Tensor] = None, controlnet_conditioning_scale: float = 1.0,
                  control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guess_mode: bool = False,
-                 record_latents: Optional[list] = None) -> Tensor:
-    """pipeline_controlnet.py:1832-2156.  ``record`` / ``record_latents`` (test helpers): per-step guided noise prediction / latents.  ``max_steps`` (test helper, not in the reference): stop after the first
+                 record_latents: Optional[list] = None, start_step: int = 0) -> Tensor:
+    """pipeline_controlnet.py:1832-2156.  ``start_step`` (test helper: resume of an interrupted golden run; DDIM at eta 0 carries no
+    state between steps): ``latents`` are the latents AFTER step ``start_step``, the first ``start_step`` schedule entries are skipped.  ``record`` / ``record_latents`` (test helpers): per-step guided noise prediction / latents.  ``max_steps`` (test helper, not in the reference): stop after the first
     max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
     vision_conditon_frames_sample_index=, sample_frame_rate=, **unet_kwargs) -> eps [2, c, n_cond + win, h, w].
@@ -224,6 +225,8 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
     for i, t in enumerate(sched.timesteps):
         if max_steps is not None and i >= max_steps:
             break
+        if i < start_step:
+            continue
         noise_pred = torch.zeros((latents.shape[0] * (2 if do_cfg else 1), *latents.shape[1:]), dtype=latents.dtype)
         counter = torch.zeros((1, 1, T, 1, 1), dtype=latents.dtype)
         for context in global_context:

@@ -30,7 +30,8 @@ Tensor = torch.Tensor
 # Numerical-experiment hook (tools/gpu_error_attribution.py): HOOK(kind, tensor) -> tensor is called at every point where an fp16
 # implementation of this network rounds a value ("gemm": a projection / convolution output incl. its fused bias / row bias / gate;
 # "gn" / "ln": a normalisation output; "stream_outer": the sum of a residual add on the network's identity path (resnet, temporal
-# conv, Transformer2DModel / TransformerTemporalModel outer residual, ReferEmbFuseAttention); "stream_inner": the residual adds inside
+# conv, Transformer2DModel / TransformerTemporalModel outer residual, ReferEmbFuseAttention); "stream_read": what the layers of a block read of that stream -- rounding it
+# but not "stream_outer" models a two-fp16 (hi + lo) carry on the identity path whose consumers read the hi half; "stream_inner": the residual adds inside
 # a BasicTransformerBlock; "attn_q" / "attn_p" / "attn_o": pre-scaled queries, unnormalised probabilities, attention output;
 # "conv_in"; "emb").  None (the default) = the oracle proper: no call, the arithmetic below is untouched.
 HOOK = None
@@ -328,7 +329,8 @@ def timestep_embedding_mlp(sd, p: str, x: Tensor) -> Tensor:
 def resnet_block_2d(sd, p: str, x: Tensor, temb: Tensor, cfg) -> Tensor:
     """diffusers ResnetBlock2D (time_embedding_norm="default", pre_norm, groups 32, eps norm_eps, scale 1)."""
     g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
-    h = F.group_norm(x, g, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
+    xr = _h("stream_read", x)   # what the block's layers read of the stream (the identity path below keeps `x` itself)
+    h = F.group_norm(xr, g, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
     h = _h("gn", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
     t = temb if cfg["resnet_2d_skip_time_act"] else _h("emb", F.silu(temb))
@@ -338,7 +340,7 @@ def resnet_block_2d(sd, p: str, x: Tensor, temb: Tensor, cfg) -> Tensor:
     h = _h("gn", F.silu(h))
     h = _h("gemm", F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1))
     if (p + ".conv_shortcut.weight") in sd:
-        x = _h("gemm", F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"]))
+        x = _h("gemm", F.conv2d(xr, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"]))
     return _h("stream_outer", x + h)
 
 
@@ -392,6 +394,7 @@ def temporal_conv_layer(sd, p: str, x: Tensor, num_frames: int) -> Tensor:
     """musev/models/resnet.py:95-135."""
     h = rearrange(x, "(b t) c h w -> b c t h w", t=num_frames)
     identity = h
+    h = _h("stream_read", h)
     for i, ci in ((1, 2), (2, 3), (3, 3), (4, 3)):
         h = F.group_norm(h, 32, sd[f"{p}.conv{i}.0.weight"], sd[f"{p}.conv{i}.0.bias"], 1e-5)
         h = _h("gn", F.silu(h))
@@ -485,7 +488,7 @@ def transformer_2d(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dict) ->
     """musev/models/transformer_2d.py:172-445, continuous-input branch; GroupNorm eps 1e-6 (diffusers ctor)."""
     b, c, h, w = x.shape
     res = x
-    y = _h("gn", F.group_norm(x, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
+    y = _h("gn", F.group_norm(_h("stream_read", x), 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
     y = _h("gemm", F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"]))
     y = y.permute(0, 2, 3, 1).reshape(b, h * w, c)
     y = basic_block_spatial(sd, p + ".transformer_blocks.0", y, ehs, heads, ctx)
@@ -500,7 +503,7 @@ def transformer_temporal(sd, p: str, x: Tensor, femb: Tensor, heads: int, num_fr
     b = bt // num_frames
     y = rearrange(x, "(b t) c h w -> b c t h w", b=b)
     res = y
-    y = _h("gn", F.group_norm(y, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
+    y = _h("gn", F.group_norm(_h("stream_read", y), 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
     y = rearrange(y, "b c t h w -> (b h w) t c")
     y = F.linear(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
     f = _h("emb", F.linear(_h("emb", F.silu(femb)), sd[p + ".frame_emb_proj.weight"], sd[p + ".frame_emb_proj.bias"]))  # [b, t, c]
@@ -635,7 +638,7 @@ def unet3d_forward(
             skips.append(x)
             rec(f"{p}.out{j}", x)
         if not final:
-            x = _h("gemm", F.conv2d(x, sd[f"{p}.downsamplers.0.conv.weight"], sd[f"{p}.downsamplers.0.conv.bias"], stride=2, padding=1))
+            x = _h("gemm", F.conv2d(_h("stream_read", x), sd[f"{p}.downsamplers.0.conv.weight"], sd[f"{p}.downsamplers.0.conv.bias"], stride=2, padding=1))
             if refer is not None:
                 x = refer_emb_fuse_attention(sd, f"{p}.refer_emb_attns.{L}", x, refer[L], heads, num_frames)
             skips.append(x)
@@ -667,12 +670,12 @@ def unet3d_forward(
                 x = transformer_2d(sd, f"{p}.attentions.{j}", x, ehs, heads, ctx)
                 x = tattn(f"{p}.temp_attentions.{j}", x)
         if i != len(ch) - 1:
-            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = F.interpolate(_h("stream_read", x), scale_factor=2.0, mode="nearest")
             x = _h("gemm", F.conv2d(x, sd[f"{p}.upsamplers.0.conv.weight"], sd[f"{p}.upsamplers.0.conv.bias"], padding=1))
         rec(p, x)
 
     # 6. post-process (:1258-1263)
-    x = F.group_norm(x, cfg["norm_num_groups"], sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], cfg["norm_eps"])
+    x = F.group_norm(_h("stream_read", x), cfg["norm_num_groups"], sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], cfg["norm_eps"])
     x = _h("gn_out", F.silu(x))
     x = F.conv2d(x, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
     return rearrange(x, "(b t) c h w -> b c t h w", t=num_frames)

@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", action="append", default=None, help="case name(s) of golden_cases.LOOP_CASES_AT_SIZE (default: all)")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--resume", action="store_true", help="continue from reference_loop_<case>.npz.part.npz (DDIM: stateless steps)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     for name, case in LOOP_CASES_AT_SIZE.items():
@@ -71,10 +72,19 @@ def main():
                 print(f"  step {len(self)} |latent|max {float(r.abs().max()):.3f} {time.time() - t0[0]:.0f} s", flush=True)
 
         rec = _Rec()
+        start = 0
+        if args.resume and os.path.exists(path + ".part.npz"):
+            with np.load(path + ".part.npz") as z:
+                while f"latents_step{start + 1}" in z:
+                    list.append(rec, torch.from_numpy(z[f"latents_step{start + 1}"]))
+                    start += 1
+            if start:
+                latents = rec[-1].clone()
+            print(f"  resuming {name} after step {start}", flush=True)
         with torch.no_grad():
             opipe.denoise_loop(unet_fn, latents, prompt, num_inference_steps=case["num_inference_steps"], max_steps=case["steps"],
                                guidance_scale=case["guidance_scale"], condition_latents=cond, context_frames=case["context_frames"],
-                               context_overlap=case["context_overlap"], motion_speed=8.0, record_latents=rec, unet_kwargs=side)
+                               context_overlap=case["context_overlap"], motion_speed=8.0, record_latents=rec, unet_kwargs=side, start_step=start)
             out = {f"latents_step{i + 1}": r.numpy().astype(np.float32) for i, r in enumerate(rec)}
         np.savez_compressed(path, **out)
         os.remove(path + ".part.npz")

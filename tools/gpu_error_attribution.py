@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_attribution.json"))
     ap.add_argument("--small", action="store_true", help="2-level net at 16x16 latents (smoke run of the tool itself)")
     ap.add_argument("--no-hip", action="store_true")
+    ap.add_argument("--only", default=None, help="substring: run only the oracle rounding runs whose name contains it (and 'ALL (')")
     args = ap.parse_args()
     from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict, loop_case_unet_kwargs
     from oracle import pipeline as opipe
@@ -79,12 +80,16 @@ def main():
     xd, pd_ = x.to(dev), prompt.to(dev)
     kwd = {k: to_dev(v) for k, v in kw.items()}
 
-    def oracle(classes=(), p_round=rtn16, weights16=False, inputs16=False, collect=None):
+    def oracle(classes=(), p_round=rtn16, weights16=False, inputs16=False, collect=None, carry_channels=None):
+        """carry_channels: widths of the residual stream whose identity path keeps the unrounded sum (a two-fp16 carry) while the
+        layers read its fp16 rounding ("stream_read")"""
         cl = set(classes)
 
         def hook(kind, v):
             if kind == "attn_p":
                 return p_round(v) if "attn_p" in cl else v
+            if kind == "stream_outer" and carry_channels is not None and (v.shape[1] in carry_channels or v.shape[-1] in carry_channels):
+                return v
             return rtn16(v) if kind in cl else v
 
         unet3d.HOOK = hook if cl else None
@@ -106,7 +111,7 @@ def main():
     report = {"case": args.case, "small": bool(args.small), "timestep": t0, "eps_absmax": ref.abs().max().item(), "eps_rms": ref.pow(2).mean().sqrt().item(),
               "device": str(dev), "classes": {}, "hip": {}}
     print(f"oracle fp32 on {dev}: |eps|max {report['eps_absmax']:.3f} rms {report['eps_rms']:.3f}  ({time.time() - t_start:.0f} s)", flush=True)
-    ALL = ["emb", "conv_in", "gemm", "gn", "gn_out", "ln", "stream_outer", "stream_inner", "attn_q", "attn_p", "attn_o"]
+    ALL = ["emb", "conv_in", "gemm", "gn", "gn_out", "ln", "stream_outer", "stream_read", "stream_inner", "attn_q", "attn_p", "attn_o"]
     runs = [("weights", dict(weights16=True)), ("inputs", dict(inputs16=True))]
     runs += [(c, dict(classes=[c])) for c in ALL]
     runs += [("attn_p_rtz", dict(classes=["attn_p"], p_round=rtz16)),
@@ -116,10 +121,14 @@ def main():
              ("ALL but stream_outer", dict(classes=[c for c in ALL if c != "stream_outer"], weights16=True, inputs16=True)),
              ("ALL but stream_outer, stream_inner", dict(classes=[c for c in ALL if not c.startswith("stream")], weights16=True, inputs16=True)),
              ("ALL but stream_outer, conv_in, gn_out", dict(classes=[c for c in ALL if c not in ("stream_outer", "conv_in", "gn_out")], weights16=True, inputs16=True)),
+             ("ALL, two-fp16 carry on the outer stream (layers read hi)", dict(classes=ALL, weights16=True, inputs16=True, carry_channels=(320, 640, 1280))),
+             ("ALL, two-fp16 carry at level 0 only (C = 320)", dict(classes=ALL, weights16=True, inputs16=True, carry_channels=(320,))),
              ("ALL but weights", dict(classes=ALL, inputs16=True)),
              ("ALL but gemm", dict(classes=[c for c in ALL if c != "gemm"], weights16=True, inputs16=True)),
              ("ALL but gn", dict(classes=[c for c in ALL if c != "gn"], weights16=True, inputs16=True))]
     for name, k in runs:
+        if args.only and args.only not in name and not name.startswith("ALL ("):
+            continue
         st = stats(oracle(**k), ref)
         report["classes"][name] = st
         print(f"  rounded: {name:55s} |d eps|max {st['max']:.3e}  p99.9 {st['p999']:.3e}  rms {st['rms']:.3e}", flush=True)
