@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 6
+#define MV_ABI_VERSION 7
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -90,6 +90,13 @@ typedef struct mv_gemm_desc {
     /*   statistics pass of nn.GroupNorm over the conv / proj_out outputs: resnet.py:57-82, transformer_2d.py:260, unet blocks) */
     float* colstats;         /* fp32 [ceil(M / rows_per_tile)][N][2], 8-byte aligned, or NULL                                   */
     int64_t colstats_floats; /* capacity of colstats in floats                                                                 */
+    /* Two-fp16 carry of the residual stream's identity path (`hidden_states = hidden_states + residual` of ResnetBlock2D,         */
+    /* resnet.py:133, transformer_2d.py:389, temporal_transformer.py:283-287; conv_in): with c_lo the epilogue forms               */
+    /*   s = value + residual + residual_lo in fp32 and stores c = fp16(s), c_lo = fp16(s - c).  Layers read c (an ordinary fp16   */
+    /* tensor); only the next residual add picks c_lo up again, so the identity path keeps ~22 bits instead of rounding to fp16 at */
+    /* every block (16-byte epilogue, one K slice, no GEGLU / LayerNorm folding; leading dimensions ldc / ldr as c / residual).    */
+    const void* residual_lo; /* fp16 [M][ldr] or NULL (a residual without a lo half)                                              */
+    void* c_lo;              /* fp16 [M][ldc] or NULL (no carry)                                                                   */
 } mv_gemm_desc;
 
 /* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "l
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 6
+MV_ABI_VERSION = 7
 
 
 class MuseVHipError(RuntimeError):
@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("cfg", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("ln_colsum", C.c_void_p), ("ln_colbias", C.c_void_p), ("ln_eps", C.c_float), ("reserved0", C.c_int32),
         ("colstats", C.c_void_p), ("colstats_floats", C.c_int64),
+        ("residual_lo", C.c_void_p), ("c_lo", C.c_void_p),
     ]
 
 

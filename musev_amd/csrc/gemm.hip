@@ -57,6 +57,10 @@ struct GemmArgs {
     // the sum and the sum of squares of the fp16 values it stores, per column over its 16 TM rows, and writes them to
     // colstats[mw0 / (16 TM)][n][2] -- mv_groupnorm_cs_f16 folds them instead of re-reading the tensor
     float* colstats;
+    // two-fp16 carry of the residual stream's identity path (wide epilogue, one K slice, no GEGLU / LayerNorm fold): the sum
+    // s = value + residual + residual_lo is formed in fp32 and stored as c = fp16(s), c_lo = fp16(s - c); layers read c only
+    const half_t* residual_lo;  // [M][ldr] or nullptr
+    half_t* c_lo;               // [M][ldc] or nullptr (no carry)
 };
 
 template <int TM, int TN>
@@ -267,13 +271,18 @@ template <int TN, bool GEGLU> struct EpiGeom {
 
 // LN: the accumulators hold x . (gamma W)^T of the RAW rows; a pass first applies v = rstd_m * acc - (rstd_m * mean_m) * colsum_n +
 // colbias_n (ln_r[i] = rstd, ln_mr[i] = rstd * mean of row 16 i + l15; the column vectors are read in the accumulator layout).
-template <int TM, int TN, bool GEGLU, bool RES, bool LN = false>
+// CARRY: a pass is staged as TWO fp16 values per element (hi = fp16(v), lo = fp16(v - hi): v to ~22 bits) in two buffers, the read
+// phase forms s = hi + lo + residual + residual_lo in fp32 and stores c = fp16(s), c_lo = fp16(s - c) -- the identity path of the
+// residual stream keeps ~22 bits across the network while every layer reads the fp16 tensor c (column statistics are those of c).
+template <int TM, int TN, bool GEGLU, bool RES, bool LN = false, bool CARRY = false>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc)[TM][TN], half_t* stg_base, int wave, int mw0,
                                                 int nw0, int lane, float alpha, int Mi, bool full, const float* ln_r = nullptr,
                                                 const float* ln_mr = nullptr, int nacc0 = 0) {
     using G = EpiGeom<TN, GEGLU>;
     constexpr int W = G::W, LDW = G::LDW, CPR = G::CPR, RPI = G::RPI, KI = G::KI;
-    half_t* stg = stg_base + wave * G::WAVE_HALFS;
+    static_assert(!CARRY || (!GEGLU && !LN), "the carry is a feature of the plain / residual epilogue");
+    constexpr int LO = G::WAVE_HALFS;  // CARRY: the lo buffers sit behind the wave's two hi buffers
+    half_t* stg = stg_base + wave * ((CARRY ? 2 : 1) * G::WAVE_HALFS);
     const int l15 = lane & 15, g = lane >> 4;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
     // read-phase geometry of this lane
@@ -285,6 +294,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
     half_t* wr = stg + l15 * LDW + 4 * g;
     half_t* const cbase = p.c + (long)mw0 * p.ldc + nw0;                                   // wave-uniform
     const half_t* const rbase = RES ? p.residual + (long)mw0 * p.ldr + nw0 : nullptr;
+    half_t* const clo = CARRY ? p.c_lo + (long)mw0 * p.ldc + nw0 : nullptr;
+    const half_t* const rlo = (CARRY && RES && p.residual_lo) ? p.residual_lo + (long)mw0 * p.ldr + nw0 : nullptr;  // (wave-uniform)
     const unsigned coff = (unsigned)(r0 * p.ldc + 8 * ch), roff = (unsigned)(r0 * p.ldr + 8 * ch);
     const bool silu = p.act == MV_ACT_SILU;
 
@@ -320,14 +331,20 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
         for (int e = 0; e < 8; ++e) cs1[e] = cs2[e] = 0.f;
     }
     half8v res[2][KI];
-    auto request = [&](int i, half8v* rs) {  // residual chunks of pass i, in the read layout
+    half8v resl[(CARRY && RES) ? 2 : 1][(CARRY && RES) ? KI : 1];
+    auto request = [&](int i, half8v* rs, half8v* rsl) {  // residual chunks of pass i, in the read layout
         if constexpr (RES) {
 #pragma unroll
             for (int k = 0; k < KI; ++k) {
                 const int row = r0 + k * RPI;
                 rs[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-                if (lane_on && row < 16 && col_ok && (full || mw0 + 16 * i + row < Mi))
+                if constexpr (CARRY) rsl[k] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+                if (lane_on && row < 16 && col_ok && (full || mw0 + 16 * i + row < Mi)) {
                     rs[k] = *reinterpret_cast<const half8v*>(rbase + (roff + (unsigned)((16 * i + k * RPI) * p.ldr)));
+                    if constexpr (CARRY) {
+                        if (rlo) rsl[k] = *reinterpret_cast<const half8v*>(rlo + (roff + (unsigned)((16 * i + k * RPI) * p.ldr)));
+                    }
+                }
             }
         }
     };
@@ -347,11 +364,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
                 if (silu) {
                     v[0] = mv_silu(v[0]); v[1] = mv_silu(v[1]); v[2] = mv_silu(v[2]); v[3] = mv_silu(v[3]);
                 }
-                *reinterpret_cast<half4v*>(wrow + 16 * j) = half4v{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                const half4v hv = half4v{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4v*>(wrow + 16 * j) = hv;
+                if constexpr (CARRY)
+                    *reinterpret_cast<half4v*>(wrow + LO + 16 * j) = half4v{(half_t)(v[0] - (float)hv[0]), (half_t)(v[1] - (float)hv[1]),
+                                                                            (half_t)(v[2] - (float)hv[2]), (half_t)(v[3] - (float)hv[3])};
             }
         }
     };
-    request(0, res[0]);
+    request(0, res[0], resl[0]);
     write_pass(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -362,14 +383,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // ---- the next pass's residual requests go out ahead of this pass's stores ----
-        if (i + 1 < TM) request(i + 1, res[buf ^ 1]);
+        if (i + 1 < TM) request(i + 1, res[buf ^ 1], resl[(CARRY && RES) ? (buf ^ 1) : 0]);
         // ---- read phase of pass i: every LDS read of the pass first (lanes past the pass rows read row 0, their values unused) ----
         const half_t* rrow = rd + buf * (16 * LDW);
-        half8v ov[KI];
+        half8v ov[KI], ovl[CARRY ? KI : 1];
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
             const int row = r0 + k * RPI;
             ov[k] = *reinterpret_cast<const half8v*>(rrow + ((lane_on && row < 16) ? k * RPI * LDW : 0));
+            if constexpr (CARRY) ovl[k] = *reinterpret_cast<const half8v*>(rrow + LO + ((lane_on && row < 16) ? k * RPI * LDW : 0));
         }
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
@@ -377,9 +399,22 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
             const bool valid = lane_on && row < 16 && col_ok && (full || mw0 + 16 * i + row < Mi);
             half8v o = half8v{0, 0, 0, 0, 0, 0, 0, 0};
             if (valid) {
-                o = ov[k];
-                if constexpr (RES) o += res[buf][k];
-                *reinterpret_cast<half8v*>(cbase + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = o;
+                if constexpr (CARRY) {
+                    half8v ol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float sv = (float)ov[k][e] + (float)ovl[k][e];
+                        if constexpr (RES) sv = (sv + (float)res[buf][k][e]) + (float)resl[buf][k][e];
+                        o[e] = (half_t)sv;
+                        ol[e] = (half_t)(sv - (float)o[e]);
+                    }
+                    *reinterpret_cast<half8v*>(cbase + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = o;
+                    *reinterpret_cast<half8v*>(clo + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = ol;
+                } else {
+                    o = ov[k];
+                    if constexpr (RES) o += res[buf][k];
+                    *reinterpret_cast<half8v*>(cbase + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = o;
+                }
             }
             if constexpr (!GEGLU) {
                 if (cs_on && valid) {
@@ -449,9 +484,10 @@ __device__ unsigned long long mv_tl_buf[kTlBlocks * 8];
 #define MV_TL_FLUSH() ((void)0)
 #endif
 
-template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false>
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false, bool CARRY = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs2 q) {
     static_assert(!LNF || MODE == MV_GEMM_LINEAR, "LayerNorm folding is a LINEAR-mode feature");
+    static_assert(!(LNF && CARRY), "no carry behind a LayerNorm-folded projection");
     static_assert((WGN & (WGN - 1)) == 0, "the k-step deal of the row statistics needs a power-of-two WGN");
     constexpr int NW = WGM * WGN;
     // SCHED: 0 = two LDS stages behind __syncthreads (two blocks per CU overlap each other's stalls);
@@ -848,7 +884,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
         }
         half_t* stg = reinterpret_cast<half_t*>(smem);  // (the launcher sizes the dynamic LDS as max(operand stages, staging area))
         const bool full = m0 + BM <= Mi && n0 + BN <= p.N;
-        if (p.geglu) {
+        if constexpr (CARRY) {
+            if (p.residual) epilogue_staged<TM, TN, false, true, false, true>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full);
+            else epilogue_staged<TM, TN, false, false, false, true>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full);
+        } else if (p.geglu) {
             if constexpr ((TN & 1) == 0) epilogue_staged<TM, TN, true, false, LNF>(p, acc, stg, wave, mw0, nw0 >> 1, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
         } else if (p.residual) {
             epilogue_staged<TM, TN, false, true, LNF>(p, acc, stg, wave, mw0, nw0, lane, alpha, Mi, full, ln_r, ln_mr, nw0);
@@ -914,12 +953,13 @@ int mv_num_cus() {
     return n;
 }
 
-template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false>
+template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false, bool CARRY = false>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
     constexpr int smem_ops = (SCHED == 3 ? 3 * 64 : 2 * 64) * (BM + BN) * (int)sizeof(half_t);
     // the LDS-staged epilogue reuses the operand LDS: two 16-row fp16 buffers of (16 TN + 8) halfs per wave must fit as well
-    constexpr int smem_epi = WGM * WGN * EpiGeom<TN, false>::WAVE_HALFS * (int)sizeof(half_t);
+    // (CARRY: two more for the lo halves)
+    constexpr int smem_epi = (CARRY ? 2 : 1) * WGM * WGN * EpiGeom<TN, false>::WAVE_HALFS * (int)sizeof(half_t);
     // LNF: + the waves' row-statistic partials [wave][16 TM][2] fp32 behind them
     constexpr int smem = (smem_ops > smem_epi ? smem_ops : smem_epi) + (LNF ? WGM * WGN * 16 * TM * 2 * (int)sizeof(float) : 0);
     static_assert(smem <= 160 * 1024, "tile does not fit LDS");
@@ -930,7 +970,7 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     a.g.kt_per_split = (nk + a.g.nsplit - 1) / a.g.nsplit;
     static bool attr_done = false;  // idempotent one-time attribute of this instantiation (not tuning state)
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED, LNF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED, LNF, CARRY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             mv_set_error("mv_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -939,7 +979,7 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid((unsigned)(a.g.tiles_m * a.g.tiles_n), (unsigned)a.g.nsplit);
-    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED, LNF>), grid, dim3(64 * WGM * WGN), smem, stream, a);
+    hipLaunchKernelGGL((gemm2_kernel<MODE, TM, TN, WGM, WGN, SCHED, LNF, CARRY>), grid, dim3(64 * WGM * WGN), smem, stream, a);
     MV_CHECK_LAUNCH("mv_gemm_f16");
     if (a.g.nsplit > 1) {
         const long work = a.g.M * (long)(a.g.N >> 2);
@@ -1011,6 +1051,35 @@ int launch_ln_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
 #undef MV_X
     }
     mv_set_error("mv_gemm_f16: tile configuration %d has no LayerNorm-folded form", id);
+    return MV_ERR_INVALID;
+}
+
+// Carry launches (GemmArgs::c_lo): the two-stage tiles of up to 80 accumulators per lane (the carry's epilogue holds the residual's
+// two halves and the staged value's two halves per pass); any other choice is mapped to the nearest of them
+inline int gemm_carry_cfg(int id) {
+    switch (id) {
+        case 0: case 1: case 2: case 3: case 8: case 13: case 15: return id;
+        case 4: case 6: case 11: return 8;    // 256x160 / 256x320 / 128x320 -> 256x160 (two stages)
+        case 12: case 18: return 0;           // 128x160 three stages -> two stages
+        case 5: case 7: case 9: case 10: case 16: return 2;   // the 128-wide family -> 128x128
+        case 17: return 1;
+        case 14: return 13;
+        default: return 0;
+    }
+}
+
+template <int MODE>
+int launch_carry_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
+    switch (id) {
+        case 0: return launch_cfg2s<MODE, 4, 5, 2, 2, 0, false, true>(a, stream);
+        case 1: return launch_cfg2s<MODE, 2, 5, 2, 2, 0, false, true>(a, stream);
+        case 2: return launch_cfg2s<MODE, 4, 4, 2, 2, 0, false, true>(a, stream);
+        case 3: return launch_cfg2s<MODE, 2, 4, 2, 2, 0, false, true>(a, stream);
+        case 8: return launch_cfg2s<MODE, 4, 5, 4, 2, 0, false, true>(a, stream);
+        case 13: return launch_cfg2s<MODE, 2, 5, 2, 1, 0, false, true>(a, stream);
+        case 15: return launch_cfg2s<MODE, 2, 5, 4, 2, 0, false, true>(a, stream);
+    }
+    mv_set_error("mv_gemm_f16: tile configuration %d has no carry form", id);
     return MV_ERR_INVALID;
 }
 
@@ -1104,6 +1173,10 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
         ch.cfg = gemm_ln_cfg(ch.cfg);
         ch.nsplit = 1;
     }
+    if (g.c_lo) {  // the carry lives in the staged epilogue of an unsplit launch
+        ch.cfg = gemm_carry_cfg(ch.cfg);
+        ch.nsplit = 1;
+    }
     return ch;
 }
 
@@ -1180,6 +1253,10 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     a.nsplit = 1; a.kt_per_split = 0; a.ws = nullptr;
     a.ln_colsum = d->ln_colsum; a.ln_colbias = d->ln_colbias; a.ln_eps = d->ln_eps;
     a.colstats = nullptr;  // (set by mv_gemm_f16 once the choice is known to support it)
+    a.residual_lo = (const half_t*)d->residual_lo; a.c_lo = (half_t*)d->c_lo;
+    MV_REQUIRE(!d->residual_lo || (d->residual && d->c_lo), "%s: residual_lo needs residual and c_lo", who);
+    if (d->c_lo)
+        MV_REQUIRE(!d->geglu && !d->ln_colsum && d->splitk <= 1, "%s: the carry (c_lo) excludes GEGLU, LayerNorm folding and a forced K split", who);
     if (d->ln_colsum || d->ln_colbias) {
         MV_REQUIRE(d->ln_colsum && d->ln_colbias && d->ln_eps > 0.f, "%s: LayerNorm folding needs ln_colsum, ln_colbias and ln_eps > 0", who);
         MV_REQUIRE(d->mode == MV_GEMM_LINEAR && !d->a2 && !d->bias && !d->rowbias && d->K % 64 == 0,
@@ -1209,6 +1286,9 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
              (!d->rowbias || (d->ldrb % 8 == 0 && al16(d->rowbias))) &&
              (!d->residual || (d->ldr % 8 == 0 && al16(d->residual)));
     if (d->ln_colsum) MV_REQUIRE(b.wide, "%s: LayerNorm folding needs the 16-byte epilogue (N, ldc, ldr %% 8, aligned pointers)", who);
+    if (d->c_lo)
+        MV_REQUIRE(b.wide && al16(d->c_lo) && (!d->residual_lo || al16(d->residual_lo)),
+                   "%s: the carry needs the 16-byte epilogue (N, ldc, ldr %% 8; c_lo / residual_lo 16-byte aligned, same leading dimensions as c / residual)", who);
     return MV_OK;
 }
 
@@ -1269,6 +1349,12 @@ extern "C" int mv_gemm_f16(const mv_gemm_desc* d, void* stream) {
     if (d->ln_colsum) {
         MV_REQUIRE(ch.nsplit == 1, "mv_gemm_f16: LayerNorm folding cannot be combined with a forced K split");
         return launch_ln_by_id(b, s, ch.cfg);
+    }
+    if (d->c_lo) {
+        MV_REQUIRE(ch.nsplit == 1, "mv_gemm_f16: the carry cannot be combined with a K split");
+        if (d->mode == MV_GEMM_CONV3X3) return launch_carry_by_id<MV_GEMM_CONV3X3>(b, s, ch.cfg);
+        if (d->mode == MV_GEMM_TCONV3) return launch_carry_by_id<MV_GEMM_TCONV3>(b, s, ch.cfg);
+        return launch_carry_by_id<MV_GEMM_LINEAR>(b, s, ch.cfg);
     }
     if (d->mode == MV_GEMM_CONV3X3) return launch_by_id<MV_GEMM_CONV3X3>(b, s, ch.cfg);
     if (d->mode == MV_GEMM_TCONV3) return launch_by_id<MV_GEMM_TCONV3>(b, s, ch.cfg);

@@ -127,7 +127,7 @@ class ResnetBlock2D(HipModule):
                 raise ValueError("ResnetBlock2D: concatenated input needs a conv_shortcut")
             sc = x
         w2 = self.packed("conv2", lambda: ops.pack_conv_weight(self.conv2.weight.detach()))
-        return ops.conv3x3(h, w2, geo.n, geo.h, geo.w, bias=w16(self.conv2.bias), residual=sc)
+        return ops.conv3x3(h, w2, geo.n, geo.h, geo.w, bias=w16(self.conv2.bias), residual=sc, carry=True)
 
 
 class Downsample2D(HipModule):

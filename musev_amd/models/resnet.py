@@ -52,5 +52,5 @@ class TemporalConvLayer(HipModule):
             w = self.packed(f"conv{i + 1}", lambda conv=conv: ops.pack_conv_weight(conv.weight.detach()))
             last = i == len(seqs) - 1
             h = ops.tconv3(h, w, geo.b, geo.t, geo.hw, bias=w16(conv.bias), residual=x if last else None,
-                           alpha=self.alpha() if last else None)
+                           alpha=self.alpha() if last else None, carry=last)
         return h

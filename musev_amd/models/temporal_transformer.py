@@ -55,4 +55,4 @@ class TransformerTemporalModel(HipModule):
         h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowbias=fproj, rows_per_group=geo.hw)
         for blk in self.transformer_blocks:
             h = blk.hip_forward_temporal(h, geo)
-        return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, alpha=self.alpha(), colstats=True)
+        return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, alpha=self.alpha(), colstats=True, carry=True)

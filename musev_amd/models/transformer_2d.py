@@ -44,4 +44,4 @@ class Transformer2DModel(HipModule):
         h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in))
         for blk in self.transformer_blocks:
             h = blk.hip_forward_spatial(h, ctx, geo, self.reference_only, self.ip_adapter_cross_attn)
-        return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, colstats=True)
+        return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, colstats=True, carry=True)

@@ -55,6 +55,38 @@ COLSTATS: bool = os.environ.get("MUSEV_COLSTATS", "1") == "1"
 COLSTATS_HITS: int = 0   # GroupNorm calls served from producer statistics (tests / reports)
 
 
+# Two-fp16 carry on the identity path of the residual stream (env knob for A/B runs: MUSEV_CARRY=0 switches it off).  The fp16
+# rounding of the stream at every `x + f(x)` is the largest single contribution to the forward's error against the fp32 reference
+# (profiles/r04a_attribution.log: 5.2e-3 of 5.6e-3 |delta eps|max alone) -- and it sits at level 0, where the network's largest values
+# live.  With the carry the epilogue of a stream-producing launch (conv_in, ResnetBlock2D.conv2 + shortcut, the temporal convolution's
+# last conv + identity, Transformer2DModel / TransformerTemporalModel proj_out + residual) stores the fp32 sum as TWO fp16 tensors
+# (hi = fp16(s), lo = fp16(s - hi)); every layer reads hi -- an ordinary fp16 tensor -- and only the next residual add picks lo up
+# again (the lo tensor rides on the hi tensor OBJECT as `_mv_lo`, like the column statistics: a view / copy / tensor produced some
+# other way has none).  Applied where the stream is at most CARRY_MAX_C channels wide (level 0 of SD-1.5: 320; the deeper levels add
+# nothing measurable, profiles/r04b_attribution_carry.log).
+CARRY: bool = os.environ.get("MUSEV_CARRY", "1") == "1"
+CARRY_MAX_C: int = int(os.environ.get("MUSEV_CARRY_MAX_C", "320"))
+CARRY_HITS: int = 0
+
+
+def _carry_setup(d: GemmDesc, o: torch.Tensor, residual: Optional[torch.Tensor], carry: bool, keep: tuple) -> tuple:
+    """fills d.c_lo / d.residual_lo for a stream-producing launch; returns the tensors to keep alive"""
+    if not (carry and CARRY) or o.shape[1] > CARRY_MAX_C or o.shape[1] % 8 or o.stride(0) % 8 or o.data_ptr() % 16:
+        return keep
+    if residual is not None and (residual.stride(0) % 8 or residual.data_ptr() % 16):
+        return keep
+    global CARRY_HITS
+    CARRY_HITS += 1
+    lo = torch.empty_strided(o.shape, o.stride(), dtype=torch.float16, device=o.device)
+    d.c_lo = lo.data_ptr()
+    rlo = getattr(residual, "_mv_lo", None) if residual is not None else None
+    if rlo is not None and rlo.shape == residual.shape and rlo.stride() == residual.stride():
+        d.residual_lo = rlo.data_ptr()
+        keep = keep + (rlo,)
+    o._mv_lo = lo
+    return keep + (lo,)
+
+
 def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
@@ -80,7 +112,8 @@ def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), co
         if d.mode == MV_GEMM_CONV3X3:
             rows_in = (int(d.M) // (int(d.hout) * int(d.wout))) * int(d.hin) * int(d.win)
         cols = int(d.N) // 2 if d.geglu else int(d.N)
-        nbytes = 2 * (rows_in * (int(d.c1) + int(d.c2)) + int(d.N) * int(d.K) + int(d.M) * cols * (2 if d.residual else 1))
+        nbytes = 2 * (rows_in * (int(d.c1) + int(d.c2)) + int(d.N) * int(d.K) +
+                      int(d.M) * cols * ((2 if d.residual else 1) + (1 if d.c_lo else 0) + (1 if d.residual_lo else 0)))
         GEMM_RECORD.append((GemmDesc.from_buffer_copy(d), keep + (ws,), nbytes))
 
 
@@ -154,15 +187,18 @@ def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> 
         raise ValueError(f"out: expected {(M, cols)}, got {tuple(o.shape)}")
     if hasattr(o, "_mv_colstats"):  # the tensor is about to be overwritten: statistics of its previous contents do not follow
         del o._mv_colstats
+    if hasattr(o, "_mv_lo"):
+        del o._mv_lo
     return o
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_group: int = 0, residual=None, alpha=None, act: int = MV_ACT_NONE, geglu: bool = False,
          out: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None,
-         colstats: bool = False) -> torch.Tensor:
+         colstats: bool = False, carry: bool = False) -> torch.Tensor:
     """out = act(|alpha| * ([a | a2] @ w.T + bias + rowbias[row // rows_per_group])) + residual   (fp16, fp32 accumulate).
     ``colstats``: the output feeds a GroupNorm next -- emit its column statistics from the epilogue (see COLSTATS).
+    ``carry``: the output is the residual stream -- keep the fp32 sum as two fp16 tensors (see CARRY).
 
     ``w`` is [N, K] (torch Linear layout).  With ``geglu`` the rows of ``w`` / ``bias`` must be packed by
     :func:`pack_geglu` and the result has N/2 columns: value * gelu(gate).
@@ -199,7 +235,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if bias is not None or rowbias is not None or a2 is not None:
             raise ValueError("gemm(ln=...): the bias is part of colbias; no rowbias / second source")
         d.ln_colsum, d.ln_colbias, d.ln_eps = cs.data_ptr(), cb.data_ptr(), float(eps)
-    _launch_gemm(d, "mv_gemm_f16", a.device, (a, a2, w, o, bias, rowbias, residual, alpha, ln), o if colstats and not geglu else None)
+    keep = (a, a2, w, o, bias, rowbias, residual, alpha, ln)
+    if carry and not geglu and ln is None:
+        keep = _carry_setup(d, o, residual, carry, keep)
+    _launch_gemm(d, "mv_gemm_f16", a.device, keep, o if colstats and not geglu else None)
     return o
 
 
@@ -265,7 +304,7 @@ def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.T
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2: Optional[torch.Tensor] = None,
             stride: int = 1, upsample: bool = False, bias=None, rowbias=None, rows_per_group: int = 0, residual=None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, carry: bool = False) -> torch.Tensor:
     """3x3 convolution, padding 1, over channels-last images x = [n_img*h*w_, C1] (+ optional concatenated x2).
 
     ``w`` is the packed weight [Cout, 9*(C1+C2)] (tap-major, see :func:`pack_conv_weight`).  ``upsample`` applies a
@@ -297,12 +336,12 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, h: int, w_: int, *, x2
     d.mode, d.stride, d.upsample = MV_GEMM_CONV3X3, stride, int(upsample)
     d.hin, d.win, d.hout, d.wout = h, w_, ho, wo
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, None, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device, (x, x2, w, o, bias, rowbias, residual), o)
+    _launch_gemm(d, "mv_gemm_f16(conv3x3)", x.device, _carry_setup(d, o, residual, carry, (x, x2, w, o, bias, rowbias, residual)), o)
     return o
 
 
 def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=None, residual=None, alpha=None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, carry: bool = False) -> torch.Tensor:
     """Conv3d (3,1,1), padding (1,0,0), over x = [b*t*hw, C] in (b, t, p) row order; w packed [Cout, 3*C]."""
     x = _mat(x, "x")
     w = _mat(w, "w")
@@ -319,7 +358,7 @@ def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=No
     d.M, d.N, d.K = M, N, K
     d.mode, d.t, d.hw = MV_GEMM_TCONV3, t, hw
     _fill_epilogue(d, N, M, bias, None, 0, residual, alpha, MV_ACT_NONE, N)
-    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device, (x, w, o, bias, residual, alpha), o)
+    _launch_gemm(d, "mv_gemm_f16(tconv3)", x.device, _carry_setup(d, o, residual, carry, (x, w, o, bias, residual, alpha)), o)
     return o
 
 
@@ -491,7 +530,7 @@ def conv3x3_cin_small_gemm(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h
     a = torch.empty((n_img * h * w_, kpad), dtype=torch.float16, device=x.device)
     check(_lib.load().mv_im2col3x3_f16(x.data_ptr(), cin, a.data_ptr(), kpad, n_img, h, w_, _stream()), "mv_im2col3x3_f16")
     wp = w if w.shape[1] == kpad else pad_cols(w, kpad)
-    return gemm(a, wp, bias=bias, residual=add_)
+    return gemm(a, wp, bias=bias, residual=add_, carry=True)  # conv_in opens the residual stream
 
 
 def pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:

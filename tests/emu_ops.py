@@ -77,7 +77,26 @@ def _store(val: torch.Tensor, out: Optional[torch.Tensor], dtype=torch.float16) 
     return out
 
 
-def _epilogue(acc, *, bias, rowbias, rows_per_group, residual, alpha, act, geglu):
+CARRY_MAX_C = 320  # musev_amd.ops.CARRY_MAX_C: widths of the residual stream that carry a lo half
+
+
+def _carry_store(s32: torch.Tensor, out):
+    """the carry epilogue: hi = fp16(s), lo = fp16(s - hi); lo rides on the hi tensor object (ops._carry_setup)"""
+    hi = _store(s32, out)
+    hi._mv_lo = (s32 - hi.float()).to(torch.float16)
+    return hi
+
+
+def _use_carry(carry, cols, residual):
+    return bool(carry) and cols <= CARRY_MAX_C and cols % 8 == 0
+
+
+def _res_lo(residual):
+    lo = getattr(residual, "_mv_lo", None) if residual is not None else None
+    return lo if (lo is not None and lo.shape == residual.shape) else None
+
+
+def _epilogue(acc, *, bias, rowbias, rows_per_group, residual, alpha, act, geglu, residual_lo=None):
     M = acc.shape[0]
     if bias is not None:
         acc = acc + bias.float()
@@ -92,6 +111,8 @@ def _epilogue(acc, *, bias, rowbias, rows_per_group, residual, alpha, act, geglu
         acc = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, -1)
     if residual is not None:
         acc = acc + residual.float()
+        if residual_lo is not None:
+            acc = acc + residual_lo.float()
     return acc
 
 
@@ -109,7 +130,7 @@ def fold_layernorm(w, bias, gamma, beta):
 
 
 def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=None, act=MV_ACT_NONE,
-         geglu=False, out=None, ln=None, colstats=False):
+         geglu=False, out=None, ln=None, colstats=False, carry=False):
     _mat(a, "a")
     _mat(w, "w")
     _req(w.is_contiguous(), "w must be contiguous [N, K]")
@@ -137,6 +158,9 @@ def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_group=0, residual=N
         var = (xf * xf).mean(dim=1, keepdim=True) - mean * mean
         rstd = torch.rsqrt(var.clamp_min(0.0) + eps)
         acc = rstd * (acc - mean * cs.reshape(1, -1)) + cb.reshape(1, -1)
+    if _use_carry(carry, cols, residual) and not geglu and ln is None:
+        return _carry_store(_epilogue(acc, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual, alpha=alpha,
+                                      act=act, geglu=False, residual_lo=_res_lo(residual)), out)
     return _store(_epilogue(acc, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual,
                             alpha=alpha, act=act, geglu=geglu), out)
 
@@ -161,7 +185,7 @@ def _rows(y):
 
 
 def conv3x3(x, w, n_img, h, w_, *, x2=None, stride=1, upsample=False, bias=None, rowbias=None, rows_per_group=0,
-            residual=None, out=None):
+            residual=None, out=None, carry=False):
     _mat(x, "x")
     _mat(w, "w")
     _req(x.shape[0] == n_img * h * w_, "conv3x3: x rows != n_img*h*w")
@@ -180,11 +204,14 @@ def conv3x3(x, w, n_img, h, w_, *, x2=None, stride=1, upsample=False, bias=None,
     if upsample:
         img = F.interpolate(img, scale_factor=2.0, mode="nearest")
     y = _rows(F.conv2d(img, _unpack(w, xs.shape[1], (3, 3)), None, stride=stride, padding=1))
+    if _use_carry(carry, w.shape[0], residual):
+        return _carry_store(_epilogue(y, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual, alpha=None,
+                                      act=MV_ACT_NONE, geglu=False, residual_lo=_res_lo(residual)), out)
     return _store(_epilogue(y, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual, alpha=None,
                             act=MV_ACT_NONE, geglu=False), out)
 
 
-def tconv3(x, w, b, t, hw, *, bias=None, residual=None, alpha=None, out=None):
+def tconv3(x, w, b, t, hw, *, bias=None, residual=None, alpha=None, out=None, carry=False):
     _mat(x, "x")
     _mat(w, "w")
     c = x.shape[1]
@@ -196,6 +223,9 @@ def tconv3(x, w, b, t, hw, *, bias=None, residual=None, alpha=None, out=None):
     vol = x.float().reshape(b, t, hw, 1, c).permute(0, 4, 1, 2, 3)
     y = F.conv3d(vol, _unpack(w, c, (3, 1, 1)), None, padding=(1, 0, 0))
     y = y.permute(0, 2, 3, 4, 1).reshape(b * t * hw, -1)
+    if _use_carry(carry, w.shape[0], residual):
+        return _carry_store(_epilogue(y, bias=bias, rowbias=None, rows_per_group=0, residual=residual, alpha=alpha,
+                                      act=MV_ACT_NONE, geglu=False, residual_lo=_res_lo(residual)), out)
     return _store(_epilogue(y, bias=bias, rowbias=None, rows_per_group=0, residual=residual, alpha=alpha,
                             act=MV_ACT_NONE, geglu=False), out)
 
@@ -304,7 +334,7 @@ def add(a, b):
     return (a.float() + b.float()).to(torch.float16)
 
 
-def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None):
+def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None, _carry=False):
     cin = x.shape[1]
     _req(x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[0] == n_img * h * w_, "conv_in: x")
     _req(w.dtype == torch.float16 and w.is_contiguous() and w.shape[1] >= 9 * cin and w.shape[0] % 8 == 0 and cin <= 16, "conv_in: w")
@@ -316,12 +346,14 @@ def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None):
         y = y + bias.float()
     if add_ is not None:
         y = y + add_.float()
+    if _carry and _use_carry(True, w.shape[0], None):
+        return _carry_store(y, None)
     return y.to(torch.float16)
 
 
 def conv3x3_cin_small_gemm(x, w, bias, n_img, h, w_, add_=None, kpad=64):
     _req(9 * x.shape[1] <= kpad and kpad % 8 == 0 and w.shape[1] in (9 * x.shape[1], kpad), "conv3x3_cin_small_gemm: bad shapes")
-    return conv3x3_cin_small(x, w, bias, n_img, h, w_, add_)
+    return conv3x3_cin_small(x, w, bias, n_img, h, w_, add_, _carry=True)  # (the GEMM form opens the residual stream with a carry)
 
 
 def pad_cols(w, k):

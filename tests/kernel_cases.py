@@ -191,6 +191,81 @@ def case_tconv3(b=2, t=5, hw=48, c=128, seed=30):
     return _cmp(f"tconv3 b{b} t{t} hw{hw} c{c}", got, ref, atol=4e-3)
 
 
+def case_carry(kind="linear", n=3, h=16, w=16, cin=64, c=320, cfg=None, seed=600, with_colstats=True):
+    """two-fp16 carry of the residual stream (mv_gemm_desc.c_lo / residual_lo): a chain of two stream-producing launches -- the first
+    opens the stream (no residual), the second adds to it -- in each of the three modes.  Checked: hi against the fp32 sum to the
+    usual fp16 bar; hi + lo against the fp32 sum to 2e-5 (1 + |ref|) -- 25 x tighter than an fp16 tensor can be (2^-11 |ref|): the
+    second launch must have picked the first one's lo half up; lo is a rounding remainder (at most half an ulp of hi); the column
+    statistics are those of hi."""
+    from musev_amd import ops
+    hw = h * w
+    M = n * hw
+    old = ops.GEMM_CFG
+    if cfg is not None:
+        ops.GEMM_CFG = cfg
+    hits = ops.CARRY_HITS
+    try:
+        # launch 1 (opens the stream, values of magnitude ~12 like the level-0 stream of the noise-predictor weights): linear, bias only
+        a0 = _rand((M, 64), seed)
+        w0 = _rand((c, 64), seed + 1, 12.0 / 8.0)
+        b0 = _rand((c,), seed + 2)
+        s1 = ops.gemm(a0, w0, bias=b0, carry=True)
+        ref1 = a0.float() @ w0.float().t() + b0.float()
+        # launch 2: f(x) + stream
+        if kind == "conv":
+            x = _rand((M, cin), seed + 3)
+            wt = _rand((c, cin, 3, 3), seed + 4, 1.0 / math.sqrt(9 * cin))
+            bias = _rand((c,), seed + 5)
+            temb = _rand((n, c), seed + 6)
+            s2 = ops.conv3x3(x, ops.pack_conv_weight(wt), n, h, w, bias=bias, rowbias=temb, rows_per_group=hw, residual=s1, carry=True)
+            f = F.conv2d(x.float().reshape(n, h, w, cin).permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1) + temb.float()[:, :, None, None]
+            f = f.permute(0, 2, 3, 1).reshape(M, c)
+        elif kind == "tconv":
+            x = _rand((M, c), seed + 3)  # (b = 1, t = n)
+            wt = _rand((c, c, 3, 1, 1), seed + 4, 1.0 / math.sqrt(3 * c))
+            bias = _rand((c,), seed + 5)
+            s2 = ops.tconv3(x, ops.pack_conv_weight(wt), 1, n, hw, bias=bias, residual=s1,
+                            alpha=torch.tensor([-0.7], dtype=torch.float32, device=DEV), carry=True)
+            vol = x.float().reshape(1, n, hw, 1, c).permute(0, 4, 1, 2, 3)
+            f = 0.7 * F.conv3d(vol, wt.float(), bias.float(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(M, c)
+        else:
+            x = _rand((M, cin), seed + 3)
+            wt = _rand((c, cin), seed + 4, 1.0 / math.sqrt(cin))
+            bias = _rand((c,), seed + 5)
+            s2 = ops.gemm(x, wt, bias=bias, residual=s1, colstats=with_colstats, carry=True)
+            f = x.float() @ wt.float().t() + bias.float()
+    finally:
+        ops.GEMM_CFG = old
+    name = f"carry {kind} cfg{cfg} M{M} c{c}"
+    if ops.CARRY_HITS != hits + 2 or getattr(s1, "_mv_lo", None) is None or getattr(s2, "_mv_lo", None) is None:
+        return {"name": name, "ok": False, "max_abs_err": float("nan"), "detail": "a launch did not take the carry path"}
+    ref2 = f + ref1
+    results = [_cmp(name + " hi1", s1, ref1, atol=4e-3), _cmp(name + " hi2", s2, ref2, atol=6e-3)]
+    for nm, t, ref in (("1", s1, ref1), ("2", s2, ref2)):
+        both = t.float() + t._mv_lo.float()
+        results.append(_cmp(name + f" hi{nm} + lo{nm}", both, ref, atol=2e-5, rtol=2e-5))
+        # lo is a rounding remainder: at most half an ulp of hi (|hi| 2^-11; its own rounding can land it exactly on the half)
+        worst = (t._mv_lo.float().abs() - (t.float().abs() * 2.0 ** -11 + 2.0 ** -25)).max().item()
+        results.append({"name": name + f" |lo{nm}| <= ulp(hi{nm}) / 2", "ok": worst <= 0.0, "max_abs_err": max(worst, 0.0)})
+    if kind == "linear" and with_colstats:
+        cs = getattr(s2, "_mv_colstats", None)
+        if cs is None:
+            return {"name": name, "ok": False, "max_abs_err": float("nan"), "detail": "no column statistics next to the carry"}
+        buf, rpt = cs
+        tiles = (M + rpt - 1) // rpt
+        tf = s2.float()
+        if tiles * rpt != M:
+            tf = torch.cat([tf, tf.new_zeros(tiles * rpt - M, c)])
+        tf = tf.reshape(tiles, rpt, -1)
+        results.append(_cmp(name + " colstats of hi", buf.reshape(tiles, -1, 2), torch.stack([tf.sum(1), (tf * tf).sum(1)], dim=-1),
+                            atol=2e-3 * rpt * 16, rtol=1e-4))
+    # a residual WITHOUT a lo half (a plain fp16 tensor) under a carry launch, and the knob off
+    plain_res = s1.clone()
+    s3 = ops.gemm(a0, w0, bias=b0, residual=plain_res, carry=True)
+    results.append(_cmp(name + " residual without lo", s3.float() + s3._mv_lo.float(), ref1 + plain_res.float(), atol=2e-5, rtol=2e-5))
+    return _all_ok(results)
+
+
 def case_groupnorm(n=3, rows=200, c1=320, c2=0, silu=True, eps=1e-5, seed=40):
     from musev_amd import ops
     c = c1 + c2
@@ -652,6 +727,11 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("colstats_tconv_groupnorm", lambda: case_colstats_groupnorm(kind="tconv", n=5, h=8, w=16, c=320, seed=320)),
     ("colstats_linear_ragged_n", lambda: case_colstats_groupnorm(kind="linear", n=2, cin=320, c=640, seed=330)),
     ("colstats_every_tile", lambda: _all_ok([case_colstats_groupnorm(n=2, c=320, seed=340 + c, cfg=c) for c in range(19)])),
+    ("carry_linear", case_carry),
+    ("carry_conv", lambda: case_carry(kind="conv", seed=610)),
+    ("carry_tconv", lambda: case_carry(kind="tconv", n=5, h=8, w=16, seed=620)),
+    ("carry_ragged", lambda: case_carry(kind="linear", n=1, h=9, w=37, cin=200, c=200, seed=630)),
+    ("carry_every_tile", lambda: _all_ok([case_carry(kind=("linear", "conv", "tconv")[c_ % 3], n=2, seed=640 + c_, cfg=c_) for c_ in range(19)])),
     ("layernorm_320", lambda: case_layernorm(c=320)),
     ("layernorm_640", case_layernorm),
     ("layernorm_1280", lambda: case_layernorm(c=1280, seed=51)),
@@ -724,6 +804,9 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("colstats_l0_conv_two_src_half", lambda: case_colstats_groupnorm(n=13, h=64, w=64, cin=320, c=640, c2=320, seed=481)),
     ("colstats_l0_tconv_half", lambda: case_colstats_groupnorm(kind="tconv", n=13, h=64, w=64, c=320, seed=482)),
     ("colstats_l1_linear_half", lambda: case_colstats_groupnorm(kind="linear", n=13, h=32, w=32, cin=640, c=640, seed=483)),
+    ("carry_l0_linear_half", lambda: case_carry(kind="linear", n=13, h=64, w=64, cin=320, c=320, seed=650)),
+    ("carry_l0_conv_half", lambda: case_carry(kind="conv", n=13, h=64, w=64, cin=320, c=320, seed=651)),
+    ("carry_l0_tconv_half", lambda: case_carry(kind="tconv", n=13, h=64, w=64, c=320, seed=652)),
     ("gemm_l1_geglu", lambda: case_gemm_geglu(M=26624, C=640)),
     ("gemm_l1_out_res", lambda: case_gemm(M=26624, N=640, K=640, seed=203)),
     ("gemm_l2_out_res", lambda: case_gemm(M=6656, N=1280, K=1280, seed=204)),                    # 256x160 three-stage ring (26 x 8 blocks)
