@@ -137,7 +137,7 @@ def kernel_source_hash() -> str:
 
 
 def measured_traffic(workload: str):
-    """HBM bytes per GEMM launch from the PMC counters: collected offline by tools/gpu_profile.sh (rocprofv3 --pmc
+    """HBM bytes of the GEMM family (gemm2_kernel + split-K reduce) PER DENOISE STEP from the PMC counters: collected offline by tools/gpu_profile.sh (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command, gfx950 read correction x2 applied by
     tools/pmc_summary.py) and committed as profiles/hbm_traffic.json -- a counter pass cannot run inside the timed
     process.  The file records the hash of the kernel sources it was measured on: a measurement of OTHER code is not
@@ -151,7 +151,10 @@ def measured_traffic(workload: str):
         if fam is None or ent.get("kernel_source_hash") != kernel_source_hash():
             return None, (f"profiles/hbm_traffic.json holds no PMC measurement of this build (kernel sources {kernel_source_hash()}, "
                           f"file: {ent.get('kernel_source_hash')})")
-        return fam["hbm_bytes_per_launch"], ent.get("source")
+        per_step = ent.get("gemm_family", {}).get("hbm_bytes_per_step")
+        if per_step is None:  # (a round-3 summary: split-K reduces counted as gemm dispatches over 2 profiled steps)
+            per_step = fam["hbm_bytes_per_launch"] * fam["launches"] / 2.0
+        return per_step, ent.get("source")
     except (OSError, ValueError, KeyError):
         return None, None
 
@@ -346,13 +349,34 @@ def main():
     if args.warmup == 0:
         sync_all()
         marks["t0"] = time.perf_counter()
+    den.time_exchange = world > 1
     out = run_steps(total, make_cb(args.warmup))
+    torch.cuda.synchronize(dev)
+    local_elapsed = time.perf_counter() - marks["t0"]   # this rank's own finish (before the closing barrier): load balance / skew
     sync_all()
     elapsed = time.perf_counter() - marks["t0"]
+    multi = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=group)
         elapsed = float(tt.item())
+        # diagnostics of the one line the driver keeps: per-rank step time, the exposed part of the exchange
+        # ([wait for the slots' all-gathers + table reduce] between two HIP events per step, timed steps only), the ranks and the
+        # distinct devices the process group really spans
+        evs = den.exchange_events[-args.steps:]
+        ex_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1) if evs else 0.0
+        props = torch.cuda.get_device_properties(dev)
+        ident = hash((os.uname().nodename, getattr(props, "pci_bus_id", local_rank), local_rank)) % (1 << 31)
+        mine = torch.tensor([local_elapsed * 1e3 / args.steps, ex_ms, float(ident), float(len(shard_units(n_windows, 2, world)[rank]))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine, group=group)
+        multi = {"backend": torch.distributed.get_backend(group), "ranks": world,
+                 "distinct_devices": len({int(v[2].item()) for v in allr}),
+                 "per_rank_ms_per_step": [round(float(v[0].item()), 3) for v in allr],
+                 "per_rank_exposed_exchange_ms_per_step": [round(float(v[1].item()), 3) for v in allr],
+                 "per_rank_units": [int(v[3].item()) for v in allr],
+                 "exchange_payload": "fp32 predictions, one async all_gather_into_tensor per unit slot (<= 786 KB per unit and rank)"}
+    den.time_exchange = False
     ms_per_step = elapsed * 1e3 / args.steps
     value = T / (DENOISE_STEPS * ms_per_step / 1e3)
     finite = bool(torch.isfinite(out).all())
@@ -507,7 +531,10 @@ def main():
         roofline = {
             "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
-            "traffic": measured_traffic(workload)[0], "traffic_unit": "HBM bytes per launch (PMC)",
+            # PMC bytes of the family per step / the step's API launches: the same denominator as algorithmic_bytes_per_launch
+            "traffic": (measured_traffic(workload)[0] / max(fam_n, 1)) if measured_traffic(workload)[0] is not None else None,
+            "traffic_unit": "HBM bytes per mv_gemm_f16 launch (PMC bytes of gemm2_kernel + splitk_reduce per step / launches per step)",
+            "traffic_ratio": (measured_traffic(workload)[0] / fam_bytes) if (measured_traffic(workload)[0] is not None and fam_bytes > 0) else None,
             "traffic_source": measured_traffic(workload)[1],
             "method": f"one recorded step's {fam_n} mv_gemm_f16 launches re-issued back to back on one stream, {reps} repetitions between "
                       "one HIP event pair (device time; no per-launch host gap)",
@@ -559,7 +586,7 @@ def main():
                        "ideal_speedup_vs_1gpu_same_workload": (n_windows * 2) / max(len(s_) for s_ in shards),
                        "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
                        "output_finite": finite, "graphs": bool(graphs)},
-            "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1,
+            "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1, "multi_gpu": multi,
         }
         if args.rehearse_shared_gpu:
             line["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo: exercises the N > 1 code path only, the timings are not multi-GPU numbers"

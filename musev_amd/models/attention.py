@@ -45,6 +45,17 @@ class BasicTransformerBlock(HipModule):
     # ---- spatial: rows = (frame n, pixel p), sequences = the HW pixels of one frame ----
     def hip_forward_spatial(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool, use_ip: bool) -> torch.Tensor:
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
+        if ctx.refer_self is not None:
+            ctx.split()  # refer_self_attn_emb is handed over per CFG half
+        x_in = x
+        x, q = ctx.shared((id(self), "attn1+q"), lambda: self._self_attention_and_query(x_in, ctx, geo, reference_only))
+        ctx.split()  # the text (and the image-prompt tokens) differ between the CFG halves from here on
+        return self._cross_attention_and_ff(x, q, ctx, geo, use_ip)
+
+    def _self_attention_and_query(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool):
+        """norm1 -> reference-only self-attention -> + x, then norm2 -> to_q of the cross-attention: the part of the block that
+        does not see the text (shared by the CFG halves in the first block of the network, runtime.PrefixMemo)"""
+        c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
         a1 = self.attn1
         qkv = ln_linear(a1, "qkv", x, self.norm1, a1.build_qkv)  # norm1 folded into the fused q/k/v projection where it pays
         k, v = qkv[:, c:2 * c], qkv[:, 2 * c:]
@@ -66,9 +77,12 @@ class BasicTransformerBlock(HipModule):
             segs.append((rkv[:, :c], rkv[:, c:], n_ref, geo.t, 1, 0))
         att = ops.attention(qkv[:, :c], segs, geo.n, geo.hw, h, d, a1.scale)
         x = a1.project_out(att, residual=x)
-
         a2 = self.attn2
-        q = ln_linear(a2, "q", x, self.norm2, lambda: lin_w(a2.to_q).contiguous())
+        return x, ln_linear(a2, "q", x, self.norm2, lambda: lin_w(a2.to_q).contiguous())
+
+    def _cross_attention_and_ff(self, x: torch.Tensor, q: torch.Tensor, ctx: Ctx, geo: Geo, use_ip: bool) -> torch.Tensor:
+        c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
+        a2 = self.attn2
         cache = a2._cache()
         # K/V of the prompt: constant over the denoise loop -> projected once per (prompt tensor, weights)
         tkv = cache.setdefault("text_kv", SourceCache()).get(ctx.text_src, lambda _s: ops.gemm(ctx.text, a2.w_kv()))

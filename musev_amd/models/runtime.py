@@ -38,6 +38,47 @@ class Geo:
         return Geo(self.b, self.t, self.h * 2, self.w * 2)
 
 
+class PrefixMemo:
+    """The part of a window forward that does not depend on the CFG half, computed once for both halves.
+
+    The loop hands both classifier-free-guidance halves the SAME latents (`latent_model_input = torch.cat([latents] * 2)`,
+    pipeline_controlnet.py:1908-1910) and the same timestep; the halves only start to differ at the first text cross-attention.
+    Everything before it -- conv_in, transformer_in, the first ResnetBlock2D / TemporalConvLayer, the first Transformer2DModel's
+    norm / proj_in / reference-only self-attention / to_q -- is the same arithmetic on the same values twice.  The first half's
+    forward RECORDS those tensors (``get`` computes and stores), the second half's forward REPLAYS them (``get`` returns the stored
+    tensor) and starts computing at the split.  Bit-identical to computing them twice; the model calls ``split()`` before the first
+    use of anything that may differ between the halves (text, per-half conditioning tensors), which closes the memo: from then on
+    ``get`` just computes.  ``on_split`` lets the caller order its streams (the second half's stream waits there)."""
+
+    def __init__(self):
+        self.store = {}
+        self.replaying = False
+        self.closed = False
+        self.on_split = None
+        self.hits = 0
+
+    def get(self, key, fn):
+        if self.closed:
+            return fn()
+        if not self.replaying:
+            v = self.store[key] = fn()
+            return v
+        self.hits += 1
+        return self.store[key]
+
+    def split(self) -> None:
+        if self.closed:
+            return
+        self.closed = True
+        if not self.replaying and self.on_split is not None:
+            self.on_split()
+
+    def replay(self) -> "PrefixMemo":
+        """arm the memo for the second half's forward"""
+        self.replaying, self.closed = True, False
+        return self
+
+
 @dataclass
 class Ctx:
     """Everything a block needs besides its activations."""
@@ -61,6 +102,16 @@ class Ctx:
     # the top of the forward ([frames, sum of C_out]); a block takes its column slice.  (39 one-tile launches with
     # M = 26 rows, each a serial 20-step K loop, become 2 launches that fill the chip.)
     emb_proj: Optional[Dict[int, torch.Tensor]] = None
+    memo: Optional[PrefixMemo] = None   # shared CFG prefix (see PrefixMemo); None = every call computes
+
+    def shared(self, key, fn):
+        """``fn()``, computed once for both CFG halves while the forward is still in its half-independent prefix"""
+        return fn() if self.memo is None else self.memo.get(key, fn)
+
+    def split(self) -> None:
+        """the next operation may depend on the CFG half: the shared prefix ends here"""
+        if self.memo is not None:
+            self.memo.split()
 
     def proj_for(self, module) -> Optional[torch.Tensor]:
         return None if self.emb_proj is None else self.emb_proj.get(id(module))

@@ -39,9 +39,11 @@ class Transformer2DModel(HipModule):
         self.reference_only = True  # set by UNet3DConditionModel from t2i_ip_adapter_attn_processor
 
     def hip_forward(self, x: torch.Tensor, ctx: Ctx, geo: Geo) -> torch.Tensor:
-        h = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.n, geo.hw, eps=self.norm.eps, silu=False,
-                          groups=self.norm.num_groups)
-        h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in))
+        def stem():
+            g = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.n, geo.hw, eps=self.norm.eps, silu=False,
+                              groups=self.norm.num_groups)
+            return ops.gemm(g, lin_w(self.proj_in), bias=lin_b(self.proj_in))
+        h = ctx.shared((id(self), "stem"), stem)
         for blk in self.transformer_blocks:
             h = blk.hip_forward_spatial(h, ctx, geo, self.reference_only, self.ip_adapter_cross_attn)
         return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, colstats=True, carry=True)

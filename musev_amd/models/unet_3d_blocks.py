@@ -69,9 +69,10 @@ class CrossAttnDownBlock3D(nn.Module):
         outs = []
         i = -1
         for i, (res, tconv, attn, tattn) in enumerate(zip(self.resnets, self.temp_convs, self.attentions, self.temp_attentions)):
-            x = res.hip_forward(x, None, ctx, geo)
+            # (ctx.shared: computed once for both CFG halves until the first cross-attention closes the shared prefix -- runtime.PrefixMemo)
+            x = ctx.shared((id(self), i, "res"), lambda x=x, res=res: res.hip_forward(x, None, ctx, geo))
             if tconv is not None:
-                x = tconv.hip_forward(x, ctx, geo)
+                x = ctx.shared((id(self), i, "tconv"), lambda x=x, tconv=tconv: tconv.hip_forward(x, ctx, geo))
             x = attn.hip_forward(x, ctx, geo)
             if tattn is not None:
                 x = tattn.hip_forward(x, ctx, geo)

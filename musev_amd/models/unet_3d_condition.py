@@ -341,7 +341,7 @@ class UNet3DConditionModel(HipModule):
                      vision_conditon_frames_sample_index=None, sample_frame_rate=10, skip_temporal_layers=None,
                      frame_index=None, down_block_refer_embs=None, mid_block_refer_emb=None, refer_self_attn_emb=None,
                      refer_self_attn_emb_mode: str = "read", vision_clip_emb=None, ip_adapter_scale: float = 1.0, face_emb=None, ip_adapter_face_emb=None,
-                     ip_adapter_face_scale: float = 1.0, pose_guider_emb=None) -> torch.Tensor:
+                     ip_adapter_face_scale: float = 1.0, pose_guider_emb=None, prefix_memo=None) -> torch.Tensor:
         """The network on channels-last rows: x fp16 [(b t h w), in_channels] -> fp32 [(b t h w), out_channels] (the
         fp32 accumulator of conv_out, unrounded: CFG and the scheduler amplify the prediction's last-bit error).
         Used directly by musev_amd.pipelines.parallel_denoise (which builds window inputs in this layout)."""
@@ -419,24 +419,28 @@ class UNet3DConditionModel(HipModule):
         ctx = Ctx(emb_proj=emb_proj, temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
                   clip=clip, clip_len=clip_len, ip_scale=float(ip_adapter_scale), skip_temporal=False,
                   text_src=encoder_hidden_states, clip_src=vision_clip_emb, face=face, face_len=face_len,
-                  face_scale=float(ip_adapter_face_scale), face_src=ip_adapter_face_emb, refer_self=refer_self)
+                  face_scale=float(ip_adapter_face_scale), face_src=ip_adapter_face_emb, refer_self=refer_self, memo=prefix_memo)
 
         # ---- 2. pre-process (:1008-1063) ----
         pose = None
         if pose_guider_emb is not None:
+            ctx.split()  # a per-half conditioning tensor: nothing is shared between the CFG halves (runtime.PrefixMemo)
             pose = pose_guider_emb.to(torch.float16).permute(0, 2, 3, 1).reshape(geo.rows, ch0).contiguous()
         w_in = self.packed("conv_in", lambda: ops.pack_conv_weight(self.conv_in.weight.detach()))
+        x_in = x
         if 9 * self.conv_in.in_channels <= 64:  # latent input (4 channels): im2col + one MFMA K step
             w_in = self.packed("conv_in64", lambda: ops.pad_cols(w_in, 64))
-            x = ops.conv3x3_cin_small_gemm(x, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose)
+            x = ctx.shared("conv_in", lambda: ops.conv3x3_cin_small_gemm(x_in, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose))
         else:
-            x = ops.conv3x3_cin_small(x, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose)
+            x = ctx.shared("conv_in", lambda: ops.conv3x3_cin_small(x_in, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose))
         self._tap("conv_in", x, geo)
         if self.need_transformer_in:
-            x = self.transformer_in.hip_forward(x, ctx, geo)
+            x_t = x
+            x = ctx.shared("transformer_in", lambda: self.transformer_in.hip_forward(x_t, ctx, geo))
             self._tap("transformer_in", x, geo)
         use_refer = self.need_refer_emb and down_block_refer_embs is not None and not self.skip_refer_downblock_emb
         if use_refer:
+            ctx.split()  # the ReferenceNet features are handed over per CFG half
             x = self.first_refer_emb_attns.hip_forward(x, down_block_refer_embs[0], geo)
 
         # ---- 3. down (:1076-1156) ----
@@ -449,6 +453,7 @@ class UNet3DConditionModel(HipModule):
                 start = 1 + num_block * i
                 refer = down_block_refer_embs[start:start + num_block]
             x, geo, outs = blk.hip_forward(x, ctx, geo, refer)
+            ctx.split()  # (at the latest: only the first down block's layers are wrapped in ctx.shared)
             skips.extend(o for o, _ in outs)
             for j, (o, g_) in enumerate(outs):
                 self._tap(f"down_blocks.{i}.out{j}", o, g_)

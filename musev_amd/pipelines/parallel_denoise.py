@@ -25,6 +25,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .. import ops
+from ..models.runtime import PrefixMemo
 from ..schedulers.scheduling_ddim import DDIMScheduler  # default; EulerDiscreteScheduler offers the same loop interface
 from ..utils.timesteps_util import generate_parameters_with_timesteps
 from .context import prepare_global_context
@@ -62,11 +63,14 @@ def group_units(units: Sequence[Unit]) -> List[Tuple[int, List[int]]]:
 class ParallelDenoiser:
     _device_check = True  # tests of the sharding logic (gloo, CPU, fake kernels) switch this off
     always_exchange = False  # diagnostic: take the multi-rank exchange path in a 1-rank group as well (see __call__)
+    time_exchange = False    # diagnostic (bench.py): HIP event pairs around [wait for the slots' all-gathers + table reduce] of every step
+    exchange_events: list = []
 
     def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, *, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
                  context_batch_size: int = 1, use_graphs: bool = True):
         self.unet = unet
+        self.exchange_events = []
         # hipGraph capture of the per-window UNet forward (~1 500 kernel launches): replayed once per window and step,
         # so the host only issues the loop glue.  A failed capture raises (MUSEV_NO_GRAPH=1 / use_graphs=False = eager on purpose).
         self.use_graphs = use_graphs and os.environ.get("MUSEV_NO_GRAPH", "0") != "1"  # env knob for per-kernel PMC profiling
@@ -74,6 +78,8 @@ class ParallelDenoiser:
         # the two CFG halves of a window as two batch-1 forwards on two HIP streams (+2.7 % frames/s at config 2,
         # profiles/r01j): MUSEV_HALF_STREAMS=0 restores the single batch-2 forward (per-kernel profiling)
         self.half_streams = os.environ.get("MUSEV_HALF_STREAMS", "1") == "1"
+        # the half-independent front of the network once for both CFG halves of a window (see _unet_rows; MUSEV_SHARE_PREFIX=0: A/B)
+        self.share_cfg_prefix = os.environ.get("MUSEV_SHARE_PREFIX", "1") == "1"
         # A rank with an ODD number of units (24 units over 8 GPUs = 3) owns one two-half window and one lone half.  Run one after
         # the other the lone batch-1 forward has the GPU to itself at ~0.65 of a pair's time; run CONCURRENTLY with the neighbouring
         # pair (its graph replayed on a third stream) three half-forwards share the GPU like a pair and a half.  Used from the second
@@ -257,8 +263,9 @@ class ParallelDenoiser:
                 if controlnet is not None and cn_on:
                     ctrl_bufs[wl].copy_(ctrl_frames[wi])
                     cn_ = (controlnet, ctrl_bufs[wl], text_rep_by_len[wl], cond_scale, bool(guess_mode))
+                # (window_gather builds every owned half from the same latents: the halves' inputs are identical)
                 return self._unet_rows(x, tuple(hs), halves, tw, h, w, t_dev, embeds, sub_idx_by_len[wl], vis_idx, motion_speed,
-                                       unet_kwargs, cn_)
+                                       unet_kwargs, cn_, same_input=True)
 
             def consume(wi, hs, eps):
                 nonlocal slot
@@ -303,10 +310,17 @@ class ParallelDenoiser:
             if exchange:
                 for k in range(slot, max_units):  # a rank with fewer units still takes part in every slot's collective
                     works.append(torch.distributed.all_gather_into_tensor(recv[k].view(-1), send[k].view(-1), group=group, async_op=True))
+                ev = None
+                if self.time_exchange and lat.is_cuda:  # bench.py --gpus N: the exposed part of the exchange, per step
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 for wk in works:
                     wk.wait()  # stream dependency for RCCL (no host block)
                 works.clear()
                 ops.window_units_reduce(recv.view(max_units * world, win_len * hw, c), cover, eps_acc)  # table order -> bit-identical replicas
+                if ev is not None:
+                    ev[1].record()
+                    self.exchange_events.append(ev)
             sched.loop_update(lat, eps_acc, counter, guidance[step], step, t)
             # the reference draws this (unused) tensor with the model output's dtype = the UNet's (:120-131), whatever the caller's latents are
             sched.consume_step_noise((1, c, T, h, w), self._unet_dtype(), dev, generator, noise_type, w_ind_noise)
@@ -319,14 +333,16 @@ class ParallelDenoiser:
         return out
 
     def _unet_rows(self, x, hs: tuple, halves: int, tw: int, h: int, w: int, t_dev, embeds, sub_idx, vis_idx, motion_speed,
-                   unet_kwargs: dict, cn=None) -> torch.Tensor:
+                   unet_kwargs: dict, cn=None, same_input: bool = False) -> torch.Tensor:
         """one UNet forward on window rows (preceded by the ControlNet forward on the same rows when ``cn`` is set);
         hipGraph-replayed when the call signature was captured before"""
         ehs = embeds[hs[0]:hs[-1] + 1] if len(hs) == 2 else embeds[hs[0]:hs[0] + 1]
         kw = {k: (self._slice_half(v, list(hs), halves) if k in _PER_HALF_KWARGS else v) for k, v in unet_kwargs.items()}
 
-        def one(inp, nb, e, k, first_half=None):
+        def one(inp, nb, e, k, first_half=None, memo=None):
             first_half = hs[0] if first_half is None else first_half
+            if memo is not None:
+                k = dict(k, prefix_memo=memo)
             if cn is not None:
                 net, ctrl, text_rep, scale, guess = cn
                 # guess mode: the ControlNet sees only the text-conditioned half, the unconditional half gets no residuals
@@ -364,17 +380,37 @@ class ParallelDenoiser:
             # of the prompt): the FIRST forward of a signature -- and the first after any parameter / pack-epoch change --
             # runs both halves on ONE stream, so no stream ever reads a cache another stream is still filling.
             wkey = (sig, _pack_epoch(), _param_epoch(self.unet), None if cn is None else _param_epoch(cn[0]))
+            # Shared CFG prefix (models/runtime.PrefixMemo): the loop hands both halves the same latents and timestep, so everything
+            # in front of the first text cross-attention is computed by the first half's forward and replayed by the second's
+            # (bit-identical to computing it twice).  Not with a ControlNet in the call (its residual inputs are per half).
+            memo = PrefixMemo() if (self.share_cfg_prefix and cn is None and same_input) else None
             if wkey not in self._warm:
                 if len(self._warm) >= 64:
                     self._warm.clear()
-                e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0])
-                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
+                e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0], memo)
+                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1], None if memo is None else memo.replay())
                 self._warm[wkey] = True
                 return torch.cat([e0, e1], dim=0)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
-            e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0])
+            if memo is None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
+                e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0])
+            else:
+                # the first half runs on the main stream and marks the end of the shared prefix with an event; the side stream's
+                # forward starts there, on the recorded tensors
+                split_ev = torch.cuda.Event()
+                memo.on_split = lambda: split_ev.record(main)
+                e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0], memo)
+                if not memo.closed:
+                    raise RuntimeError("the UNet forward never closed the shared CFG prefix")
+                side.wait_event(split_ev)
+                with torch.cuda.stream(side):
+                    for v in memo.store.values():
+                        for t_ in (v if isinstance(v, (tuple, list)) else (v,)):
+                            if torch.is_tensor(t_):
+                                t_.record_stream(side)
+                    e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1], memo.replay())
             main.wait_stream(side)
             e1.record_stream(main)
             return torch.cat([e0, e1], dim=0)

@@ -196,6 +196,51 @@ def test_denoise_loop_over_the_module(scheduler, emulated):
     assert torch.equal(got[:, :, 0].float(), want[:, :, 0])
 
 
+@pytest.mark.parametrize("name", ["musev_hipw", "refnet_hipw", "musev_hipw_refer_self"])
+def test_shared_cfg_prefix_is_bit_identical_to_two_forwards(name, emulated):
+    """models/runtime.PrefixMemo: the first CFG half's forward records everything in front of the first text cross-attention, the
+    second half's forward replays it.  Checked on the emulated kernels: both halves' outputs are bit-identical to two independent
+    batch-1 forwards; the `musev` flavour really shares (conv_in, transformer_in, the first resnet / temporal conv, the first
+    block's self-attention and query); flavours / calls whose front depends on per-half tensors (ReferenceNet features,
+    refer_self_attn_emb) share only what precedes them."""
+    from oracle import unet3d
+    from musev_amd.models.runtime import PrefixMemo
+    from musev_amd.models.unet_loader import load_unet_by_name
+    case = UNET_CASES[name]
+    _widths(emulated, case["arch"])
+    cfg = case_config(case)
+    sd = unet3d.init_state_dict(cfg, case["weight_seed"])
+    x, t, ehs, ckw = case_inputs(case, cfg)
+    unet = _cpu(load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]))
+    if case.get("refer_self"):
+        unet.insert_spatial_self_attn_idx()
+    b, c, tt, h, w = x.shape
+    x = x[:1].repeat(2, 1, 1, 1, 1)  # the loop's CFG duplication: both halves see the same latents
+    rows = x.permute(0, 2, 3, 4, 1).reshape(b * tt * h * w, c).to(torch.float16).contiguous()
+    half = rows.shape[0] // 2
+
+    from musev_amd.pipelines.parallel_denoise import _PER_HALF_KWARGS, ParallelDenoiser
+
+    def forward(i, memo):
+        kw = {k: (ParallelDenoiser._slice_half(v, [i], 2) if k in _PER_HALF_KWARGS else v) for k, v in ckw.items()}
+        return unet.forward_rows(rows[i * half:(i + 1) * half], 1, tt, h, w, t, ehs[i:i + 1], prefix_memo=memo, **kw)
+
+    plain = [forward(0, None), forward(1, None)]
+    memo = PrefixMemo()
+    splits = []
+    memo.on_split = lambda: splits.append(len(memo.store))
+    shared = [forward(0, memo)]
+    assert memo.closed and len(splits) == 1
+    shared.append(forward(1, memo.replay()))
+    assert memo.closed
+    for a, b_ in zip(plain, shared):
+        assert torch.equal(a, b_)
+    if name == "musev_hipw":
+        assert memo.hits == len(memo.store) >= 5, (memo.hits, list(memo.store))
+    elif name == "refnet_hipw":
+        assert memo.hits == len(memo.store) == 1   # conv_in only: the ReferenceNet features come per half right behind it
+
+
 @pytest.mark.parametrize("one_half_per_forward", [True, False])
 def test_denoise_loop_slices_refer_self_attn_emb_per_cfg_half(one_half_per_forward, emulated):
     """refer_self_attn_emb ("read", attention.py:261-289) is a list of [2 b, c, t, h, w] tensors batched over the CFG halves: the loop

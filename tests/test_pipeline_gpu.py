@@ -22,6 +22,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+FREE_RUNNING_BAR = 1e-2   # north_star: |delta latent|max < 1e-2 on the loop's OUTPUT (free-running, every step)
+
 ARCH = dict(block_out_channels=(320, 640), layers_per_block=1,
             down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"), up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
 
@@ -255,27 +257,36 @@ def test_twenty_step_drift_against_fp16_torch_floor():
     #     in the same run, plus the cap the at-size test uses
     for a, b in zip(d_hip, d_f16):
         assert a <= 1.0 * b + 2e-3, (d_hip, d_f16)
-    assert max(d_hip) < 2e-2, f"|delta latent|max per step: {d_hip}"
+    # round 4: with the two-fp16 carry on the residual stream the free-running drift itself is inside the north-star bar (the CPU
+    # ensemble profiles/r04b_loop_rounding_ensemble.json: 7.2e-3 ... 9.6e-3 with the carry, 1.0e-2 ... 1.5e-2 for any plain fp16 forward)
+    assert max(d_hip) < FREE_RUNNING_BAR, f"|delta latent|max per step: {d_hip}"
 
 
-def test_config2_loop_at_size_matches_reference_unet_loop_golden():
-    """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, the first 4
-    steps of the 20-step DDIM schedule, full-width `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the
-    HIP loop against those recorded by tests/golden/make_loop_goldens.py (oracle loop around the REFERENCE'S OWN
-    UNet3DConditionModel, fp32 on the CPU): ABSOLUTE |delta latent|max < 1e-2 at every step; the replay is bit-identical."""
+@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop"])
+def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
+    """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, full-width
+    `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the HIP loop against those recorded by
+    tests/golden/make_loop_goldens.py (oracle loop around the REFERENCE'S OWN UNet3DConditionModel, fp32 on the CPU):
+    `musev_cfg2_loop20` = the WHOLE 20-step DDIM schedule, `musev_cfg2_loop` = its first 4 steps.  Asserted: free-running
+    ABSOLUTE |delta latent|max < 1e-2 at EVERY step (the metric's output bar; the two-fp16 carry on the residual stream is what
+    makes it reachable, profiles/r04b_loop_rounding_ensemble.json); every step started from the reference's latents < 1e-2; the
+    graph replay is bit-identical."""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import json
     import os
 
     import numpy as np
     from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict
     from musev_amd.models.unet_loader import load_unet_by_name
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
-    name = "musev_cfg2_loop"
     case = LOOP_CASES_AT_SIZE[name]
+    path = os.path.join(os.path.dirname(__file__), "golden", f"reference_loop_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated (tests/golden/make_loop_goldens.py --case {name}: hours of CPU)")
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg, sd = loop_case_state_dict(case)
     latents, cond, prompt = loop_case_inputs(case)
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_loop_{name}.npz"))
+    gold = np.load(path)
     dev = torch.device("cuda", 0)
     unet = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16).to(dev)
     del sd
@@ -291,12 +302,9 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden():
         runs.append(rec)
     assert len(runs[0]) == case["steps"]
     errs = [(r - torch.from_numpy(gold[f"latents_step{i + 1}"])).abs().max().item() for i, r in enumerate(runs[0])]
-    print("config 2 at size, per-step |delta latent|max:", ["%.2e" % e for e in errs],
+    print(f"{name}: free-running per-step |delta latent|max:", ["%.2e" % e for e in errs],
           "| |latent|max", ["%.2f" % float(np.abs(gold[f"latents_step{i + 1}"]).max()) for i in range(case["steps"])])
     assert all(torch.equal(a, b) for a, b in zip(*runs)), "graph replay must reproduce the eager first call bit for bit"
-    # free-running, the fp16 error accumulates over the steps (measured 6.4e-3 / 9.3e-3 / 1.05e-2 / 1.30e-2, profiles/r03f; CFG 3.5
-    # multiplies every forward error by up to 6): bounded at 2e-2 here, and the north-star bar is asserted per step below
-    assert max(errs) < 2e-2, errs
     forced = []
     prev = latents
     for i in range(case["steps"]):
@@ -305,8 +313,18 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden():
         want = torch.from_numpy(gold[f"latents_step{i + 1}"])
         forced.append((out.float().cpu() - want).abs().max().item())
         prev = want
-    print("config 2 at size, per-step |delta latent|max from the reference loop's latents:", ["%.2e" % e for e in forced])
+    print(f"{name}: per-step |delta latent|max from the reference loop's latents:", ["%.2e" % e for e in forced])
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    from musev_amd import ops
+    with open(os.path.join(out_dir, f"loop_at_size_{name}.json"), "w") as f:
+        json.dump({"case": name, "config": "BASELINE config 2: musev, 512x512, 12 + 1 frames, guidance 3.5, 20-step DDIM schedule",
+                   "golden": "oracle loop around the reference's own UNet3DConditionModel, fp32 CPU (tests/golden/make_loop_goldens.py)",
+                   "carry": bool(ops.CARRY), "colstats": bool(ops.COLSTATS), "ln_fold": bool(ops.LN_FOLD),
+                   "free_running_abs_max": errs, "per_step_from_reference_latents": forced,
+                   "latent_absmax": [float(np.abs(gold[f"latents_step{i + 1}"]).max()) for i in range(case["steps"])]}, f, indent=1)
     assert max(forced) < 1e-2, forced
+    assert max(errs) < FREE_RUNNING_BAR, errs
 
 
 def test_odd_unit_lane_is_bit_identical_to_running_the_groups_in_turn(monkeypatch):

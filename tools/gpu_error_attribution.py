@@ -136,8 +136,8 @@ def main():
         from musev_amd import ops
         from musev_amd.models.unet_loader import load_unet_by_name
         model = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]).to(dev)
-        for cs, fold in ((True, True), (False, True), (True, False), (False, False)):
-            ops.COLSTATS, ops.LN_FOLD = cs, fold
+        for carry, cs, fold in ((True, True, True), (False, True, True), (True, False, True), (True, True, False), (False, False, False)):
+            ops.CARRY, ops.COLSTATS, ops.LN_FOLD = carry, cs, fold
             ops._ln_fold_cache.clear()
             taps = {}
             model._collect = taps
@@ -153,12 +153,13 @@ def main():
                     # the carrier features (calibrate_as_denoiser: channels 0..7 of the level-0 stream) next to the rest
                     entry["taps"][name] = {"max": d.max().item(), "rms": d.pow(2).mean().sqrt().item(), "ref_absmax": r.abs().max().item(),
                                            "max_ch0_7": d[:, :8].max().item() if d.shape[1] >= 8 else None}
-            report["hip"][f"colstats={int(cs)} ln_fold={int(fold)}"] = entry
-            print(f"  HIP colstats={int(cs)} ln_fold={int(fold)}: |d eps|max {entry['out']['max']:.3e} p99.9 {entry['out']['p999']:.3e} rms {entry['out']['rms']:.3e}", flush=True)
+            report["hip"][f"carry={int(carry)} colstats={int(cs)} ln_fold={int(fold)}"] = entry
+            print(f"  HIP carry={int(carry)} colstats={int(cs)} ln_fold={int(fold)}: |d eps|max {entry['out']['max']:.3e} p99.9 {entry['out']['p999']:.3e} rms {entry['out']['rms']:.3e}", flush=True)
             if cs and fold:
+                print(f"    taps, carry={int(carry)}:")
                 for name, e in entry["taps"].items():
                     print(f"      tap {name:22s} |d|max {e['max']:.3e} (channels 0-7: {e['max_ch0_7']:.3e})  rms {e['rms']:.3e}  |ref|max {e['ref_absmax']:.2f}", flush=True)
-        ops.COLSTATS, ops.LN_FOLD = True, True
+        ops.CARRY, ops.COLSTATS, ops.LN_FOLD = True, True, True
         ops._ln_fold_cache.clear()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
