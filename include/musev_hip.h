@@ -124,6 +124,30 @@ int mv_gemm_config_desc(int cfg, int32_t* desc5);
  * Host-side evaluation of that map (launches nothing): tile_m[b], tile_n[b] of workgroup b, for b < tiles_m*tiles_n */
 int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int32_t* tile_n);
 
+/* ---- feed-forward of a BasicTransformerBlock as one launch (K5 + K7 + K3) ------------------------------
+ * replaces: norm3 -> ff (FeedForward(GEGLU) of diffusers) -> + hidden_states in BasicTransformerBlock.forward
+ *   (musev/models/attention.py:398-429) for the 320-channel (level 0) stream:
+ *     out = residual + ( GEGLU( LayerNorm(x) W1^T + b1 ) ) W2^T + b2
+ * w1 / bias1: the GEGLU-packed first projection ([16 value rows | 16 gate rows] blocks, as mv_gemm_f16's geglu epilogue takes
+ * it).  The normalised rows and the [M, 4 C] activation never leave the compute unit.  C = 320, hidden = 1280 only
+ * (MV_ERR_INVALID otherwise: the caller keeps the three-launch form there). */
+typedef struct mv_ffn_desc {
+    const void* x;           /* fp16 [M][ldx], C columns: the rows norm3 reads                                  */
+    const void* ln_gamma;    /* fp16 [C], 16-byte aligned                                                       */
+    const void* ln_beta;     /* fp16 [C], 16-byte aligned                                                       */
+    const void* w1;          /* fp16 [2 H][C] packed                                                            */
+    const void* bias1;       /* fp16 [2 H] packed like w1's rows, or NULL                                       */
+    const void* w2;          /* fp16 [C][H] (torch Linear layout)                                               */
+    const void* bias2;       /* fp16 [C] or NULL                                                                */
+    const void* residual;    /* fp16 [M][ldr] (the block passes x)                                              */
+    void* out;               /* fp16 [M][ldo]                                                                   */
+    int64_t M;
+    int32_t C, H;            /* 320, 1280                                                                       */
+    int32_t ldx, ldr, ldo;   /* leading dimensions in elements (multiples of 8)                                 */
+    float ln_eps;
+} mv_ffn_desc;
+int mv_ffn_geglu_f16(const mv_ffn_desc* d, void* stream);
+
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
  * replaces: torch.nn.GroupNorm(32, C)(+SiLU) in ResnetBlock2D.norm1/norm2, Transformer2DModel.norm
  *   (musev/models/transformer_2d.py:260), TransformerTemporalModel.norm (temporal_transformer.py:117,239),
@@ -133,11 +157,14 @@ int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int
  * y: [n_items][rows][c1+c2].  Three launches: statistics (per-split group partials), fold, apply.
  * partial: fp32 scratch [n_items][nsplit][num_groups][2]; stat: fp32 scratch [n_items][num_groups][2] (mean, rstd).
  * gamma / beta 16-byte aligned.
+ * x1_lo / y_lo (optional, single source, the three-launch form): the lo halves of a two-fp16 carry (see mv_gemm_desc.c_lo) -- the
+ *   apply pass normalises hi + lo in fp32 and writes y = fp16(v), y_lo = fp16(v - y) (leading dimensions ld1 / ldy): conv_norm_out
+ *   reads the carried residual stream and hands the output convolution ~22 bits (unet_3d_condition.py:1258-1263).
  */
 int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                      int64_t n_items, int64_t rows, int32_t num_groups, float eps,
                      const void* gamma, const void* beta, int32_t silu,
-                     void* y, int32_t ldy, float* partial, int32_t nsplit, float* stat, void* stream);
+                     void* y, int32_t ldy, float* partial, int32_t nsplit, float* stat, const void* x1_lo, void* y_lo, void* stream);
 /* the same with the statistics folded from producer-side column statistics (mv_gemm_desc.colstats) instead of a pass over x:
  * cs1 = colstats of the launch that wrote x1 (its N == c1, row tiles of rpt1 rows, rows %% rpt1 == 0), cs2 / rpt2 those of
  * x2 (required when x2 != NULL).  Two launches: fold (one block per (item, group)), apply.  Slabs small enough for the
@@ -145,7 +172,8 @@ int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int
 int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                         int64_t n_items, int64_t rows, int32_t num_groups, float eps,
                         const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
-                        const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, void* stream);
+                        const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, int32_t nsplit, float* stat,
+                        const void* x1_lo, void* y_lo, void* stream);
 /* scratch size (in floats) of `partial` for the call above */
 int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_groups, int32_t nsplit);
 int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c);
@@ -214,8 +242,9 @@ int mv_conv3x3_cin_small_f16(const void* x, int32_t cin, const void* w /* [cout]
 /* im2col of a 3x3 / pad-1 convolution with tiny Cin: y[pix][tap*cin + ci], zero-filled up to kpad columns (kpad % 8 == 0);
  * conv_in then is mv_gemm_f16(LINEAR) with the weight rows zero-padded to kpad.                                          */
 int mv_im2col3x3_f16(const void* x, int32_t cin, void* y, int32_t kpad, int64_t n_img, int32_t h, int32_t w_, void* stream);
-/* y: [rows][cout] fp16, or fp32 when y_is_f32 (the UNet's noise prediction leaves the network unrounded) */
-int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
+/* y: [rows][cout] fp16, or fp32 when y_is_f32 (the UNet's noise prediction leaves the network unrounded); x_lo (optional): the lo
+ * half of a two-fp16 input (the convolution reads x + x_lo in fp32) */
+int mv_conv3x3_cout_small_f16(const void* x, const void* x_lo, int32_t cin, const void* w /* [cout][3][3][cin] */, const void* bias,
                               void* y, int32_t y_is_f32, int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream);
 
 /* direct 3x3 convolution, padding 1, stride 1 | 2, fused bias (+ SiLU when act = MV_ACT_SILU), any cin <= 455 (the 8 x 9 cin fp16 weight slab of a block must fit 64 KB of LDS), cout % 8 == 0:
@@ -247,9 +276,11 @@ int mv_bthwc_to_bcthw_f16(const void* x, int32_t x_is_f32, void* y, int32_t y_is
  * replaces: musev/pipelines/pipeline_controlnet.py:1902-1946 (gather, CFG repeat, scale_model_input (identity
  *   for DDIM), batch_concat_two_tensor_with_index).
  * latents: fp32 [C][T_total][HW] (batch 1), cond: fp32 [C][n_cond][HW].
+ * hi_lo = 1: rows of 2 C columns [fp16(v) | fp16(v - fp16(v))]: the fp32 latents as two fp16 halves -- conv_in with its weight
+ *   duplicated over the two channel groups then convolves the unrounded input (conv is linear).
  */
 int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
-                     int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, void* out, void* stream);
+                     int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, int32_t hi_lo, void* out, void* stream);
 /* mv_window_scatter_add: eps_acc[half][C][T_total][HW] += eps_win (channels-last fp16|fp32 [halves][n_cond+win][HW][C],
  *   cond frames dropped); counter[T_total] += 1.
  * replaces: pipeline_controlnet.py:2068-2078. */

@@ -40,6 +40,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("w1", C.c_void_p), ("bias1", C.c_void_p),
+        ("w2", C.c_void_p), ("bias2", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("ldx", C.c_int32), ("ldr", C.c_int32), ("ldo", C.c_int32),
+        ("ln_eps", C.c_float),
+    ]
+
+
 class AttnSeg(C.Structure):
     _fields_ = [
         ("k", C.c_void_p), ("v", C.c_void_p),
@@ -66,6 +75,7 @@ SIGNATURES = {
     "mv_abi_version": (_i32, []),
     "mv_last_error": (C.c_char_p, []),
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
+    "mv_ffn_geglu_f16": (_i32, [C.POINTER(FfnDesc), _vp]),
     "mv_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
     "mv_gemm_choice": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
     "mv_gemm_stats_layout": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
@@ -73,9 +83,9 @@ SIGNATURES = {
     "mv_gemm_config_desc": (_i32, [_i32, _vp]),
     "mv_gemm_tile_order": (_i32, [_i32, _i32, _i32, _vp, _vp]),
     "mv_groupnorm_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
-                                _vp, _i32, _vp, _vp]),
+                                _vp, _i32, _vp, _vp, _vp, _vp]),
     "mv_groupnorm_cs_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
-                            _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+                            _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mv_groupnorm_partial_floats": (_i64, [_i64, _i32, _i32]),
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),
@@ -86,14 +96,14 @@ SIGNATURES = {
     "mv_conv3x3_cin_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "mv_conv3x3_direct_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mv_im2col3x3_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
-    "mv_conv3x3_cout_small_f16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "mv_conv3x3_cout_small_f16": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
     "mv_timestep_embedding_f16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "mv_silu_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "mv_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "mv_zero_rows_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     "mv_bcthw_to_bthwc_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mv_bthwc_to_bcthw_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "mv_window_gather": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mv_window_gather": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mv_window_scatter_add": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mv_softmax_rows_f16": (_i32, [_vp, _i64, _i64, _i32, _vp]),
     "mv_window_units_reduce": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

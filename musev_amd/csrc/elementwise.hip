@@ -201,7 +201,7 @@ __global__ void im2col3x3_kernel(const half_t* x, int cin, half_t* y, int kpad, 
 
 // ---- conv3x3 with tiny Cout (conv_out: 320 -> 4): one wave per output pixel, lanes split the 9*Cin reduction ----
 template <typename OutT>
-__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x, int cin, const half_t* w,
+__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x, const half_t* x_lo, int cin, const half_t* w,
                                                                  const half_t* bias, OutT* y, int cout, long n_img,
                                                                  int h, int wd) {
     extern __shared__ __attribute__((aligned(16))) half_t swh[];  // [cout][9*cin]
@@ -224,13 +224,22 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x
             const int tap = e / oc, o = e - tap * oc;
             const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
             if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
-            half8v xv = *reinterpret_cast<const half8v*>(x + ((img * h + iy) * wd + ix) * cin + o * 8);
+            const long xoff = ((img * h + iy) * wd + ix) * cin + o * 8;
+            half8v xv = *reinterpret_cast<const half8v*>(x + xoff);
+            float xf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xf[q] = (float)xv[q];
+            if (x_lo) {  // (uniform) two-fp16 input: hi + lo in fp32
+                const half8v xl = *reinterpret_cast<const half8v*>(x_lo + xoff);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xf[q] += (float)xl[q];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j < cout) {
                     half8v wv = *reinterpret_cast<const half8v*>(swh + j * kk + tap * cin + o * 8);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[j] = fmaf((float)xv[q], (float)wv[q], acc[j]);
+                    for (int q = 0; q < 8; ++q) acc[j] = fmaf(xf[q], (float)wv[q], acc[j]);
                 }
             }
         }
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x
 // ---- sliding-window loop glue ----
 // out: channels-last fp16 [copies][n_cond + win][hw][c]; frame f < n_cond from cond[c][n_cond][hw], else latents[:, idx[f-n_cond]]
 __global__ void window_gather_kernel(const float* latents, const float* cond, const int* idx, int win, int n_cond, int c,
-                                     int t_total, int hw, int copies, half_t* out) {
+                                     int t_total, int hw, int copies, int hi_lo, half_t* out) {
     const int tw = n_cond + win;
     const long per = (long)tw * hw * c;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
@@ -262,6 +271,15 @@ __global__ void window_gather_kernel(const float* latents, const float* cond, co
         if (f < n_cond) v = cond[((long)ci * n_cond + f) * hw + p];
         else v = latents[((long)ci * t_total + idx[f - n_cond]) * hw + p];
         const half_t hv = (half_t)v;
+        if (hi_lo) {  // rows of 2 c columns: [hi | lo]
+            const half_t lv = (half_t)(v - (float)hv);
+            const long ro = r * (2 * c) + ci;
+            for (int k = 0; k < copies; ++k) {
+                out[k * 2 * per + ro] = hv;
+                out[k * 2 * per + ro + c] = lv;
+            }
+            continue;
+        }
         for (int k = 0; k < copies; ++k) out[k * per + i] = hv;
     }
 }
@@ -595,7 +613,7 @@ extern "C" int mv_im2col3x3_f16(const void* x, int32_t cin, void* y, int32_t kpa
     return MV_OK;
 }
 
-extern "C" int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void* w, const void* bias, void* y, int32_t y_is_f32,
+extern "C" int mv_conv3x3_cout_small_f16(const void* x, const void* x_lo, int32_t cin, const void* w, const void* bias, void* y, int32_t y_is_f32,
                                          int32_t cout, int64_t n_img, int32_t h, int32_t w_, void* stream) {
     MV_REQUIRE(x && w && y && cin % 8 == 0 && cout > 0 && cout <= 8 && n_img > 0 && h > 0 && w_ > 0, "mv_conv3x3_cout_small_f16: bad args (cin=%d cout=%d)", cin, cout);
     const size_t smem = (size_t)9 * cin * cout * sizeof(half_t);
@@ -604,20 +622,20 @@ extern "C" int mv_conv3x3_cout_small_f16(const void* x, int32_t cin, const void*
     if (g > 4096) g = 4096;
     if (y_is_f32)
         hipLaunchKernelGGL(conv3x3_cout_small_kernel<float>, dim3((unsigned)g), dim3(kBlock), smem, (hipStream_t)stream,
-                           (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (float*)y, cout, (long)n_img, h, w_);
+                           (const half_t*)x, (const half_t*)x_lo, cin, (const half_t*)w, (const half_t*)bias, (float*)y, cout, (long)n_img, h, w_);
     else
         hipLaunchKernelGGL(conv3x3_cout_small_kernel<half_t>, dim3((unsigned)g), dim3(kBlock), smem, (hipStream_t)stream,
-                           (const half_t*)x, cin, (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_);
+                           (const half_t*)x, (const half_t*)x_lo, cin, (const half_t*)w, (const half_t*)bias, (half_t*)y, cout, (long)n_img, h, w_);
     MV_CHECK_LAUNCH("mv_conv3x3_cout_small_f16");
     return MV_OK;
 }
 
 extern "C" int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
-                                int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, void* out, void* stream) {
+                                int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, int32_t hi_lo, void* out, void* stream) {
     MV_REQUIRE(latents && idx && out && win > 0 && n_cond >= 0 && (n_cond == 0 || cond) && c > 0 && t_total > 0 && hw > 0 && cfg_copies > 0,
                "mv_window_gather: bad args");
     hipLaunchKernelGGL(window_gather_kernel, dim3(grid_for((long)(n_cond + win) * hw * c)), dim3(kBlock), 0, (hipStream_t)stream,
-                       latents, cond, idx, win, n_cond, c, t_total, hw, cfg_copies, (half_t*)out);
+                       latents, cond, idx, win, n_cond, c, t_total, hw, cfg_copies, hi_lo, (half_t*)out);
     MV_CHECK_LAUNCH("mv_window_gather");
     return MV_OK;
 }

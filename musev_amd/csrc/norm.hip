@@ -36,6 +36,9 @@ struct GnArgs {
     const float* cs1;
     const float* cs2;
     int rpt1, rpt2;
+    // two-fp16 carry through the apply pass (single source): x = x1 + x1_lo in fp32, y = fp16(v), y_lo = fp16(v - y)
+    const half_t* x1_lo;
+    half_t* y_lo;
 };
 
 __device__ __forceinline__ const half_t* gn_src(const GnArgs& a, long item, long row, int o) {
@@ -241,6 +244,25 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     };
     long r = r0 + rl;
     const long st = a.rl;
+    if (a.x1_lo != nullptr || a.y_lo != nullptr) {  // (block-uniform) the carried form: conv_norm_out only, one launch per forward
+        for (; r < r1; r += st) {
+            const long off = (item * a.rows + r) * a.ld1 + o * 8;
+            const half8v v = *reinterpret_cast<const half8v*>(a.x1 + off);
+            half8v l = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.x1_lo) l = *reinterpret_cast<const half8v*>(a.x1_lo + off);
+            half8v wh, wl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = ((float)v[j] + (float)l[j]) * sc[j] + sh[j];
+                if (a.silu) f = mv_silu(f);
+                wh[j] = (half_t)f;
+                wl[j] = (half_t)(f - (float)wh[j]);
+            }
+            *reinterpret_cast<half8v*>(a.y + (item * a.rows + r) * a.ldy + o * 8) = wh;
+            if (a.y_lo) *reinterpret_cast<half8v*>(a.y_lo + (item * a.rows + r) * a.ldy + o * 8) = wl;
+        }
+        return;
+    }
     for (; r + 3 * st < r1; r += 4 * st) {  // four loads in flight per thread (see gn_stats_kernel)
         half8v v[4];
 #pragma unroll
@@ -496,8 +518,11 @@ namespace {
 // shared by mv_groupnorm_f16 (cs1 == nullptr: statistics by a pass over x) and mv_groupnorm_cs_f16
 int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2, int64_t n_items,
               int64_t rows, int32_t num_groups, float eps, const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
-              float* partial, int32_t nsplit, float* stat, const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, void* stream) {
+              float* partial, int32_t nsplit, float* stat, const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2,
+              const void* x1_lo, void* y_lo, void* stream) {
     MV_REQUIRE(x1 && y && gamma && beta && stat && (partial || cs1), "%s: null pointer", who);
+    MV_REQUIRE((!x1_lo && !y_lo) || !x2, "%s: the carried form (x1_lo / y_lo) takes one source", who);
+    MV_REQUIRE(((reinterpret_cast<uintptr_t>(x1_lo) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0, "%s: x1_lo / y_lo must be 16-byte aligned", who);
     if (!x2) c2 = 0;
     const int C = c1 + c2;
     MV_REQUIRE(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "%s: channels must be multiples of 8 (c1=%d c2=%d)", who, c1, c2);
@@ -525,8 +550,9 @@ int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32
     a.gamma = (const half_t*)gamma; a.beta = (const half_t*)beta; a.y = (half_t*)y; a.ldy = ldy; a.silu = silu;
     a.groups = num_groups; a.eps = eps;
     a.cs1 = cs1; a.cs2 = c2 ? cs2 : nullptr; a.rpt1 = rpt1; a.rpt2 = rpt2;
+    a.x1_lo = (const half_t*)x1_lo; a.y_lo = (half_t*)y_lo;
     hipStream_t s = (hipStream_t)stream;
-    {   // small slabs: one launch (see gn_small_kernel)
+    if (!x1_lo && !y_lo) {   // small slabs: one launch (see gn_small_kernel); the carried form always takes the apply pass
         const int cpg = C / num_groups;
         const long slab_bytes = rows * (long)cpg * 2;
         const int opg = cpg / 8;
@@ -566,19 +592,19 @@ int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32
 extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                                 int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
                                 const void* beta, int32_t silu, void* y, int32_t ldy, float* partial, int32_t nsplit,
-                                float* stat, void* stream) {
+                                float* stat, const void* x1_lo, void* y_lo, void* stream) {
     MV_REQUIRE(partial, "mv_groupnorm_f16: null pointer");
     return gn_launch("mv_groupnorm_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, partial,
-                     nsplit, stat, nullptr, 0, nullptr, 0, stream);
+                     nsplit, stat, nullptr, 0, nullptr, 0, x1_lo, y_lo, stream);
 }
 
 extern "C" int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
                                    int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
                                    const void* beta, int32_t silu, void* y, int32_t ldy, const float* cs1, int32_t rpt1,
-                                   const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, void* stream) {
+                                   const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, const void* x1_lo, void* y_lo, void* stream) {
     MV_REQUIRE(cs1, "mv_groupnorm_cs_f16: null column statistics");
     return gn_launch("mv_groupnorm_cs_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, nullptr,
-                     nsplit, stat, cs1, rpt1, cs2, rpt2, stream);
+                     nsplit, stat, cs1, rpt1, cs2, rpt2, x1_lo, y_lo, stream);
 }
 
 extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t c,

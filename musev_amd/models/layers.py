@@ -175,6 +175,10 @@ class FeedForward(HipModule):
 
     def hip_forward(self, x: torch.Tensor, residual: torch.Tensor, norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
         """FF(norm(x)) + residual when ``norm`` is given (the block's norm3, folded into the GEGLU projection), else FF(x) + residual"""
+        if norm is not None and ops.ffn_fused_applies(x.shape[1], self.net[2].in_features):
+            # level 0: norm3 -> GEGLU projection -> output projection -> + residual as ONE launch (csrc/ffn.hip)
+            wp, bp = self._geglu_packed()
+            return ops.ffn_geglu(x, w16(norm.weight), w16(norm.bias), norm.eps, wp, bp, lin_w(self.net[2]), lin_b(self.net[2]), residual)
         if norm is not None:
             h = ln_linear(self, "geglu_w", x, norm, lambda: self._geglu_packed()[0], lambda: self._geglu_packed()[1], geglu=True)
         else:

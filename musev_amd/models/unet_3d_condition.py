@@ -316,8 +316,13 @@ class UNet3DConditionModel(HipModule):
         if sample.ndim != 5:
             raise ValueError(f"sample must be b c t h w, got ndim={sample.ndim}")
         b, _, t, h, w = sample.shape
+        if sample.dtype == torch.float32 and ops.CARRY and pose_guider_emb is None:
+            # an fp32 sample enters conv_in unrounded, as two fp16 halves (what the denoise loop does through window_gather)
+            x_rows = ops.split_hi_lo(sample.permute(0, 2, 3, 4, 1).reshape(-1, sample.shape[1]))
+        else:
+            x_rows = ops.bcthw_to_bthwc(sample)
         rows = self.forward_rows(
-            ops.bcthw_to_bthwc(sample), b, t, h, w, timestep, encoder_hidden_states, class_labels=class_labels,
+            x_rows, b, t, h, w, timestep, encoder_hidden_states, class_labels=class_labels,
             timestep_cond=timestep_cond, attention_mask=attention_mask,
             down_block_additional_residuals=down_block_additional_residuals,
             mid_block_additional_residual=mid_block_additional_residual, sample_index=sample_index,
@@ -428,7 +433,13 @@ class UNet3DConditionModel(HipModule):
             pose = pose_guider_emb.to(torch.float16).permute(0, 2, 3, 1).reshape(geo.rows, ch0).contiguous()
         w_in = self.packed("conv_in", lambda: ops.pack_conv_weight(self.conv_in.weight.detach()))
         x_in = x
-        if 9 * self.conv_in.in_channels <= 64:  # latent input (4 channels): im2col + one MFMA K step
+        if x.shape[1] == 2 * self.conv_in.in_channels and 18 * self.conv_in.in_channels <= 128:
+            # the fp32 sample as two fp16 halves, rows [hi | lo] (ops.window_gather(hi_lo=True) / ops.split_hi_lo): the convolution
+            # is linear, so conv_in over the 2 C channels with its weight duplicated convolves the UNROUNDED input
+            w_in2 = self.packed("conv_in_hilo", lambda: ops.pad_cols(ops.pack_conv_weight(
+                torch.cat([self.conv_in.weight.detach(), self.conv_in.weight.detach()], dim=1)), 128))
+            x = ctx.shared("conv_in", lambda: ops.conv3x3_cin_small_gemm(x_in, w_in2, w16(self.conv_in.bias), geo.n, h, w, add_=pose, kpad=128))
+        elif 9 * self.conv_in.in_channels <= 64:  # latent input (4 channels): im2col + one MFMA K step
             w_in = self.packed("conv_in64", lambda: ops.pad_cols(w_in, 64))
             x = ctx.shared("conv_in", lambda: ops.conv3x3_cin_small_gemm(x_in, w_in, w16(self.conv_in.bias), geo.n, h, w, add_=pose))
         else:
@@ -474,8 +485,10 @@ class UNet3DConditionModel(HipModule):
             self._tap(f"up_blocks.{i}", x, geo)
 
         # ---- 6. post-process (:1258-1263) ----
+        # (carry: the norm reads the residual stream's two fp16 halves and hands conv_out two halves as well -- the last layers of the
+        # network see the identity path unrounded, ops.CARRY)
         x = ops.groupnorm(x, w16(self.conv_norm_out.weight), w16(self.conv_norm_out.bias), geo.n, geo.hw,
-                          eps=self.conv_norm_out.eps, silu=True, groups=self.conv_norm_out.num_groups)
+                          eps=self.conv_norm_out.eps, silu=True, groups=self.conv_norm_out.num_groups, carry=True)
         w_out = self.packed("conv_out", lambda: ops.pack_conv_weight(self.conv_out.weight.detach()))
         x = ops.conv3x3_cout_small(x, w_out, w16(self.conv_out.bias), geo.n, geo.h, geo.w, out_dtype=torch.float32)
         if skip_temporal_layers is not None:

@@ -242,6 +242,43 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     return o
 
 
+# The level-0 feed-forward as one launch (mv_ffn_geglu_f16; env knob for A/B runs: MUSEV_FFN_FUSED=0 keeps LayerNorm + the GEGLU
+# projection + the output projection)
+FFN_FUSED: bool = os.environ.get("MUSEV_FFN_FUSED", "1") == "1"
+FFN_FUSED_HITS: int = 0
+
+
+def ffn_fused_applies(c: int, hidden: int) -> bool:
+    return FFN_FUSED and c == 320 and hidden == 1280
+
+
+def ffn_geglu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w1p: torch.Tensor, b1p: Optional[torch.Tensor],
+              w2: torch.Tensor, b2: Optional[torch.Tensor], residual: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """residual + (GEGLU(LayerNorm(x) @ w1p.T + b1p)) @ w2.T + b2 in ONE launch (C = 320, hidden = 1280): ``w1p`` / ``b1p`` are the
+    GEGLU-packed first projection (:func:`pack_geglu`), ``w2`` the torch-layout [C, hidden] output projection."""
+    x = _mat(x, "x")
+    residual = _mat(residual, "residual")
+    w1p = _mat(w1p, "w1")
+    w2 = _mat(w2, "w2")
+    M, c = x.shape
+    hidden = w2.shape[1]
+    if not (w1p.is_contiguous() and w2.is_contiguous() and tuple(w1p.shape) == (2 * hidden, c) and w2.shape[0] == c and tuple(residual.shape) == (M, c)):
+        raise ValueError("ffn_geglu: shape mismatch")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(b1p, "bias1", 2 * hidden)
+    _vec(b2, "bias2", c)
+    o = _out(out, M, c, x)
+    d = _lib.FfnDesc()
+    d.x, d.ln_gamma, d.ln_beta, d.w1, d.bias1 = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w1p.data_ptr(), _p(b1p)
+    d.w2, d.bias2, d.residual, d.out = w2.data_ptr(), _p(b2), residual.data_ptr(), o.data_ptr()
+    d.M, d.C, d.H, d.ldx, d.ldr, d.ldo, d.ln_eps = M, c, hidden, x.stride(0), residual.stride(0), o.stride(0), float(eps)
+    check(_lib.load().mv_ffn_geglu_f16(C.byref(d), _stream()), "mv_ffn_geglu_f16")
+    global FFN_FUSED_HITS
+    FFN_FUSED_HITS += 1
+    return o
+
+
 def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], reps: int = 1) -> float:
     """the two lists re-issued CONCURRENTLY, one per HIP stream (how the loop runs the two CFG halves); returns the elapsed device
     milliseconds from the common start to the later of the two ends, over all reps"""
@@ -364,8 +401,9 @@ def tconv3(x: torch.Tensor, w: torch.Tensor, b: int, t: int, hw: int, *, bias=No
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items: int, rows: int, *, eps: float,
               silu: bool, x2: Optional[torch.Tensor] = None, groups: int = 32,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """GroupNorm(groups) (+SiLU) with statistics over (rows, C/groups) per item; x = [n_items*rows, C1] (+ x2)."""
+              out: Optional[torch.Tensor] = None, carry: bool = False) -> torch.Tensor:
+    """GroupNorm(groups) (+SiLU) with statistics over (rows, C/groups) per item; x = [n_items*rows, C1] (+ x2).
+    ``carry`` (conv_norm_out): normalise x + its lo half (see CARRY) in fp32 and hand the result on as two fp16 halves as well."""
     x = _mat(x, "x")
     c1 = x.shape[1]
     c2 = 0
@@ -382,6 +420,13 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
         raise ValueError("groupnorm: gamma / beta must be 16-byte aligned")
     nsplit = lib.mv_groupnorm_default_nsplit(n_items, rows, c)
     o = _out(out, n_items * rows, c, x)
+    x_lo = y_lo = None
+    if carry and CARRY and x2 is None and c <= CARRY_MAX_C and o.stride(0) % 8 == 0:
+        x_lo = getattr(x, "_mv_lo", None)
+        if x_lo is not None and (x_lo.shape != x.shape or x_lo.stride() != x.stride()):
+            x_lo = None
+        y_lo = torch.empty_strided(o.shape, o.stride(), dtype=torch.float16, device=o.device)
+        o._mv_lo = y_lo
     cs1 = getattr(x, "_mv_colstats", None) if COLSTATS else None
     cs2 = getattr(x2, "_mv_colstats", None) if (COLSTATS and x2 is not None) else None
     if cs1 is not None and rows % cs1[1] == 0 and (x2 is None or (cs2 is not None and rows % cs2[1] == 0)):
@@ -393,14 +438,14 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
                                       n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
                                       o.data_ptr(), o.stride(0), cs1[0].data_ptr(), cs1[1],
                                       cs2[0].data_ptr() if cs2 is not None else None, cs2[1] if cs2 is not None else 0,
-                                      nsplit, stat.data_ptr(), _stream()), "mv_groupnorm_cs_f16")
+                                      nsplit, stat.data_ptr(), _p(x_lo), _p(y_lo), _stream()), "mv_groupnorm_cs_f16")
         return o
     scratch = torch.empty(n_items * nsplit * 2 * groups + n_items * 2 * groups, dtype=torch.float32, device=x.device)
     partial_ptr = scratch.data_ptr()
     stat_ptr = partial_ptr + 4 * n_items * nsplit * 2 * groups
     check(lib.mv_groupnorm_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
                                n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
-                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _stream()), "mv_groupnorm_f16")
+                               o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _p(x_lo), _p(y_lo), _stream()), "mv_groupnorm_f16")
     return o
 
 
@@ -551,7 +596,10 @@ def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: in
     if out_dtype not in (torch.float16, torch.float32):
         raise ValueError("conv3x3_cout_small: out_dtype must be fp16 or fp32")
     y = torch.empty((n_img * h * w_, cout), dtype=out_dtype, device=x.device)
-    check(_lib.load().mv_conv3x3_cout_small_f16(x.data_ptr(), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
+    x_lo = getattr(x, "_mv_lo", None) if CARRY else None   # two-fp16 input (groupnorm(carry=True)): the convolution reads hi + lo
+    if x_lo is not None and (x_lo.shape != x.shape or not x_lo.is_contiguous()):
+        x_lo = None
+    check(_lib.load().mv_conv3x3_cout_small_f16(x.data_ptr(), _p(x_lo), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
                                                 y.data_ptr(), int(out_dtype == torch.float32), cout, n_img, h, w_, _stream()),
           "mv_conv3x3_cout_small_f16")
     return y
@@ -612,14 +660,24 @@ def bthwc_to_bcthw(x: torch.Tensor, b: int, t: int, h: int, w: int, dtype=torch.
     return y
 
 
-def window_gather(latents: torch.Tensor, cond: Optional[torch.Tensor], idx: torch.Tensor, n_cond: int, copies: int) -> torch.Tensor:
-    """latents fp32 [C, T_total, HW]; cond fp32 [C, n_cond, HW]; idx int32 [win] -> fp16 [copies*(n_cond+win)*HW, C]."""
+def window_gather(latents: torch.Tensor, cond: Optional[torch.Tensor], idx: torch.Tensor, n_cond: int, copies: int,
+                  hi_lo: bool = False) -> torch.Tensor:
+    """latents fp32 [C, T_total, HW]; cond fp32 [C, n_cond, HW]; idx int32 [win] -> fp16 [copies*(n_cond+win)*HW, C].
+    ``hi_lo``: rows of 2 C columns [fp16(v) | fp16(v - fp16(v))] -- the fp32 latents as two fp16 halves (the UNet's conv_in takes
+    them with its weight duplicated over the two channel groups: the input is not rounded to fp16, see CARRY)."""
     c, t_total, hw = latents.shape
     win = idx.numel()
-    out = torch.empty((copies * (n_cond + win) * hw, c), dtype=torch.float16, device=latents.device)
-    check(_lib.load().mv_window_gather(latents.data_ptr(), _p(cond), idx.data_ptr(), win, n_cond, c, t_total, hw, copies,
+    out = torch.empty((copies * (n_cond + win) * hw, 2 * c if hi_lo else c), dtype=torch.float16, device=latents.device)
+    check(_lib.load().mv_window_gather(latents.data_ptr(), _p(cond), idx.data_ptr(), win, n_cond, c, t_total, hw, copies, int(hi_lo),
                                        out.data_ptr(), _stream()), "mv_window_gather")
     return out
+
+
+def split_hi_lo(x32: torch.Tensor) -> torch.Tensor:
+    """fp32 rows [M, C] -> fp16 [M, 2 C] = [hi | lo] (what window_gather(hi_lo=True) builds inside the loop), for callers that hand
+    UNet3DConditionModel.forward an fp32 sample"""
+    hi = x32.to(torch.float16)
+    return torch.cat([hi, (x32 - hi.float()).to(torch.float16)], dim=1).contiguous()
 
 
 def window_scatter_add(eps_win: torch.Tensor, idx: torch.Tensor, n_cond: int, halves: int, half_offset: int,

@@ -258,7 +258,8 @@ class ParallelDenoiser:
             def run_group(wi, hs):
                 wl = len(wins[wi])
                 tw = n_cond + wl
-                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs))
+                # (hi_lo: the fp32 latents as two fp16 halves -- conv_in sees them unrounded, ops.CARRY)
+                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs), hi_lo=ops.CARRY and controlnet is None)
                 cn_ = None
                 if controlnet is not None and cn_on:
                     ctrl_bufs[wl].copy_(ctrl_frames[wi])

@@ -230,7 +230,7 @@ def tconv3(x, w, b, t, hw, *, bias=None, residual=None, alpha=None, out=None, ca
                             act=MV_ACT_NONE, geglu=False), out)
 
 
-def groupnorm(x, gamma, beta, n_items, rows, *, eps, silu, x2=None, groups=32, out=None):
+def groupnorm(x, gamma, beta, n_items, rows, *, eps, silu, x2=None, groups=32, out=None, carry=False):
     _mat(x, "x")
     _req(x.shape[0] == n_items * rows, "groupnorm: x rows != n_items*rows")
     if x2 is not None:
@@ -242,10 +242,22 @@ def groupnorm(x, gamma, beta, n_items, rows, *, eps, silu, x2=None, groups=32, o
     _vec(gamma, "gamma", c)
     _vec(beta, "beta", c)
     _check_out(out, n_items * rows, c, 8)
-    y = F.group_norm(xs.float().reshape(n_items, rows, c).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)
+    xf = xs.float()
+    use_carry = bool(carry) and x2 is None and c <= CARRY_MAX_C
+    if use_carry and getattr(x, "_mv_lo", None) is not None:
+        # the kernel takes the statistics of the hi half and normalises hi + lo
+        st = xf.reshape(n_items, rows, groups, c // groups)
+        mean = st.mean(dim=(1, 3), keepdim=True)
+        var = st.var(dim=(1, 3), unbiased=False, keepdim=True)
+        y = ((xf + x._mv_lo.float()).reshape(n_items, rows, groups, c // groups) - mean) * torch.rsqrt(var + eps)
+        y = y.reshape(n_items, rows, c) * gamma.float() + beta.float()
+        y = y.permute(0, 2, 1)
+    else:
+        y = F.group_norm(xf.reshape(n_items, rows, c).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)
     if silu:
         y = F.silu(y)
-    return _store(y.permute(0, 2, 1).reshape(n_items * rows, c), out)
+    y = y.permute(0, 2, 1).reshape(n_items * rows, c)
+    return _carry_store(y, out) if use_carry else _store(y, out)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
@@ -334,6 +346,35 @@ def add(a, b):
     return (a.float() + b.float()).to(torch.float16)
 
 
+def ffn_fused_applies(c, hidden):
+    return c == 320 and hidden == 1280
+
+
+def ffn_geglu(x, gamma, beta, eps, w1p, b1p, w2, b2, residual, out=None):
+    """the kernel's arithmetic: LayerNorm rounded to fp16, fp32 accumulation, the gated activation rounded to fp16, fp32 residual add"""
+    _mat(x, "x")
+    _mat(residual, "residual")
+    M, c = x.shape
+    hidden = w2.shape[1]
+    _req(c == 320 and hidden == 1280 and tuple(w1p.shape) == (2 * hidden, c) and tuple(w2.shape) == (c, hidden), "ffn_geglu: C = 320, hidden = 1280 only")
+    _req(tuple(residual.shape) == (M, c) and w1p.is_contiguous() and w2.is_contiguous(), "ffn_geglu: shapes")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(b1p, "bias1", 2 * hidden)
+    _vec(b2, "bias2", c)
+    _check_out(out, M, c, 8)
+    xn = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), eps).to(torch.float16)
+    acc = xn.float() @ w1p.float().t()
+    if b1p is not None:
+        acc = acc + b1p.float()
+    blk = acc.reshape(M, -1, 2, 16)
+    gact = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, -1).to(torch.float16)
+    y = gact.float() @ w2.float().t()
+    if b2 is not None:
+        y = y + b2.float()
+    return _store(y + residual.float(), out)
+
+
 def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None, _carry=False):
     cin = x.shape[1]
     _req(x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[0] == n_img * h * w_, "conv_in: x")
@@ -368,7 +409,8 @@ def conv3x3_cout_small(x, w, bias, n_img, h, w_, out_dtype=torch.float16):
     _req(x.is_contiguous() and w.shape[1] == 9 * x.shape[1] and x.shape[1] % 8 == 0 and w.shape[0] <= 8, "conv_out: shapes")
     _req(x.shape[0] == n_img * h * w_ and out_dtype in (torch.float16, torch.float32), "conv_out: rows / dtype")
     _vec(bias, "bias", w.shape[0])
-    y = _rows(F.conv2d(_images(x, n_img, h, w_), _unpack(w, x.shape[1], (3, 3)), None, padding=1))
+    xin = x.float() + x._mv_lo.float() if getattr(x, "_mv_lo", None) is not None else x
+    y = _rows(F.conv2d(_images(xin, n_img, h, w_), _unpack(w, x.shape[1], (3, 3)), None, padding=1))
     if bias is not None:
         y = y + bias.float()
     return y.to(out_dtype).contiguous()
@@ -421,7 +463,7 @@ def pack_geglu(w, bias):
 EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
-            "pack_conv_weight", "pack_geglu"]
+            "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu"]
 
 
 def install(monkeypatch) -> None:

@@ -8,12 +8,16 @@ import math
 import torch
 
 
-def window_gather(latents, cond, idx, n_cond, copies):
+def window_gather(latents, cond, idx, n_cond, copies, hi_lo=False):
     frames = latents[:, idx.long()]
     if n_cond:
         frames = torch.cat([cond, frames], dim=1)
     rows = frames.permute(1, 2, 0).reshape(-1, latents.shape[0])
-    return torch.cat([rows] * copies, dim=0).to(torch.float16)
+    rows = torch.cat([rows] * copies, dim=0)
+    hi = rows.to(torch.float16)
+    if hi_lo:  # rows of 2 C columns [hi | lo] (mv_window_gather(hi_lo = 1))
+        return torch.cat([hi, (rows.float() - hi.float()).to(torch.float16)], dim=1)
+    return hi
 
 
 def window_scatter_add(eps_win, idx, n_cond, halves, half_offset, eps_acc, counter, add_counter):
@@ -54,7 +58,11 @@ class FakeUNet:
     """eps = tanh(0.5 x) * (1 + 0.1 * mean(text)) + 0.01 * (timestep / 1000) + 0.05 * frame_position -- depends on the
     input frames, the CFG half's prompt, the timestep and the window-local frame position, like the real network."""
 
+    in_channels = 4
+
     def forward_rows(self, x, b, t, h, w, timestep, ehs, **kw):
+        if x.shape[1] == 2 * self.in_channels:
+            x = x[:, :self.in_channels]  # [hi | lo] rows: this double works on the fp16 half, like `nchw` below
         c = x.shape[1]
         v = x.float().reshape(b, t, h * w, c)
         s = 1.0 + 0.1 * ehs.float().mean(dim=(1, 2)).reshape(b, 1, 1, 1)

@@ -266,6 +266,57 @@ def case_carry(kind="linear", n=3, h=16, w=16, cin=64, c=320, cfg=None, seed=600
     return _all_ok(results)
 
 
+def case_ffn_fused(M=300, seed=700, offset=0.0, with_bias=True):
+    """the level-0 feed-forward as one launch (mv_ffn_geglu_f16): residual + GEGLU(LayerNorm(x) W1^T + b1) W2^T + b2, C = 320, hidden =
+    1280, against the torch fp32 expression of the chain (and, as a second check, against the three-launch form it replaces)"""
+    from musev_amd import ops
+    c, hd = 320, 1280
+    x = (_rand((M, c), seed, 1.5).float() + offset).half()
+    gamma = (_rand((c,), seed + 1, 0.2).float() + 1.0).half()
+    beta = _rand((c,), seed + 2, 0.2)
+    w1 = _rand((2 * hd, c), seed + 3, 1.0 / math.sqrt(c))
+    b1 = _rand((2 * hd,), seed + 4, 0.3) if with_bias else None
+    w2 = _rand((c, hd), seed + 5, 1.0 / math.sqrt(hd))
+    b2 = _rand((c,), seed + 6, 0.3) if with_bias else None
+    res = _rand((M, c), seed + 7, 2.0)
+    w1p, b1p = ops.pack_geglu(w1, b1)
+    hits = ops.FFN_FUSED_HITS
+    got = ops.ffn_geglu(x, gamma, beta, 1e-5, w1p, b1p, w2, b2, res)
+    xn = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    h = xn @ w1.float().t() + (b1.float() if with_bias else 0.0)
+    ref = (h[:, :hd] * F.gelu(h[:, hd:])) @ w2.float().t() + (b2.float() if with_bias else 0.0) + res.float()
+    results = [_cmp(f"ffn fused M{M} offset{offset}", got, ref, atol=6e-3)]
+    if ops.FFN_FUSED_HITS != hits + 1:
+        return {"name": f"ffn fused M{M}", "ok": False, "max_abs_err": float("nan"), "detail": "the fused launch was not taken"}
+    three = ops.gemm(ops.gemm(ops.layernorm(x, gamma, beta, 1e-5), w1p, bias=b1p, geglu=True), w2, bias=b2, residual=res)
+    results.append(_cmp(f"ffn fused vs three launches M{M}", got, three.float(), atol=6e-3))
+    return _all_ok(results)
+
+
+def case_tail_carry(n=3, h=16, w=16, c=320, seed=800):
+    """the network's tail on a carried stream: conv_norm_out reads hi + lo (statistics of hi, from the producer's column statistics or
+    its own pass), normalises in fp32 and hands conv_out two fp16 halves; conv_out (320 -> 4, fp32 out) reads both.  Against the
+    torch fp32 expression on the fp32 stream: 4 x tighter than the bar of the fp16 tail."""
+    from musev_amd import ops
+    hw = h * w
+    s32 = (_rand((n * hw, c), seed, 6.0).float() + 0.37 * _rand((n * hw, c), seed + 1).float())
+    hi = s32.half()
+    hi._mv_lo = (s32 - hi.float()).half()
+    gamma = (_rand((c,), seed + 2, 0.2).float() + 1.0).half()
+    beta = _rand((c,), seed + 3, 0.2)
+    wt = _rand((4, c, 3, 3), seed + 4, 1.0 / math.sqrt(9 * c))
+    bias = _rand((4,), seed + 5)
+    y = ops.groupnorm(hi, gamma, beta, n, hw, eps=1e-5, silu=True, carry=True)
+    if getattr(y, "_mv_lo", None) is None:
+        return {"name": "tail carry", "ok": False, "max_abs_err": float("nan"), "detail": "groupnorm(carry=True) returned no lo half"}
+    ref_n = F.silu(F.group_norm(s32.reshape(n, hw, c).permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5))
+    results = [_cmp("tail carry: norm hi + lo", y.float() + y._mv_lo.float(), ref_n.permute(0, 2, 1).reshape(n * hw, c), atol=1.5e-4, rtol=1e-4)]
+    out = ops.conv3x3_cout_small(y, ops.pack_conv_weight(wt), bias, n, h, w, out_dtype=torch.float32)
+    ref = F.conv2d(ref_n.reshape(n, c, h, w), wt.float(), bias.float(), padding=1).permute(0, 2, 3, 1).reshape(n * hw, 4)
+    results.append(_cmp("tail carry: conv_out", out, ref, atol=4e-4, rtol=1e-4))
+    return _all_ok(results)
+
+
 def case_groupnorm(n=3, rows=200, c1=320, c2=0, silu=True, eps=1e-5, seed=40):
     from musev_amd import ops
     c = c1 + c2
@@ -587,6 +638,10 @@ def case_window_loop():
     ref_in = frames.permute(1, 2, 0).reshape(-1, c)
     ref_in = torch.cat([ref_in, ref_in], dim=0)
     r1 = _cmp("window_gather", inp, ref_in.half().float(), atol=1e-6)
+    both = ops.window_gather(lat, cond, idx, n_cond, 2, hi_lo=True)   # rows [hi | lo]: the fp32 values as two fp16 halves
+    r1b = _all_ok([_cmp("window_gather hi_lo: hi", both[:, :c], ref_in.half().float(), atol=0.0, rtol=0.0),
+                   _cmp("window_gather hi_lo: hi + lo", both[:, :c].float() + both[:, c:].float(), ref_in.float(), atol=1e-6, rtol=4e-6)])
+    r1["ok"] = r1["ok"] and r1b["ok"]
     eps_win = _rand((2 * (n_cond + win) * hw, c), 131)
     acc = torch.zeros((2, c, t_total, hw), device=DEV)
     cnt = torch.zeros((t_total,), device=DEV)
@@ -732,6 +787,10 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("carry_tconv", lambda: case_carry(kind="tconv", n=5, h=8, w=16, seed=620)),
     ("carry_ragged", lambda: case_carry(kind="linear", n=1, h=9, w=37, cin=200, c=200, seed=630)),
     ("carry_every_tile", lambda: _all_ok([case_carry(kind=("linear", "conv", "tconv")[c_ % 3], n=2, seed=640 + c_, cfg=c_) for c_ in range(19)])),
+    ("ffn_fused", case_ffn_fused),
+    ("ffn_fused_ragged_large_mean", lambda: case_ffn_fused(M=1111, seed=710, offset=6.0)),
+    ("ffn_fused_no_bias_one_row_block", lambda: case_ffn_fused(M=128, seed=720, with_bias=False)),
+    ("tail_carry", case_tail_carry),
     ("layernorm_320", lambda: case_layernorm(c=320)),
     ("layernorm_640", case_layernorm),
     ("layernorm_1280", lambda: case_layernorm(c=1280, seed=51)),
@@ -807,6 +866,8 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("carry_l0_linear_half", lambda: case_carry(kind="linear", n=13, h=64, w=64, cin=320, c=320, seed=650)),
     ("carry_l0_conv_half", lambda: case_carry(kind="conv", n=13, h=64, w=64, cin=320, c=320, seed=651)),
     ("carry_l0_tconv_half", lambda: case_carry(kind="tconv", n=13, h=64, w=64, c=320, seed=652)),
+    ("ffn_fused_l0_half", lambda: case_ffn_fused(M=53248, seed=730)),
+    ("tail_carry_l0_half", lambda: case_tail_carry(n=13, h=64, w=64, seed=810)),
     ("gemm_l1_geglu", lambda: case_gemm_geglu(M=26624, C=640)),
     ("gemm_l1_out_res", lambda: case_gemm(M=26624, N=640, K=640, seed=203)),
     ("gemm_l2_out_res", lambda: case_gemm(M=6656, N=1280, K=1280, seed=204)),                    # 256x160 three-stage ring (26 x 8 blocks)
@@ -840,6 +901,7 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("cfg5_gemm_l0_ln_qkv_half", lambda: case_gemm_ln(M=119808, N=960, K=320, seed=502)),
     ("cfg5_gemm_l0_geglu_half", lambda: case_gemm_geglu(M=119808, C=320)),
     ("cfg5_gemm_l0_ff2_half", lambda: case_gemm(M=119808, N=320, K=1280, seed=503)),
+    ("cfg5_ffn_fused_l0_half", lambda: case_ffn_fused(M=119808, seed=731)),
     ("cfg5_gemm_l1_out_res_half", lambda: case_gemm(M=29952, N=640, K=640, seed=504)),
     ("cfg5_gemm_l1_out_res", lambda: case_gemm(M=59904, N=640, K=640, seed=505)),
     ("cfg5_gemm_l2_qkv_half", lambda: case_gemm(M=7488, N=3840, K=1280, epilogue=False, seed=506)),

@@ -35,6 +35,9 @@ CASES = {
     "carry_tconv": "kc.case_carry(kind='tconv', n=3, h=4, w=12, c=64)",
     "carry_ragged": "kc.case_carry(kind='linear', n=1, h=5, w=15, cin=72, c=72)",
     "carry_every_tile": "kc._all_ok([kc.case_carry(kind=('linear', 'conv', 'tconv')[c % 3], n=2, h=4, w=12, cin=64, c=64, seed=640 + c, cfg=c) for c in range(19)])",
+    "ffn_fused": "kc.case_ffn_fused(M=200)",
+    "ffn_fused_one_block_no_bias": "kc.case_ffn_fused(M=70, seed=720, with_bias=False, offset=3.0)",
+    "tail_carry": "kc.case_tail_carry(n=2, h=8, w=8, c=64)",
     "conv3x3": "kc.case_conv3x3(n=2, h=8, w=12, c1=64, cout=64)",
     "conv3x3_two_src": "kc.case_conv3x3(n=2, h=8, w=12, c1=64, c2=64, cout=64)",
     "conv3x3_stride2_odd": "kc.case_conv3x3(n=2, h=7, w=9, c1=64, cout=64, stride=2)",
@@ -87,7 +90,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups",
+    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
