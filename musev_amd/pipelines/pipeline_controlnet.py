@@ -20,9 +20,11 @@ itself accepts in their place:
     control_image                        ControlNet residuals / PoseGuider embedding   tensor [b, 3, t, H, W] in [0, 1] (the reference's prepare_image
                                                                                        output); PIL / numpy inputs are the caller's to convert
 
+``image`` (+ ``strength``, ``add_latents_noise``): the img2img / video2video start of prepare_latents (:283-430) and get_timesteps
+(:1627-1633) -- ``image`` goes through ``vae_encode``; the schedule then starts at step N - int(N * strength) when ``latents`` are given too.
+
 Keywords of branches this package does not build raise ``NotImplementedError`` when they are USED (not when they are merely
-passed with their default): img2img / video2video initialisation (``image`` + ``strength``; the reference's own docstring marks it
-unsupported), FaceIn / IP-Adapter-FaceID (``refer_face_image``, ``ip_adapter_face_image``), the serial-denoise recording hooks
+passed with their default): FaceIn / IP-Adapter-FaceID (``refer_face_image``, ``ip_adapter_face_image``), the serial-denoise recording hooks
 (``record_mid_video_*``, ``last_mid_video_*``), histogram matching and ``interpolation_factor``."""
 from __future__ import annotations
 
@@ -133,7 +135,7 @@ class MusevControlNetPipeline:
                  context_batch_size=1, interpolation_factor=1, decoder_t_segment: int = 200,
                  # tensors the reference computes with its encoders, accepted directly (module docstring)
                  ip_adapter_image_emb: Optional[torch.Tensor] = None, refer_image_vae_emb: Optional[torch.Tensor] = None):
-        for name, value, default in (("image", image, None), ("refer_face_image", refer_face_image, None),
+        for name, value, default in (("refer_face_image", refer_face_image, None),
                                      ("ip_adapter_face_image", ip_adapter_face_image, None),
                                      ("record_mid_video_noises", record_mid_video_noises, False),
                                      ("last_mid_video_noises", last_mid_video_noises, None),
@@ -141,7 +143,7 @@ class MusevControlNetPipeline:
                                      ("last_mid_video_latents", last_mid_video_latents, None), ("need_hist_match", need_hist_match, False),
                                      ("controlnet_condition_images", controlnet_condition_images, None),
                                      ("controlnet_condition_latents", controlnet_condition_latents, None),
-                                     ("controlnet_latents", controlnet_latents, None), ("add_latents_noise", add_latents_noise, False),
+                                     ("controlnet_latents", controlnet_latents, None),
                                      ("cross_attention_kwargs", cross_attention_kwargs, None), ("interpolation_factor", interpolation_factor, 1),
                                      ("need_middle_latents", need_middle_latents, False)):
             _unsupported(name, value, default)
@@ -172,14 +174,45 @@ class MusevControlNetPipeline:
         sched = den.scheduler
         sched.set_timesteps(num_inference_steps)
         c_lat = self.unet.config.in_channels if hasattr(self.unet, "config") else 4
-        if latents is None:
+        # ---- img2img / video2video start (:1627-1633 timesteps, :283-430 prepare_latents) ----
+        # `image` (frames to start from) is VAE-encoded to init_latents; with `latents` also given, `strength` shortens the schedule
+        # (get_timesteps of the img2img pipelines: the last int(N * strength) entries) and the caller's latents are used as they are
+        # (x init_noise_sigma) or noised (`add_latents_noise`); with `image` alone the init latents are noised to the first timestep.
+        # get_timesteps / add_noise live in the un-vendored diffusers base classes: restated from upstream, parity unpinned.
+        start_step = 0
+        user_latents = latents
+        noise = None
+        if user_latents is None or add_latents_noise:
             if height is None or width is None:
-                raise ValueError("height / width (pixels) are needed to draw the initial latents")
-            shape = (1, c_lat, int(video_length), height // 8, width // 8)
-            latents = prepare_noise_latents(shape, dtype=torch.float32, device=dev, generator=generator, noise_type=noise_type,
-                                            w_ind_noise=w_ind_noise, initial_common_latent=initial_common_latent,
-                                            condition_latents=condition_latents, need_img_based_video_noise=need_img_based_video_noise,
-                                            img_weight=img_weight, init_noise_sigma=float(getattr(sched, "init_noise_sigma", 1.0)))
+                if user_latents is None:
+                    raise ValueError("height / width (pixels) are needed to draw the initial latents")
+                shape = tuple(user_latents.shape)
+            else:
+                shape = (1, c_lat, int(video_length), height // 8, width // 8)
+            noise = prepare_noise_latents(shape, dtype=torch.float32, device=dev, generator=generator, noise_type=noise_type,
+                                          w_ind_noise=w_ind_noise, initial_common_latent=initial_common_latent,
+                                          condition_latents=condition_latents if (image is None and user_latents is None) else None,
+                                          need_img_based_video_noise=need_img_based_video_noise and image is None and user_latents is None,
+                                          img_weight=img_weight, init_noise_sigma=1.0)
+        if strength and image is not None and user_latents is not None:
+            init_t = min(int(num_inference_steps * float(strength)), int(num_inference_steps))
+            start_step = max(int(num_inference_steps) - init_t, 0)
+        sigma0 = float(getattr(sched, "init_noise_sigma", 1.0))
+        if user_latents is None:
+            if image is None:
+                latents = noise * sigma0
+            else:
+                if self.vae_encode is None:
+                    raise ValueError("`image` needs vae_encode=callable(frames) -> latents [1, c, t, h, w]")
+                init_latents = self.vae_encode(image).to(dev, torch.float32)
+                if init_latents.shape[-2:] != noise.shape[-2:]:
+                    init_latents = torch.nn.functional.interpolate(
+                        init_latents.permute(0, 2, 1, 3, 4).reshape(-1, c_lat, *init_latents.shape[-2:]), size=tuple(noise.shape[-2:]),
+                        mode="bilinear").reshape(1, -1, c_lat, *noise.shape[-2:]).permute(0, 2, 1, 3, 4)
+                latents = sched.add_noise(init_latents, noise, start_step)
+        else:
+            latents = user_latents.to(dev, torch.float32)
+            latents = sched.add_noise(latents, noise, start_step) if add_latents_noise else latents * sigma0
         latents = latents.to(dev)
         if condition_latents is not None:
             condition_latents = condition_latents.to(dev)
@@ -257,7 +290,7 @@ class MusevControlNetPipeline:
                       callback=cb, guidance_scale_end=guidance_scale_end, guidance_scale_method=guidance_scale_method,
                       generator=generator, noise_type=noise_type, w_ind_noise=w_ind_noise, controlnet=controlnet, control_image=ctrl,
                       controlnet_conditioning_scale=float(controlnet_conditioning_scale), control_guidance_start=float(control_guidance_start),
-                      control_guidance_end=float(control_guidance_end), guess_mode=bool(guess_mode))
+                      control_guidance_end=float(control_guidance_end), guess_mode=bool(guess_mode), start_step=start_step)
         finally:
             if skip_temporal_layer:
                 self.unet.set_skip_temporal_layers(False)                                               # :2175-2176

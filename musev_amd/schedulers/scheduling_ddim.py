@@ -79,6 +79,12 @@ class DDIMScheduler:
         """DDIM draws step noise only when eta > 0 (scheduling_ddim.py:266-295); this loop runs eta = 0: nothing to consume"""
         return
 
+    def add_noise(self, original: torch.Tensor, noise: torch.Tensor, step_index: int) -> torch.Tensor:
+        """sqrt(alpha_bar_t) x0 + sqrt(1 - alpha_bar_t) noise at the timestep of schedule entry ``step_index`` (diffusers
+        DDIMScheduler.add_noise; the img2img start of the pipeline, pipeline_controlnet.py:414,423)"""
+        a_t = float(self.alphas_cumprod[int(self.timesteps[int(step_index)])])
+        return (a_t ** 0.5) * original + ((1.0 - a_t) ** 0.5) * noise
+
     def loop_update(self, latents: torch.Tensor, eps_acc: torch.Tensor, counter: torch.Tensor, guidance: float,
                     step_index: int, timestep) -> None:
         """fused average / CFG / DDIM step on the loop state (latents fp32 [C, T, HW], in place)"""

@@ -88,6 +88,11 @@ class EulerDiscreteScheduler:
             return max_sigma
         return (max_sigma ** 2 + 1) ** 0.5
 
+    def add_noise(self, original: torch.Tensor, noise: torch.Tensor, step_index: int) -> torch.Tensor:
+        """x0 + sigma_t noise at schedule entry ``step_index`` (diffusers EulerDiscreteScheduler.add_noise; the img2img start of the
+        pipeline, pipeline_controlnet.py:414,423)"""
+        return original + float(self.sigmas[int(step_index)]) * noise
+
     def set_timesteps(self, num_inference_steps: int, device=None) -> None:
         n_train = self.config.num_train_timesteps
         self.num_inference_steps = num_inference_steps

@@ -491,5 +491,30 @@ def test_pipeline_call_runs_the_loop_like_the_oracle(emulated):
     assert torch.equal(tup[1], out.latents)
     with pytest.raises(ValueError):
         pipe(T, prompt="a cat", latents=latents, num_inference_steps=2)          # strings need a text encoder callable
-    with pytest.raises(NotImplementedError):
-        pipe(T, prompt_embeds=prompt, latents=latents, image=torch.zeros(1, 3, T, 64, 64), num_inference_steps=2)   # img2img branch
+    # img2img / video2video start (pipeline_controlnet.py:1627-1633, 283-430): `image` + `latents` + `strength` -> the schedule starts
+    # at step N - int(N * strength) from the caller's latents; `image` alone -> its VAE latents noised to the first timestep
+    N, strength = 4, 0.5
+    want2 = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), latents, prompt, num_inference_steps=N,
+                               guidance_scale=3.5, condition_latents=cond, motion_speed=8.0, context_frames=win, context_overlap=ov,
+                               start_step=N - int(N * strength))
+    frames = torch.zeros(1, 3, T, 64, 64)
+    with pytest.raises(ValueError):
+        pipe(T, prompt_embeds=prompt, image=frames, height=64, width=64, num_inference_steps=N)   # `image` alone needs a VAE encoder
+    got2 = pipe(T, prompt_embeds=prompt, latents=latents, image=frames, strength=strength, condition_latents=cond, num_inference_steps=N,
+                guidance_scale=3.5, context_frames=win, context_overlap=ov, output_type="latent").latents
+    scale2 = max(1.0, float(want2.abs().max()) / 4.0)
+    assert (got2.float() - want2).abs().max().item() < TOL * scale2
+    init = 0.18215 * torch.randn(1, 4, T, h, w, generator=torch.Generator().manual_seed(5))
+    pipe2 = MusevControlNetPipeline(unet=unet, vae_encode=lambda img: init)
+    gen = torch.Generator().manual_seed(9)
+    got3 = pipe2(T, prompt_embeds=prompt, image=frames, height=8 * h, width=8 * w, condition_latents=cond, num_inference_steps=N,
+                 guidance_scale=3.5, context_frames=win, context_overlap=ov, output_type="latent", generator=gen).latents
+    from musev_amd.schedulers import DDIMScheduler
+    from musev_amd.utils.noise_util import prepare_noise_latents
+    sch = DDIMScheduler()
+    sch.set_timesteps(N)
+    noise = prepare_noise_latents((1, 4, T, h, w), dtype=torch.float32, device=torch.device("cpu"), generator=torch.Generator().manual_seed(9))
+    want3 = opipe.denoise_loop(lambda x, t, e, **k: unet3d.unet3d_forward(sd, cfg, x, t, e, **k), sch.add_noise(init, noise, 0), prompt,
+                               num_inference_steps=N, guidance_scale=3.5, condition_latents=cond, motion_speed=8.0, context_frames=win,
+                               context_overlap=ov)
+    assert (got3.float() - want3).abs().max().item() < TOL * max(1.0, float(want3.abs().max()) / 4.0)
