@@ -6,18 +6,21 @@
 // [M, 4 C] activation and the normalised rows through HBM: at M = 53 248 that is 340 MB of the chain's 442 MB, and the GEGLU launch
 // is bound by writing its output (635 TFLOP/s against 800+ for every other level-0 GEMM, profiles/r04b_gemm_by_problem.json).
 // Here a block owns 128 rows for the whole chain and the hidden activation never leaves the CU:
-//   * prologue: the block's 128 rows of x are normalised in registers (two-pass LayerNorm, 4 lanes per row, fp32) and stored ONCE
-//     as fp16 in LDS in MFMA-operand layout (5 K tiles of [128 rows][64], 128-byte rows, XOR-(row & 7) slot swizzle: every
-//     fragment is one conflict-free ds_read_b128) -- the values mv_layernorm_f16 would have written to HBM;
+//   * prologue: the block's 128 rows of x are normalised in registers (two-pass LayerNorm, 4 lanes per row, fp32), rounded to fp16 --
+//     the values mv_layernorm_f16 would have written to HBM -- and turned into MFMA-operand FRAGMENTS through LDS (5 K tiles of
+//     [128 rows][64], 128-byte rows, XOR-(row & 7) slot swizzle: every fragment is one conflict-free ds_read_b128): a wave keeps the
+//     2 x 10 fragments of its 32 rows in registers for the whole kernel, and the LDS they passed through becomes part of the ring;
 //   * the hidden dimension is walked in 20 chunks of 64: per chunk  S = xn . W1[chunk]^T + b1  (128 packed columns = 64 values +
 //     64 gates, K = 320), g = value * gelu(gate) as fp16 into an LDS tile in the same operand layout, then  acc += g . W2[:, chunk]^T
 //     (K = 64, all 320 output columns) -- the accumulators of the OUTPUT (32 rows x 160 columns per wave; 8 waves = 4 row groups x 2
 //     column groups) stay in registers across the chunks;
 //   * both weight matrices stream through ONE ring of 16-KiB LDS tiles ([128 weight rows][64 k], same layout, filled by
 //     buffer_load ... lds through two buffer descriptors): 5 W1 tiles + 3 W2 tiles per chunk, 160 tiles per block, every tile = 16
-//     MFMAs per wave (8 for the half-empty third W2 tile); counted vmcnt waits + one raw s_barrier per tile keep RING - 1 tiles in
-//     flight; nothing else issues vector-memory loads inside the loop (b1 sits in LDS: vmcnt is in-order, a stray load would drain
-//     the ring when its value is waited for);
+//     MFMAs per wave (8 for the half-empty third W2 tile); counted vmcnt waits + one raw s_barrier per tile keep RING - 1 = 7 tiles
+//     (112 KB) in flight -- one 8-wave block per CU cannot hide a late tile behind another block, only behind its own prefetch depth
+//     (the first form of this kernel kept x in LDS and had room for 3 stages: 212 us at M = 53 248, profiles/r04d_ffn_bench.log);
+//     nothing else issues vector-memory loads inside the loop (b1 sits in LDS: vmcnt is in-order, a stray load would drain the ring
+//     when its value is waited for);
 //   * the epilogue stages the fp32 result through the idle LDS so that the residual loads and the stores are 16 bytes per lane on
 //     consecutive bytes of a row; b2 is the initial value of the accumulators; the residual add is fp32, rounded once.
 // Weights are read from L2 / the infinity cache (2.4 MB per block, the same bytes for every block); HBM sees x, the residual and
@@ -50,21 +53,18 @@ constexpr int kChunks = kH / kHC;        // 20
 constexpr int kKT1 = kC / 64;            // 5 K tiles of the first projection
 constexpr int kTilesPerChunk = kKT1 + 3; // + 3 tiles of W2 (output columns 0-127, 128-255, 256-319)
 constexpr int kTileHalfs = 128 * 64;     // one operand tile: [128 rows][64 k] halfs = 16 KiB
-#ifndef MV_FFN_RING
-#define MV_FFN_RING 3
-#endif
-constexpr int kRing = MV_FFN_RING;       // LDS stages of the weight stream
-constexpr int kXHalfs = kKT1 * kTileHalfs;   // the normalised rows: 5 tiles = 80 KiB
+constexpr int kRing = 8;                 // LDS stages of the weight stream; stages 0 .. 4 first carry the normalised rows to the registers
 constexpr int kGHalfs = kBM * kHC;       // the chunk's gated activation: one tile
-constexpr int kLdsHalfs = kXHalfs + kRing * kTileHalfs + kGHalfs + 2 * kH;
+constexpr int kLdsHalfs = kRing * kTileHalfs + kGHalfs + 2 * kH;
 constexpr unsigned kOob = 0x80000000u;
 constexpr int kSLd = kC + 4;             // epilogue: floats per staging row
-static_assert(64 * kSLd * 4 <= (kXHalfs + kRing * kTileHalfs) * 2, "a 64-row fp32 staging tile must fit the x tiles + the ring");
+static_assert(64 * kSLd * 4 <= kRing * kTileHalfs * 2, "a 64-row fp32 staging tile must fit the ring");
+static_assert(kRing - 1 - kKT1 >= 1 && kRing - 1 <= kTilesPerChunk, "prologue: tiles 0 .. RING - 2 of chunk 0, the first of them beside the x tiles");
 
 __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
-    half_t* const xs = lds;                             // [5][128][64]
-    half_t* const ring = lds + kXHalfs;                 // [kRing][128][64]
+    half_t* const ring = lds;                           // [kRing][128][64]
+    half_t* const xs = lds;                             // [5][128][64]: stages 0 .. 4, until the rows are in registers
     half_t* const gbuf = ring + kRing * kTileHalfs;     // [128][64]
     half_t* const b1s = gbuf + kGHalfs;                 // [2 H]
 
@@ -123,16 +123,10 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
             }
         }
     };
-    static_assert(kRing >= 2 && kRing - 1 <= kTilesPerChunk, "the prologue issues the first RING - 1 tiles of chunk 0");
-    {
-        int st = 0;
-        auto pro = [&](auto sc) __attribute__((always_inline)) {
-            if constexpr (decltype(sc)::value < kRing - 1) issue(sc, 0, st++);
-        };
-        pro(std::integral_constant<int, 0>{}); pro(std::integral_constant<int, 1>{}); pro(std::integral_constant<int, 2>{});
-        pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{}); pro(std::integral_constant<int, 5>{});
-        pro(std::integral_constant<int, 6>{});
-    }
+    // tile seq lives in stage (seq + 5) % RING: the first RING - 1 - 5 tiles go to the stages beside the x tiles at once, the rest of
+    // the prologue's tiles follow when the rows have left stages 0 .. 4
+    issue(std::integral_constant<int, 0>{}, 0, 5);
+    issue(std::integral_constant<int, 1>{}, 0, 6);
 
     // ---- LayerNorm of the rows (two-pass in registers, the 4 lanes of a row meet by xor-shuffles) -> xs, operand layout ----
     {
@@ -169,8 +163,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
     // the first projection's bias -> LDS (packed order, 5 KB); zeros when there is none
     for (int i = tid; i < 2 * kH / 8; i += 512)
         *reinterpret_cast<half8v*>(b1s + 8 * i) = p.bias1 ? *reinterpret_cast<const half8v*>(p.bias1 + 8 * i) : half8v{0, 0, 0, 0, 0, 0, 0, 0};
-
-    // ---- output accumulators, starting from b2: acc2[i][jj] = rows 32 wm + 16 i + l15, columns ocol(jj) + 4 g .. + 3 ----
+    // ---- output accumulators, starting from b2 (requested ahead of the barrier below: no stray load in the ring's queue): acc2[i][jj] = rows 32 wm + 16 i + l15, columns ocol(jj) + 4 g .. + 3 ----
     // column tiles jj 0-3: output columns 64 wn + 16 jj (W2 tile 0), 4-7: 128 + 64 wn + 16 (jj - 4) (tile 1), 8-9: 256 + 32 wn + 16 (jj - 8)
     auto ocol = [&](int jj) { return jj < 4 ? 64 * wn + 16 * jj : jj < 8 ? 128 + 64 * wn + 16 * (jj - 4) : 256 + 32 * wn + 16 * (jj - 8); };
     float4v acc2[2][10];
@@ -185,13 +178,29 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
         acc2[1][jj] = b0;
     }
 
+    // ---- the rows as B-operand fragments in registers: xreg[i][2 kt + kk] = xn[row 32 wm + 16 i + l15][64 kt + 32 kk + 8 g .. + 7] ----
+    half8v xreg[2][10];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sk = 0; sk < 10; ++sk)
+            xreg[i][sk] = *reinterpret_cast<const half8v*>(xs + (sk >> 1) * kTileHalfs + (32 * wm + 16 * i + l15) * 64 +
+                                                           (((((sk & 1) * 4 + g) ^ (l15 & 7))) << 3));
+    __syncthreads();  // every wave holds its rows: stages 0 .. 4 join the ring
+    issue(std::integral_constant<int, 2>{}, 0, 7);
+    issue(std::integral_constant<int, 3>{}, 0, 0);
+    issue(std::integral_constant<int, 4>{}, 0, 1);
+    issue(std::integral_constant<int, 5>{}, 0, 2);
+    issue(std::integral_constant<int, 6>{}, 0, 3);
+
     const int swz = l15 & 7;
     const int arow = (32 * wm + l15) * 64;   // this lane's row inside an operand tile ([row][64]); + 16 * 64 for the second row tile
     float4v acc1[2][4];
 
     // one tile step: wait for tile (chunk, SLOT) -- ring stage `stage` --, issue the tile RING - 1 ahead into the stage tile seq - 1 just
     // left, multiply.  `stage` / `istage` run mod RING on the scalar unit.
-    int stage = 0, istage = kRing - 1;
+    int stage = 5, istage = 4;  // tile 0 sits in stage 5; the first tile issued by the loop (seq RING - 1 = 7) goes to stage (7 + 5) % 8
     auto step = [&](auto slot_c, int chunk) __attribute__((always_inline)) {
         constexpr int slot = decltype(slot_c)::value;
         // this wave's 2 pieces of the tile have landed when at most its pieces of the younger tiles are in flight
@@ -203,7 +212,9 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
             case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
             case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
             case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's LDS writes -- xs, b1s, the g tile -- are complete before the barrier)
         __builtin_amdgcn_s_barrier();  // every wave's pieces of this tile are visible; every wave has left the tile before it (its stage is free)
@@ -229,19 +240,17 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
                     acc1[1][jj] = b0;
                 }
             }
-            const half_t* xt = xs + slot * kTileHalfs + arow;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int slot_off = (((kk * 4 + g) ^ swz) << 3);
-                half8v wf[4], xf[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const half8v*>(xt + i * (16 * 64) + slot_off);
+                half8v wf[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) wf[jj] = *reinterpret_cast<const half8v*>(tile + (64 * wn + 16 * jj + l15) * 64 + slot_off);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj], xf[i], acc1[i][jj], 0, 0, 0);
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj], xreg[i][2 * slot + kk], acc1[i][jj], 0, 0, 0);
             }
             if constexpr (slot == kKT1 - 1) {
                 // ---- GEGLU of the chunk -> g[row][hidden] (fp16, operand layout): hidden units 32 wn + 16 pr + 4 g .. + 3 of rows 16 i + l15.
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
         step(std::integral_constant<int, 6>{}, chunk); step(std::integral_constant<int, 7>{}, chunk);
     }
 
-    // ---- epilogue: the accumulator layout gives a lane 4 columns of ONE row; the fp32 tile goes through the idle LDS (x tiles + ring)
+    // ---- epilogue: the accumulator layout gives a lane 4 columns of ONE row; the fp32 tile goes through the idle LDS (the ring)
     // in two halves of 64 rows (64 x 324 x 4 B = 83 KB) so that the residual loads and the stores are 16 bytes per lane on consecutive
     // bytes of a row; the residual add is fp32, rounded once ----
     float* const stg = reinterpret_cast<float*>(lds);
