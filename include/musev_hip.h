@@ -145,6 +145,7 @@ typedef struct mv_ffn_desc {
     int32_t C, H;            /* 320, 1280                                                                       */
     int32_t ldx, ldr, ldo;   /* leading dimensions in elements (multiples of 8)                                 */
     float ln_eps;
+    int32_t flags;           /* bit 0: row blocks walk the hidden chunks from different starting chunks (spreads the weight reads) */
 } mv_ffn_desc;
 int mv_ffn_geglu_f16(const mv_ffn_desc* d, void* stream);
 

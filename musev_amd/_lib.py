@@ -45,7 +45,7 @@ class FfnDesc(C.Structure):
         ("x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("w1", C.c_void_p), ("bias1", C.c_void_p),
         ("w2", C.c_void_p), ("bias2", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
         ("M", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("ldx", C.c_int32), ("ldr", C.c_int32), ("ldo", C.c_int32),
-        ("ln_eps", C.c_float),
+        ("ln_eps", C.c_float), ("flags", C.c_int32),
     ]
 
 

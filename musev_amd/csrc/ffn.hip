@@ -44,6 +44,7 @@ struct FfnArgs {
     int ldx, ldr, ldo;
     float eps;
     unsigned w1_bytes, w2_bytes;
+    int rotate;              // blocks start their walk over the hidden chunks at different chunks (see ffn_geglu_kernel)
 };
 
 constexpr int kC = 320, kH = 1280;
@@ -73,8 +74,12 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
     const int nblk = (int)((p.M + kBM - 1) / kBM);
-    const int m0 = mv_xcd_remap(blockIdx.x, nblk) * kBM;
+    const int bid = mv_xcd_remap(blockIdx.x, nblk);
+    const int m0 = bid * kBM;
     const int Mi = (int)p.M;
+    // rotate: block b walks the chunks from chunk (7 b) % 20 on, so that the ~256 blocks in flight do not all ask the L2 for the same
+    // 16-KiB weight tile at the same moment (the sum over chunks is in a different -- fixed per row block -- order: bit-reproducible)
+    const int cbase = p.rotate ? (bid * 7) % kChunks : 0;
 
     const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, p.w1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, p.w2_bytes, 0x00020000);
@@ -103,8 +108,9 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
     }
     // the weight stream: tile (chunk, slot), slots 0 .. 4 = W1 k tiles, 5 .. 7 = W2 column tiles, into ring stage `stage`.  The slot is
     // a compile-time constant (the tile loop below is unrolled over a chunk's 8 steps): no branch, no division in the stream
-    auto issue = [&](auto slot_c, int chunk, int stage) __attribute__((always_inline)) {
+    auto issue = [&](auto slot_c, int chunk_i, int stage) __attribute__((always_inline)) {
         constexpr int slot = decltype(slot_c)::value;
+        const int chunk = chunk_i + cbase < kChunks ? chunk_i + cbase : chunk_i + cbase - kChunks;
         half_t* dst = ring + stage * kTileHalfs;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
     int stage = 5, istage = 4;  // tile 0 sits in stage 5; the first tile issued by the loop (seq RING - 1 = 7) goes to stage (7 + 5) % 8
     auto step = [&](auto slot_c, int chunk) __attribute__((always_inline)) {
         constexpr int slot = decltype(slot_c)::value;
+        const int chunk_w = chunk + cbase < kChunks ? chunk + cbase : chunk + cbase - kChunks;   // the chunk of the weights this step multiplies
         // this wave's 2 pieces of the tile have landed when at most its pieces of the younger tiles are in flight
         constexpr int left_in_chunk = kTilesPerChunk - 1 - slot;
         int younger = (kChunks - 1 - chunk) * kTilesPerChunk + left_in_chunk;  // tiles after this one
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
                 // start from b1: the wave's 4 packed column tiles [value 0 | gate 0 | value 1 | gate 1], columns 128 chunk + 64 wn + 16 jj + 4 g
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const half4v b = *reinterpret_cast<const half4v*>(b1s + 128 * chunk + 64 * wn + 16 * jj + 4 * g);
+                    const half4v b = *reinterpret_cast<const half4v*>(b1s + 128 * chunk_w + 64 * wn + 16 * jj + 4 * g);
                     const float4v b0 = float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
                     acc1[0][jj] = b0;
                     acc1[1][jj] = b0;
@@ -353,6 +360,7 @@ extern "C" int mv_ffn_geglu_f16(const mv_ffn_desc* d, void* stream) {
     a.w2 = (const half_t*)d->w2; a.bias2 = (const half_t*)d->bias2; a.residual = (const half_t*)d->residual; a.out = (half_t*)d->out;
     a.M = d->M; a.ldx = d->ldx; a.ldr = d->ldr; a.ldo = d->ldo; a.eps = d->ln_eps;
     a.w1_bytes = (unsigned)(2L * kH * kC * 2); a.w2_bytes = (unsigned)((long)kC * kH * 2);
+    a.rotate = (d->flags & 1) ? 1 : 0;
     constexpr int smem = kLdsHalfs * (int)sizeof(half_t);
     static_assert(smem <= 160 * 1024, "ffn tile does not fit LDS");
     static bool attr_done = false;

@@ -246,6 +246,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
 # projection + the output projection)
 FFN_FUSED: bool = os.environ.get("MUSEV_FFN_FUSED", "1") == "1"
 FFN_FUSED_HITS: int = 0
+FFN_ROTATE: bool = os.environ.get("MUSEV_FFN_ROTATE", "1") == "1"   # mv_ffn_desc.flags bit 0
 
 
 def ffn_fused_applies(c: int, hidden: int) -> bool:
@@ -273,6 +274,7 @@ def ffn_geglu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     d.x, d.ln_gamma, d.ln_beta, d.w1, d.bias1 = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w1p.data_ptr(), _p(b1p)
     d.w2, d.bias2, d.residual, d.out = w2.data_ptr(), _p(b2), residual.data_ptr(), o.data_ptr()
     d.M, d.C, d.H, d.ldx, d.ldr, d.ldo, d.ln_eps = M, c, hidden, x.stride(0), residual.stride(0), o.stride(0), float(eps)
+    d.flags = int(FFN_ROTATE)
     check(_lib.load().mv_ffn_geglu_f16(C.byref(d), _stream()), "mv_ffn_geglu_f16")
     global FFN_FUSED_HITS
     FFN_FUSED_HITS += 1

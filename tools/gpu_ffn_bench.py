@@ -47,7 +47,14 @@ for M in (53248, 106496, 119808):
         x = xs[k[0]]
         return ops.gemm(ops.gemm(ops.layernorm(x, gamma, beta, 1e-5), w1p, bias=b1p, geglu=True), w2, bias=b2, residual=x)
 
-    tf, t3 = timed(fused), timed(three)
+    ops.FFN_ROTATE = False
+    tf = timed(fused)
+    ops.FFN_ROTATE = True
+    tr = timed(fused)
+    t3 = timed(three)
     fl = 2.0 * M * c * 2 * hd + 2.0 * M * hd * c
-    print(f"M {M}: fused {tf:.1f} us ({fl / tf / 1e6:.0f} TFLOP/s)   three launches {t3:.1f} us ({fl / t3 / 1e6:.0f} TFLOP/s)   diff max "
-          f"{(fused().float() - three().float()).abs().max().item():.2e}", flush=True)
+    x0 = xs[0]
+    a_ = ops.ffn_geglu(x0, gamma, beta, 1e-5, w1p, b1p, w2, b2, x0).float()
+    b_ = ops.gemm(ops.gemm(ops.layernorm(x0, gamma, beta, 1e-5), w1p, bias=b1p, geglu=True), w2, bias=b2, residual=x0).float()
+    print(f"M {M}: fused {tf:.1f} us ({fl / tf / 1e6:.0f} TFLOP/s), rotated chunk order {tr:.1f} us ({fl / tr / 1e6:.0f})   three launches {t3:.1f} us "
+          f"({fl / t3 / 1e6:.0f} TFLOP/s)   diff max {(a_ - b_).abs().max().item():.2e}", flush=True)
