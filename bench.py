@@ -424,7 +424,11 @@ def main():
         rec, ops.GEMM_RECORD = ops.GEMM_RECORD, None
         den.use_graphs = True
         rows = []
-        for d, _keep, nb in rec:
+        for d, _keep, nb, *_ in rec:
+            if isinstance(d, _lib.FfnDesc):   # the fused level-0 feed-forward (mv_ffn_geglu_f16): both projections in one launch
+                rows.append({"mode": 3, "M": int(d.M), "N": int(d.C), "K": int(d.H), "geglu": 1, "ln": 1, "residual": 1, "colstats": 0, "cfg": -1,
+                             "nsplit": 1, "algorithmic_bytes": nb})
+                continue
             cfg, ns = C.c_int32(), C.c_int32()
             _lib.load().mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns))
             rows.append({"mode": int(d.mode), "M": int(d.M), "N": int(d.N), "K": int(d.K), "geglu": int(d.geglu), "ln": int(bool(d.ln_colsum)),
@@ -451,26 +455,36 @@ def main():
         sync_all()
         rec_all, ops.GEMM_RECORD = ops.GEMM_RECORD, None
         den.use_graphs = True
-        names = {0: "linear", 1: "conv3x3", 2: "tconv3"}
+        from musev_amd import _lib as _mvlib
+        names = {0: "linear", 1: "conv3x3", 2: "tconv3", 3: "ffn_fused"}
+
+        def rmode(d):
+            return 3 if isinstance(d, _mvlib.FfnDesc) else int(d.mode)
         reps = 3
         ops.replay_gemms(rec_all, 1)  # warm (clocks, code objects)
         fam_ms = ops.replay_gemms(rec_all, reps) / reps
         fam_n = len(rec_all)
-        fam_flops = sum(2.0 * d.M * d.N * d.K for d, _k, _b in rec_all)
-        fam_bytes = float(sum(nb for _d, _k, nb in rec_all))
+        fam_flops = sum(ops.record_flops(d) for d, _k, _b, *_ in rec_all)
+        fam_bytes = float(sum(nb for _d, _k, nb, *_ in rec_all))
         by_mode = {}
         for mode, nm in names.items():
-            sub = [r for r in rec_all if int(r[0].mode) == mode]
+            sub = [r for r in rec_all if rmode(r[0]) == mode]
             if not sub:
                 continue
             ms = ops.replay_gemms(sub, reps) / reps
-            fl = sum(2.0 * d.M * d.N * d.K for d, _k, _b in sub)
+            fl = sum(ops.record_flops(d) for d, _k, _b, *_ in sub)
             by_mode[nm] = {"tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "ms_per_step": ms, "launches_per_step": len(sub)}
         # the same launches as the loop runs them: the two CFG halves' lists concurrently on two streams (info; `achieved` stays the
         # one-stream figure, which is what a rocprofv3 kernel trace -- it serialises the streams -- reproduces)
         two_stream = None
         if den.half_streams and fam_n % 2 == 0 and hasattr(ops, "replay_gemms_two_streams"):
-            ha, hb = rec_all[:fam_n // 2], rec_all[fam_n // 2:]
+            # the two lists = the launches each of the loop's two streams issued (every recorded launch carries its stream; with more
+            # than one window per step a plain split of the list in half would mix the CFG halves of different windows)
+            main_s = torch.cuda.current_stream().cuda_stream
+            ha = [r for r in rec_all if r[3] == main_s]
+            hb = [r for r in rec_all if r[3] != main_s]
+            if not ha or not hb:
+                ha, hb = rec_all[:fam_n // 2], rec_all[fam_n // 2:]
             ops.replay_gemms_two_streams(ha, hb, 1)
             ms2 = ops.replay_gemms_two_streams(ha, hb, reps) / reps
             two_stream = {"family_ms_per_step": ms2, "tflops": fam_flops / (ms2 * 1e-3) / 1e12, "frac": fam_flops / (ms2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS}
@@ -488,7 +502,7 @@ def main():
             den.use_graphs, den.half_streams = True, True
             ops.replay_gemms(rec_b2, 1)
             ms_b2 = ops.replay_gemms(rec_b2, reps) / reps
-            fl_b2 = sum(2.0 * d.M * d.N * d.K for d, _k, _b in rec_b2)
+            fl_b2 = sum(ops.record_flops(d) for d, _k, _b, *_ in rec_b2)
             batch2 = {"family_ms_per_step": ms_b2, "tflops": fl_b2 / (ms_b2 * 1e-3) / 1e12, "frac": fl_b2 / (ms_b2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                       "launches_per_step": len(rec_b2)}
             del rec_b2
@@ -496,8 +510,11 @@ def main():
             probs = {}
             for r in rec_all:
                 d = r[0]
-                key = (names[int(d.mode)], int(d.M), int(d.N), int(d.K), "geglu" if d.geglu else "ln" if d.ln_colsum else "res" if d.residual else "-",
-                       int(bool(d.colstats)), int(bool(d.a2)))
+                if rmode(d) == 3:
+                    key = ("ffn_fused", int(d.M), int(d.C), int(d.H), "ln+geglu+res", 0, 0)
+                else:
+                    key = (names[int(d.mode)], int(d.M), int(d.N), int(d.K), "geglu" if d.geglu else "ln" if d.ln_colsum else "res" if d.residual else "-",
+                           int(bool(d.colstats)), int(bool(d.a2)))
                 probs.setdefault(key, []).append(r)
             rows = []
             for key, lst in probs.items():
@@ -505,7 +522,7 @@ def main():
                 ops.replay_gemms(one, 2)
                 us = ops.replay_gemms(one, 10) / 10 * 1e3
                 d = one[0][0]
-                fl = 2.0 * d.M * d.N * d.K
+                fl = ops.record_flops(d)
                 row = {"mode": key[0], "M": key[1], "N": key[2], "K": key[3], "epilogue": key[4], "colstats": key[5], "two_source": key[6],
                        "launches_per_step": len(lst), "us": us, "tflops": fl / us / 1e6, "algorithmic_GBps": one[0][2] / us / 1e3,
                        "ms_per_step": us * len(lst) / 1e3}
@@ -529,14 +546,14 @@ def main():
         del rec_all
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3)",
+            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
             # PMC bytes of the family per step / the step's API launches: the same denominator as algorithmic_bytes_per_launch
             "traffic": (measured_traffic(workload)[0] / max(fam_n, 1)) if measured_traffic(workload)[0] is not None else None,
             "traffic_unit": "HBM bytes per mv_gemm_f16 launch (PMC bytes of gemm2_kernel + splitk_reduce per step / launches per step)",
             "traffic_ratio": (measured_traffic(workload)[0] / fam_bytes) if (measured_traffic(workload)[0] is not None and fam_bytes > 0) else None,
             "traffic_source": measured_traffic(workload)[1],
-            "method": f"one recorded step's {fam_n} mv_gemm_f16 launches re-issued back to back on one stream, {reps} repetitions between "
+            "method": f"one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 launches re-issued back to back on one stream, {reps} repetitions between "
                       "one HIP event pair (device time; no per-launch host gap)",
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
             "launches_per_step": fam_n,

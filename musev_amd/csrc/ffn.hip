@@ -45,7 +45,14 @@ struct FfnArgs {
     float eps;
     unsigned w1_bytes, w2_bytes;
     int rotate;              // blocks start their walk over the hidden chunks at different chunks (see ffn_geglu_kernel)
+    int ablate;              // experiment builds only (MV_EXPERIMENT, tools/gpu_ffn_bench.py --ablate): bit 0 no gelu, 1 no phase-1 MFMAs,
+                             // 2 no phase-2 MFMAs, 3 no g tile write  (wrong results: timing only)
 };
+#ifdef MV_EXPERIMENT
+#define MV_FFN_ABL(bit) (p.ablate & (1 << (bit)))
+#else
+#define MV_FFN_ABL(bit) 0
+#endif
 
 constexpr int kC = 320, kH = 1280;
 constexpr int kBM = 128;                 // rows per block
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
-                        acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj], xreg[i][2 * slot + kk], acc1[i][jj], 0, 0, 0);
+                        if (!MV_FFN_ABL(1)) acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj], xreg[i][2 * slot + kk], acc1[i][jj], 0, 0, 0);
             }
             if constexpr (slot == kKT1 - 1) {
                 // ---- GEGLU of the chunk -> g[row][hidden] (fp16, operand layout): hidden units 32 wn + 16 pr + 4 g .. + 3 of rows 16 i + l15.
@@ -268,10 +275,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         const float4v v = acc1[i][2 * pr], gt = acc1[i][2 * pr + 1];
-                        const half4v o = half4v{(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
-                                                (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
+                        half4v o = half4v{(half_t)(v[0] * mv_gelu(gt[0])), (half_t)(v[1] * mv_gelu(gt[1])),
+                                          (half_t)(v[2] * mv_gelu(gt[2])), (half_t)(v[3] * mv_gelu(gt[3]))};
+                        if (MV_FFN_ABL(0)) o = half4v{(half_t)(v[0] * gt[0]), (half_t)(v[1] * gt[1]), (half_t)(v[2] * gt[2]), (half_t)(v[3] * gt[3])};
                         const int hcol = 32 * wn + 16 * pr + 4 * g;  // hidden index inside the chunk
-                        *reinterpret_cast<half4v*>(gbuf + row * 64 + ((((hcol >> 3) ^ (row & 7)) << 3) | (hcol & 7))) = o;
+                        if (!MV_FFN_ABL(3)) *reinterpret_cast<half4v*>(gbuf + row * 64 + ((((hcol >> 3) ^ (row & 7)) << 3) | (hcol & 7))) = o;
                     }
                 }
             }
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int jj = 0; jj < TN; ++jj)
-                        acc2[i][4 * t + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj], gf[i], acc2[i][4 * t + jj], 0, 0, 0);
+                        if (!MV_FFN_ABL(2)) acc2[i][4 * t + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj], gf[i], acc2[i][4 * t + jj], 0, 0, 0);
             }
         }
     };
@@ -361,6 +369,7 @@ extern "C" int mv_ffn_geglu_f16(const mv_ffn_desc* d, void* stream) {
     a.M = d->M; a.ldx = d->ldx; a.ldr = d->ldr; a.ldo = d->ldo; a.eps = d->ln_eps;
     a.w1_bytes = (unsigned)(2L * kH * kC * 2); a.w2_bytes = (unsigned)((long)kC * kH * 2);
     a.rotate = (d->flags & 1) ? 1 : 0;
+    a.ablate = (d->flags >> 8) & 0xff;
     constexpr int smem = kLdsHalfs * (int)sizeof(half_t);
     static_assert(smem <= 160 * 1024, "ffn tile does not fit LDS");
     static bool attr_done = false;

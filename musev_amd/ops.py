@@ -90,13 +90,14 @@ def _carry_setup(d: GemmDesc, o: torch.Tensor, residual: Optional[torch.Tensor],
 def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
+    pending_stats = None
     if colstats_for is not None and COLSTATS:
         rpt, nfl = C.c_int32(), C.c_int64()
         check(lib.mv_gemm_stats_layout(C.byref(d), C.byref(rpt), C.byref(nfl)), what)
         if rpt.value > 0:
             cs = torch.empty(nfl.value, dtype=torch.float32, device=dev)
             d.colstats, d.colstats_floats = cs.data_ptr(), nfl.value
-            colstats_for._mv_colstats = (cs, rpt.value)
+            pending_stats = (cs, rpt.value)
             keep = keep + (cs,)
     need = lib.mv_gemm_workspace_bytes(C.byref(d))
     if need < 0:
@@ -106,6 +107,10 @@ def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), co
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), need
     check(lib.mv_gemm_f16(C.byref(d), _stream()), what)
+    if pending_stats is not None:
+        # (set once the launch was accepted; the tensor's torch version rides along: a later in-place torch op on the tensor -- copy_,
+        # add_, ... -- bumps it and groupnorm() then ignores the stale statistics)
+        colstats_for._mv_colstats = pending_stats + (colstats_for._version,)
     if GEMM_RECORD is not None:
         # algorithmic HBM bytes of the launch: every operand read once, the output written once
         rows_in = int(d.M)
@@ -114,7 +119,21 @@ def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), co
         cols = int(d.N) // 2 if d.geglu else int(d.N)
         nbytes = 2 * (rows_in * (int(d.c1) + int(d.c2)) + int(d.N) * int(d.K) +
                       int(d.M) * cols * ((2 if d.residual else 1) + (1 if d.c_lo else 0) + (1 if d.residual_lo else 0)))
-        GEMM_RECORD.append((GemmDesc.from_buffer_copy(d), keep + (ws,), nbytes))
+        GEMM_RECORD.append((GemmDesc.from_buffer_copy(d), keep + (ws,), nbytes, _stream()))
+
+
+def _replay_one(lib, d, st) -> None:
+    if isinstance(d, _lib.FfnDesc):
+        check(lib.mv_ffn_geglu_f16(C.byref(d), st), "mv_ffn_geglu_f16(replay)")
+    else:
+        check(lib.mv_gemm_f16(C.byref(d), st), "mv_gemm_f16(replay)")
+
+
+def record_flops(d) -> float:
+    """algorithmic FLOPs of a recorded launch (mv_gemm_f16: 2 M N K; the fused feed-forward: both projections)"""
+    if isinstance(d, _lib.FfnDesc):
+        return 2.0 * d.M * d.C * 2 * d.H + 2.0 * d.M * d.H * d.C
+    return 2.0 * d.M * d.N * d.K
 
 
 def replay_gemms(record: Sequence[tuple], reps: int = 1) -> float:
@@ -126,8 +145,8 @@ def replay_gemms(record: Sequence[tuple], reps: int = 1) -> float:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        for d, _keep, _nb in record:
-            check(lib.mv_gemm_f16(C.byref(d), st), "mv_gemm_f16(replay)")
+        for d, _keep, _nb, *_ in record:
+            _replay_one(lib, d, st)
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1)
@@ -278,6 +297,9 @@ def ffn_geglu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     check(_lib.load().mv_ffn_geglu_f16(C.byref(d), _stream()), "mv_ffn_geglu_f16")
     global FFN_FUSED_HITS
     FFN_FUSED_HITS += 1
+    if GEMM_RECORD is not None:  # the fused feed-forward is matrix work of the same family: recorded next to the mv_gemm_f16 launches
+        nbytes = 2 * (3 * M * c + 3 * hidden * c)   # x, the residual and the output once; both weight matrices once
+        GEMM_RECORD.append((_lib.FfnDesc.from_buffer_copy(d), (x, gamma, beta, w1p, b1p, w2, b2, residual, o), nbytes, _stream()))
     return o
 
 
@@ -291,10 +313,10 @@ def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], rep
     e0.record(main)
     side.wait_stream(main)
     for _ in range(reps):
-        for d, _keep, _nb in rec_b:
-            check(lib.mv_gemm_f16(C.byref(d), side.cuda_stream), "mv_gemm_f16(replay)")
-        for d, _keep, _nb in rec_a:
-            check(lib.mv_gemm_f16(C.byref(d), main.cuda_stream), "mv_gemm_f16(replay)")
+        for d, _keep, _nb, *_ in rec_b:
+            _replay_one(lib, d, side.cuda_stream)
+        for d, _keep, _nb, *_ in rec_a:
+            _replay_one(lib, d, main.cuda_stream)
     main.wait_stream(side)
     e1.record(main)
     e1.synchronize()
@@ -316,7 +338,7 @@ def ln_fold_applies(M: int, N: int, K: int, geglu: bool) -> bool:
         # epilogue instead of the in-loop ones -- which would also let the GEGLU launch fold -- measured +0.6 ms per step:
         # profiles/r03o_rowstats_ab.log, commit 35438ca; not kept.)
         return False
-    key = (M, N, K, bool(geglu))
+    key = (M, N, K, bool(geglu), GEMM_CFG, GEMM_SPLITK)   # (the tuner / A-B tools change the forced configuration at run time)
     hit = _ln_fold_cache.get(key)
     if hit is None:
         d = GemmDesc()
@@ -431,6 +453,10 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
         o._mv_lo = y_lo
     cs1 = getattr(x, "_mv_colstats", None) if COLSTATS else None
     cs2 = getattr(x2, "_mv_colstats", None) if (COLSTATS and x2 is not None) else None
+    if cs1 is not None and len(cs1) > 2 and cs1[2] != x._version:
+        cs1 = None   # the tensor was modified in place after its producer wrote the statistics
+    if cs2 is not None and len(cs2) > 2 and cs2[2] != x2._version:
+        cs2 = None
     if cs1 is not None and rows % cs1[1] == 0 and (x2 is None or (cs2 is not None and rows % cs2[1] == 0)):
         # the producers of x (and x2) left column statistics behind: fold those instead of reading the tensors once more
         global COLSTATS_HITS

@@ -30,11 +30,32 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+ABLATE = "--ablate" in sys.argv
+if ABLATE:
+    # ablation through the EXPERIMENT build (MV_EXTRA_FLAGS=-DMV_EXPERIMENT MV_LIB_NAME=libmusev_hip_exp.so): flags bits 8.. switch parts of
+    # the kernel off (wrong results, timing only) -- what bounds the block?
+    import ctypes as C
+    from musev_amd import _lib
+    exp = C.CDLL(os.path.join(ROOT, "musev_amd", "csrc", "libmusev_hip_exp.so"))
+    exp.mv_ffn_geglu_f16.restype = C.c_int32
+    exp.mv_ffn_geglu_f16.argtypes = [C.POINTER(_lib.FfnDesc), C.c_void_p]
+    prod = _lib.load()
+    abl = [0]
+
+    class Shim:
+        def __getattr__(self, name):
+            if name == "mv_ffn_geglu_f16":
+                def f(desc, stream):
+                    desc._obj.flags |= abl[0] << 8
+                    return exp.mv_ffn_geglu_f16(desc, stream)
+                return f
+            return getattr(prod, name)
+    _lib._lib = Shim()
 c, hd = 320, 1280
 gamma, beta = rnd((c,), 1, 0.2) + 1, rnd((c,), 2, 0.2)
 w1p, b1p = ops.pack_geglu(rnd((2 * hd, c), 3, 1 / math.sqrt(c)), rnd((2 * hd,), 4, 0.3))
 w2, b2 = rnd((c, hd), 5, 1 / math.sqrt(hd)), rnd((c,), 6, 0.3)
-for M in (53248, 106496, 119808):
+for M in ((53248,) if ABLATE else (53248, 106496, 119808)):
     xs = [rnd((M, c), 10 + i, 1.5) for i in range(4)]   # cycled: 4 x 34 MB inputs
     k = [0]
 
@@ -47,6 +68,12 @@ for M in (53248, 106496, 119808):
         x = xs[k[0]]
         return ops.gemm(ops.gemm(ops.layernorm(x, gamma, beta, 1e-5), w1p, bias=b1p, geglu=True), w2, bias=b2, residual=x)
 
+    if ABLATE:
+        for bits, what in ((0, "full kernel"), (1, "no gelu (value * gate)"), (2, "no phase-1 MFMAs"), (4, "no phase-2 MFMAs"), (6, "no MFMAs at all"),
+                           (7, "no MFMAs, no gelu"), (15, "no MFMAs, no gelu, no g write: the weight stream + barriers + fragment reads")):
+            abl[0] = bits
+            print(f"M {M} ablate {bits:2d} {what}: {timed(fused):.1f} us", flush=True)
+        continue
     ops.FFN_ROTATE = False
     tf = timed(fused)
     ops.FFN_ROTATE = True
