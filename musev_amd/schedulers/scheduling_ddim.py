@@ -3,8 +3,9 @@ diffusers' DDIMScheduler): ``set_timesteps``, ``timesteps``, ``scale_model_input
 ``step(...).prev_sample``.  Constants (betas, alphas_cumprod, timestep table) are host-side; the elementwise update
 itself runs in the fused HIP kernel ``mv_cfg_ddim_step`` (no torch elementwise fallback).
 
-Scope: epsilon prediction, eta = 0, no clipping/thresholding -- the SD-1.5 configuration BASELINE.json's metric is
-quoted on.  Other prediction types / eta > 0 / video-fusion noise raise NotImplementedError ("next" row)."""
+Scope: epsilon prediction (the SD-1.5 configuration BASELINE.json's metric is quoted on) and v-prediction with the zero-terminal-SNR
+beta rescale and "trailing" timestep spacing (the predictor's `enable_zero_snr` scheduler, pipeline_controlnet_predictor.py:270-282);
+eta = 0, no clipping / thresholding.  "sample" prediction and eta > 0 raise NotImplementedError."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -15,6 +16,17 @@ import numpy as np
 import torch
 
 from .. import ops
+
+
+def rescale_zero_terminal_snr(betas: torch.Tensor) -> torch.Tensor:
+    """diffusers' rescale_zero_terminal_snr (Lin et al., "Common Diffusion Noise Schedules and Sample Steps are Flawed", alg. 1):
+    shift and scale sqrt(alpha_bar) so that the last timestep has zero SNR and the first keeps its value"""
+    alphas_bar_sqrt = torch.cumprod(1.0 - betas, dim=0).sqrt()
+    a0, aT = alphas_bar_sqrt[0].clone(), alphas_bar_sqrt[-1].clone()
+    alphas_bar_sqrt = (alphas_bar_sqrt - aT) * (a0 / (a0 - aT))
+    alphas_bar = alphas_bar_sqrt ** 2
+    alphas = torch.cat([alphas_bar[0:1], alphas_bar[1:] / alphas_bar[:-1]])
+    return 1.0 - alphas
 
 
 @dataclass
@@ -28,7 +40,8 @@ class DDIMScheduler:
 
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
                  beta_schedule: str = "scaled_linear", clip_sample: bool = False, set_alpha_to_one: bool = False,
-                 steps_offset: int = 1, prediction_type: str = "epsilon", timestep_spacing: str = "leading"):
+                 steps_offset: int = 1, prediction_type: str = "epsilon", timestep_spacing: str = "leading",
+                 rescale_betas_zero_snr: bool = False):
         # constants are built with torch on the host exactly like diffusers does (fp32 linspace / cumprod), so that
         # alpha_bar_t matches the reference bit for bit
         if beta_schedule == "scaled_linear":
@@ -37,14 +50,16 @@ class DDIMScheduler:
             betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
         else:
             raise NotImplementedError(f"{beta_schedule} is not implemented for {self.__class__}")
-        if prediction_type != "epsilon" or clip_sample:
-            raise NotImplementedError("only epsilon prediction without clipping (SD-1.5 config)")
-        if timestep_spacing != "leading":
-            raise NotImplementedError("only 'leading' timestep spacing (SD-1.5 config)")
+        if prediction_type not in ("epsilon", "v_prediction") or clip_sample:
+            raise NotImplementedError("epsilon / v_prediction without clipping")
+        if timestep_spacing not in ("leading", "trailing"):
+            raise NotImplementedError("'leading' (SD-1.5 config) or 'trailing' (zero-SNR config) timestep spacing")
+        if rescale_betas_zero_snr:
+            betas = rescale_zero_terminal_snr(betas)
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       beta_schedule=beta_schedule, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
                                       steps_offset=steps_offset, prediction_type=prediction_type,
-                                      timestep_spacing=timestep_spacing)
+                                      timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self.init_noise_sigma = 1.0
@@ -58,8 +73,12 @@ class DDIMScheduler:
         if num_inference_steps > self.config.num_train_timesteps:
             raise ValueError("`num_inference_steps` cannot be larger than `num_train_timesteps`")
         self.num_inference_steps = num_inference_steps
-        ratio = self.config.num_train_timesteps // num_inference_steps
-        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        if self.config.timestep_spacing == "trailing":
+            ratio = self.config.num_train_timesteps / num_inference_steps
+            ts = np.round(np.arange(self.config.num_train_timesteps, 0, -ratio)).astype(np.int64) - 1
+        else:
+            ratio = self.config.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
         self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
 
     def alphas_for(self, timestep: int) -> Tuple[float, float]:
@@ -89,7 +108,20 @@ class DDIMScheduler:
                     step_index: int, timestep) -> None:
         """fused average / CFG / DDIM step on the loop state (latents fp32 [C, T, HW], in place)"""
         a_t, a_prev = self.alphas_for(int(timestep))
-        ops.cfg_ddim_step(latents, eps_acc, counter, guidance, a_t, a_prev)
+        if self.config.prediction_type == "v_prediction":
+            cx, ce = self.v_coefficients(a_t, a_prev)
+            ops.cfg_affine_step(latents, eps_acc, counter, guidance, cx, ce)
+        else:
+            ops.cfg_ddim_step(latents, eps_acc, counter, guidance, a_t, a_prev)
+
+    @staticmethod
+    def v_coefficients(a_t: float, a_prev: float) -> Tuple[float, float]:
+        """x_prev = cx x + ce v for v-prediction at eta = 0 (scheduling_ddim.py:224-231,257-264): x0 = sqrt(a_t) x - sqrt(1 - a_t) v,
+        eps = sqrt(a_t) v + sqrt(1 - a_t) x, x_prev = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps -- an affine map of (x, v), so the
+        fused CFG + affine step kernel of the Euler scheduler serves it"""
+        sa, sb = a_t ** 0.5, (1.0 - a_t) ** 0.5
+        pa, pb = a_prev ** 0.5, (1.0 - a_prev) ** 0.5
+        return pa * sa + pb * sb, pb * sa - pa * sb
 
     def step(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0,
              use_clipped_model_output: bool = False, generator=None, variance_noise=None, return_dict: bool = True,
@@ -103,7 +135,11 @@ class DDIMScheduler:
         x = sample.detach().to(torch.float32).reshape(1, -1, 1, 1).clone().view(-1, 1, 1)   # [C=n, T=1, HW=1] view of all elements
         eps = model_output.detach().to(torch.float32).reshape(1, -1, 1, 1).contiguous()
         ones = torch.ones(1, dtype=torch.float32, device=sample.device)
-        ops.cfg_ddim_step(x, eps, ones, 0.0, a_t, a_prev)
+        if self.config.prediction_type == "v_prediction":
+            cx, ce = self.v_coefficients(a_t, a_prev)
+            ops.cfg_affine_step(x, eps, ones, 0.0, cx, ce)
+        else:
+            ops.cfg_ddim_step(x, eps, ones, 0.0, a_t, a_prev)
         prev = x.view(shape).to(sample.dtype)
         if not return_dict:
             return (prev,)

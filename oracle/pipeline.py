@@ -85,8 +85,18 @@ class DDIMOracle:
     set_alpha_to_one False, epsilon prediction, "leading" spacing), eta = 0."""
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
-                 set_alpha_to_one=False):
-        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+                 set_alpha_to_one=False, beta_schedule="scaled_linear", prediction_type="epsilon", timestep_spacing="leading",
+                 rescale_betas_zero_snr=False):
+        if beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        if rescale_betas_zero_snr:  # diffusers rescale_zero_terminal_snr (un-vendored: restated from upstream, unpinned)
+            abs_ = torch.cumprod(1.0 - betas, dim=0).sqrt()
+            a0, aT = abs_[0].clone(), abs_[-1].clone()
+            ab = ((abs_ - aT) * (a0 / (a0 - aT))) ** 2
+            betas = 1.0 - torch.cat([ab[0:1], ab[1:] / ab[:-1]])
+        self.prediction_type, self.timestep_spacing = prediction_type, timestep_spacing
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self.num_train_timesteps = num_train_timesteps
@@ -96,8 +106,11 @@ class DDIMOracle:
 
     def set_timesteps(self, n: int):
         self.num_inference_steps = n
-        ratio = self.num_train_timesteps // n
-        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
+        if self.timestep_spacing == "trailing":  # diffusers "trailing" spacing (un-vendored base class: restated, unpinned)
+            ts = np.round(np.arange(self.num_train_timesteps, 0, -self.num_train_timesteps / n)).astype(np.int64) - 1
+        else:
+            ratio = self.num_train_timesteps // n
+            ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
         self.timesteps = torch.from_numpy(ts)
 
     def alphas(self, t: int):
@@ -110,8 +123,13 @@ class DDIMOracle:
         """scheduling_ddim.py:198-264 with eta = 0, epsilon prediction, no clipping."""
         a_t, a_prev = self.alphas(int(t))
         beta_t = 1 - a_t
-        x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5  # :214-218
-        direction = (1 - a_prev) ** 0.5 * model_output              # :257-259 (std_dev_t = 0)
+        if self.prediction_type == "v_prediction":                  # :224-231
+            x0 = a_t ** 0.5 * sample - beta_t ** 0.5 * model_output
+            eps = a_t ** 0.5 * model_output + beta_t ** 0.5 * sample
+        else:
+            x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5  # :214-218
+            eps = model_output
+        direction = (1 - a_prev) ** 0.5 * eps                       # :257-259 (std_dev_t = 0)
         return a_prev ** 0.5 * x0 + direction                       # :262-264
 
 

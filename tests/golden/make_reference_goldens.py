@@ -121,6 +121,15 @@ def gen_ddim():
     np.savez_compressed(os.path.join(HERE, "reference_ddim.npz"), timesteps=s.timesteps.numpy(),
                         alphas_cumprod=s.alphas_cumprod.numpy(), **outs)
     print("ddim:", s.timesteps.tolist()[:3], "...")
+    # the predictor's zero-SNR scheduler (pipeline_controlnet_predictor.py:270-282): v-prediction through the reference's own step
+    # (scheduling_ddim.py:224-231); the beta rescale and the "trailing" spacing come from the stand-in base class (upstream, unpinned)
+    s = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                      prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    s.set_timesteps(20)
+    outs = {f"t{int(t)}": s.step(eps, int(t), x).prev_sample.numpy() for t in s.timesteps[[0, 7, 18, 19]]}
+    np.savez_compressed(os.path.join(HERE, "reference_ddim_vpred.npz"), timesteps=s.timesteps.numpy(),
+                        alphas_cumprod=s.alphas_cumprod.numpy(), **outs)
+    print("ddim v-prediction / zero SNR:", s.timesteps.tolist()[:3], "...", float(s.alphas_cumprod[-1]))
 
 
 def gen_euler():
@@ -361,6 +370,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--multi-shot" in sys.argv:
         gen_multi_shot()
+        sys.exit(0)
+    if "--ddim" in sys.argv:
+        gen_ddim()
         sys.exit(0)
     if "--at-size" in sys.argv:  # the BASELINE-size UNet cases only (minutes of CPU, ~25 GB)
         gen_unet(UNET_CASES_AT_SIZE)

@@ -423,6 +423,11 @@ class DiffusersDDIMScheduler(SchedulerMixin, ConfigMixin):
             self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         else:
             raise NotImplementedError(beta_schedule)
+        if rescale_betas_zero_snr:  # upstream rescale_zero_terminal_snr
+            abs_ = torch.cumprod(1.0 - self.betas, dim=0).sqrt()
+            a0, aT = abs_[0].clone(), abs_[-1].clone()
+            ab = ((abs_ - aT) * (a0 / (a0 - aT))) ** 2
+            self.betas = 1.0 - torch.cat([ab[0:1], ab[1:] / ab[:-1]])
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
@@ -440,9 +445,12 @@ class DiffusersDDIMScheduler(SchedulerMixin, ConfigMixin):
 
     def set_timesteps(self, num_inference_steps, device=None):
         self.num_inference_steps = num_inference_steps
-        assert self.config.timestep_spacing == "leading"
-        ratio = self.config.num_train_timesteps // num_inference_steps
-        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        if self.config.timestep_spacing == "trailing":
+            ts = np.round(np.arange(self.config.num_train_timesteps, 0, -self.config.num_train_timesteps / num_inference_steps)).astype(np.int64) - 1
+        else:
+            assert self.config.timestep_spacing == "leading"
+            ratio = self.config.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
         self.timesteps = torch.from_numpy(ts).to(device)
 
 

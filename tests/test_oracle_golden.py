@@ -96,6 +96,33 @@ def test_ddim_matches_reference():
         assert p.alphas_for(t) == o.alphas(t)
 
 
+def test_ddim_v_prediction_zero_snr_matches_reference():
+    """the predictor's `enable_zero_snr` scheduler (pipeline_controlnet_predictor.py:270-282): v-prediction, zero-terminal-SNR betas,
+    "trailing" spacing -- oracle step and the product's affine coefficients against the reference's own step (scheduling_ddim.py:224-264)"""
+    from oracle import pipeline as opipe
+    from musev_amd.schedulers import DDIMScheduler
+    g = np.load(os.path.join(GOLD, "reference_ddim_vpred.npz"))
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, prediction_type="v_prediction",
+              rescale_betas_zero_snr=True, timestep_spacing="trailing", set_alpha_to_one=True)   # (diffusers' default: the predictor does not pass it)
+    o = opipe.DDIMOracle(**kw)
+    o.set_timesteps(20)
+    p = DDIMScheduler(clip_sample=False, **kw)
+    p.set_timesteps(20)
+    assert o.timesteps.tolist() == g["timesteps"].tolist() == p.timesteps.tolist()
+    assert np.allclose(o.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=0, atol=1e-7)
+    assert np.allclose(p.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=0, atol=1e-7)
+    assert float(p.alphas_cumprod[-1]) == 0.0   # zero terminal SNR
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 4, 6, 8, 8, generator=gen)
+    v = torch.randn(1, 4, 6, 8, 8, generator=gen)
+    for key in (k for k in g.files if k.startswith("t") and k[1:].isdigit()):
+        t = int(key[1:])
+        want = torch.from_numpy(g[key])
+        assert (o.step(v, t, x) - want).abs().max().item() < 1e-5, t
+        cx, ce = p.v_coefficients(*p.alphas_for(t))           # what loop_update hands mv_cfg_affine_step
+        assert (cx * x + ce * v - want).abs().max().item() < 1e-5, t
+
+
 def test_datautil_semantics():
     """the index helpers the loop relies on (data_util.py:242-292,413-437,605-652) and the AdaIN no-op (:550-602)"""
     from oracle import unet3d
