@@ -565,7 +565,10 @@ def main():
             "batch2_one_stream": batch2,
             "whole_step": {"algorithmic_tflop_per_rank_step": per_rank_flops / 1e12,
                            "achieved_tflops_per_gpu": per_rank_flops / (ms_per_step * 1e-3) / 1e12,
-                           "frac_of_mfma_peak": per_rank_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
+                           "frac_of_mfma_peak": per_rank_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                           # algorithmic = the reference's work (both CFG halves in full); with the shared front the part
+                           # of a window forward in front of the first cross-attention is executed once for both halves
+                           "shared_cfg_prefix": bool(getattr(den, "share_cfg_prefix", False) and den.half_streams)},
         }
 
     cpu, cpu_timed_out = None, False

@@ -125,6 +125,11 @@ def load() -> C.CDLL:
         raise MuseVHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(musev_amd has no CPU fallback)")
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64, same soname as /opt/rocm's).  Whichever copy the process loads
+    # first serves both; with libmusev_hip.so loaded ahead of torch the system runtime came first and torch's device enumeration
+    # then failed on the GPU box ("no ROCm-capable device is detected" at the first launch, profiles/r04y_smoke.log: build() and
+    # smoke() in one process).  Tensors, streams and graphs are torch's: its runtime is the one that must be resident.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: the ABI is incomplete

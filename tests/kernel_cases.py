@@ -251,7 +251,7 @@ def case_carry(kind="linear", n=3, h=16, w=16, cin=64, c=320, cfg=None, seed=600
         cs = getattr(s2, "_mv_colstats", None)
         if cs is None:
             return {"name": name, "ok": False, "max_abs_err": float("nan"), "detail": "no column statistics next to the carry"}
-        buf, rpt = cs
+        buf, rpt = cs[:2]
         tiles = (M + rpt - 1) // rpt
         tf = s2.float()
         if tiles * rpt != M:
@@ -372,7 +372,7 @@ def case_colstats_groupnorm(kind="conv", n=3, h=16, w=16, cin=64, c=320, c2=0, c
         cs = getattr(t, "_mv_colstats", None)
         if cs is None:
             return {"name": f"colstats {kind} cfg{cfg}", "ok": False, "max_abs_err": float("nan"), "detail": "producer emitted no column statistics"}
-        buf, rpt = cs
+        buf, rpt = cs[:2]
         tiles = (t.shape[0] + rpt - 1) // rpt
         tf = t.float()
         pad = tiles * rpt - t.shape[0]
