@@ -448,10 +448,15 @@ def main():
         # launch latency inside each "duration": 104 us per launch on the driver's box against 88 us in the rocprofv3 trace.)
         # The record is taken with the loop's own stream setting, so the problem sizes are the ones the timed region ran (two
         # batch-1 forwards per window when the CFG halves run on two streams).
+        # The recorder keeps every operand of the recorded launches alive: a whole step of a many-window workload (config 4: 12
+        # windows, config 5: 768 x 768) would pin hundreds of GB.  Every window issues the same launches, so ONE window is recorded
+        # (12 frames) and the per-step figures are that window's times the step's window count (`recorded_windows` says so).
+        rec_lat = None if n_windows == 1 else make_latents(win)
+        rec_scale = 1 if n_windows == 1 else n_windows
         ops.GEMM_RECORD = []
         den.use_graphs = False
         sync_all()
-        run_steps(1)
+        run_steps(1, None, rec_lat)
         sync_all()
         rec_all, ops.GEMM_RECORD = ops.GEMM_RECORD, None
         den.use_graphs = True
@@ -473,7 +478,7 @@ def main():
                 continue
             ms = ops.replay_gemms(sub, reps) / reps
             fl = sum(ops.record_flops(d) for d, _k, _b, *_ in sub)
-            by_mode[nm] = {"tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "ms_per_step": ms, "launches_per_step": len(sub)}
+            by_mode[nm] = {"tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "ms_per_step": ms * rec_scale, "launches_per_step": len(sub) * rec_scale}
         # the same launches as the loop runs them: the two CFG halves' lists concurrently on two streams (info; `achieved` stays the
         # one-stream figure, which is what a rocprofv3 kernel trace -- it serialises the streams -- reproduces)
         two_stream = None
@@ -487,7 +492,7 @@ def main():
                 ha, hb = rec_all[:fam_n // 2], rec_all[fam_n // 2:]
             ops.replay_gemms_two_streams(ha, hb, 1)
             ms2 = ops.replay_gemms_two_streams(ha, hb, reps) / reps
-            two_stream = {"family_ms_per_step": ms2, "tflops": fam_flops / (ms2 * 1e-3) / 1e12, "frac": fam_flops / (ms2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS}
+            two_stream = {"family_ms_per_step": ms2 * rec_scale, "tflops": fam_flops / (ms2 * 1e-3) / 1e12, "frac": fam_flops / (ms2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS}
         # and the same step as ONE batch-2 forward per window on one stream (MUSEV_HALF_STREAMS=0): the launches round 2's roofline
         # timed (its timed path was the two-stream one as well, but the per-launch pass ran the batch-2 forward) -- info, for
         # round-over-round comparison
@@ -496,15 +501,15 @@ def main():
             ops.GEMM_RECORD = []
             den.use_graphs, den.half_streams = False, False
             sync_all()
-            run_steps(1)
+            run_steps(1, None, rec_lat)
             sync_all()
             rec_b2, ops.GEMM_RECORD = ops.GEMM_RECORD, None
             den.use_graphs, den.half_streams = True, True
             ops.replay_gemms(rec_b2, 1)
             ms_b2 = ops.replay_gemms(rec_b2, reps) / reps
             fl_b2 = sum(ops.record_flops(d) for d, _k, _b, *_ in rec_b2)
-            batch2 = {"family_ms_per_step": ms_b2, "tflops": fl_b2 / (ms_b2 * 1e-3) / 1e12, "frac": fl_b2 / (ms_b2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
-                      "launches_per_step": len(rec_b2)}
+            batch2 = {"family_ms_per_step": ms_b2 * rec_scale, "tflops": fl_b2 / (ms_b2 * 1e-3) / 1e12, "frac": fl_b2 / (ms_b2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                      "launches_per_step": len(rec_b2) * rec_scale}
             del rec_b2
         if args.gemm_by_problem and rank == 0:
             probs = {}
@@ -549,17 +554,18 @@ def main():
             "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
             # PMC bytes of the family per step / the step's API launches: the same denominator as algorithmic_bytes_per_launch
-            "traffic": (measured_traffic(workload)[0] / max(fam_n, 1)) if measured_traffic(workload)[0] is not None else None,
+            "traffic": (measured_traffic(workload)[0] / max(fam_n * rec_scale, 1)) if measured_traffic(workload)[0] is not None else None,
             "traffic_unit": "HBM bytes per mv_gemm_f16 launch (PMC bytes of gemm2_kernel + splitk_reduce per step / launches per step)",
-            "traffic_ratio": (measured_traffic(workload)[0] / fam_bytes) if (measured_traffic(workload)[0] is not None and fam_bytes > 0) else None,
+            "traffic_ratio": (measured_traffic(workload)[0] / (fam_bytes * rec_scale)) if (measured_traffic(workload)[0] is not None and fam_bytes > 0) else None,
             "traffic_source": measured_traffic(workload)[1],
             "method": f"one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 launches re-issued back to back on one stream, {reps} repetitions between "
                       "one HIP event pair (device time; no per-launch host gap)",
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
-            "launches_per_step": fam_n,
+            "launches_per_step": fam_n * rec_scale,
+            "recorded_windows": f"1 of {n_windows} (every window issues the same launches; per-step figures = the recorded window x {n_windows})",
             "avg_launch_ms": fam_ms / max(fam_n, 1),
             "algorithmic_flops_per_launch": fam_flops / max(fam_n, 1),
-            "family_ms_per_step": fam_ms,
+            "family_ms_per_step": fam_ms * rec_scale,
             "by_mode": by_mode,
             "two_streams": two_stream,
             "batch2_one_stream": batch2,

@@ -25,6 +25,9 @@ def dispatch_values(path):
 def join(launches, fetch, write):
     """per launch: the gemm2_kernel dispatch (+ the splitk_reduce dispatch behind it when the launch was split).  The counter passes
     hold several identical steps (warm-up + timed + the first eager pass): the LAST complete step is used."""
+    have_ffn = any("ffn_geglu" in r[1] for r in fetch)
+    if not have_ffn:  # rows kept before the fused feed-forward's dispatches were part of the filter: its launches cannot be joined
+        launches = [l for l in launches if l["mode"] != 3]
     per_step = sum(1 + (1 if l["nsplit"] > 1 else 0) for l in launches)
     out = []
     for rows in (fetch, write):
@@ -35,7 +38,8 @@ def join(launches, fetch, write):
     res, i = [], 0
     for l in launches:
         n = 1 + (1 if l["nsplit"] > 1 else 0)
-        if not ("gemm2_kernel" in f[i][1] and (n == 1 or "splitk_reduce" in f[i + 1][1])):
+        want = "ffn_geglu" if l["mode"] == 3 else "gemm2_kernel"
+        if not (want in f[i][1] and (n == 1 or "splitk_reduce" in f[i + 1][1])):
             raise SystemExit(f"dispatch order does not match the launch list at launch {len(res)}: {f[i][1][:60]}")
         fb = sum(v for _d, _n, v in f[i:i + n])
         wb = sum(v for _d, _n, v in w[i:i + n])
@@ -52,7 +56,7 @@ def main():
     write = dispatch_values(os.path.join(out, f"{tag}_pmc_WRITE_SIZE_gemm_rows.csv"))
     agg = defaultdict(lambda: [0, 0.0, 0.0])
     for l, measured in join(launches, fetch, write):
-        key = (("linear", "conv3x3", "tconv3")[l["mode"]], l["M"], l["N"], l["K"], "geglu" if l["geglu"] else "ln" if l["ln"] else "res" if l["residual"] else "-",
+        key = (("linear", "conv3x3", "tconv3", "ffn_fused")[l["mode"]], l["M"], l["N"], l["K"], "geglu" if l["geglu"] else "ln" if l["ln"] else "res" if l["residual"] else "-",
                l["cfg"], l["nsplit"])
         a = agg[key]
         a[0] += 1
@@ -60,6 +64,7 @@ def main():
         a[2] += l["algorithmic_bytes"]
     tot_m = sum(a[1] for a in agg.values())
     tot_a = sum(a[2] for a in agg.values())
+    launches = [l for l, _m in join(launches, fetch, write)]
     print(f"{len(launches)} launches per step: measured {tot_m / 1e9:.1f} GB, algorithmic {tot_a / 1e9:.1f} GB, ratio {tot_m / tot_a:.2f}")
     print("excess GB | launches | measured MB | algorithmic MB | ratio | problem (mode, M, N, K, epilogue, cfg, K slices)")
     for key, a in sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:40]:
