@@ -262,12 +262,14 @@ def test_twenty_step_drift_against_fp16_torch_floor():
     assert max(d_hip) < FREE_RUNNING_BAR, f"|delta latent|max per step: {d_hip}"
 
 
-@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop"])
+@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop"])
 def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, full-width
     `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the HIP loop against those recorded by
     tests/golden/make_loop_goldens.py (oracle loop around the REFERENCE'S OWN UNet3DConditionModel, fp32 on the CPU):
-    `musev_cfg2_loop20` = the WHOLE 20-step DDIM schedule, `musev_cfg2_loop` = its first 4 steps.  Asserted: free-running
+    `musev_cfg2_loop20` = the WHOLE 20-step DDIM schedule, `musev_cfg2_loop` = its first 4 steps, `refnet_cfg3_loop` = the first 4
+    steps of BASELINE config 3 (`musev_referencenet`: ReferenceNet features + IP-Adapter image tokens as loop-constant side
+    inputs).  Asserted: free-running
     ABSOLUTE |delta latent|max < 1e-2 at EVERY step (the metric's output bar; the two-fp16 carry on the residual stream is what
     makes it reachable, profiles/r04b_loop_rounding_ensemble.json); every step started from the reference's latents < 1e-2; the
     graph replay is bit-identical."""
@@ -276,7 +278,7 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     import os
 
     import numpy as np
-    from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict
+    from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict, loop_case_unet_kwargs
     from musev_amd.models.unet_loader import load_unet_by_name
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
     case = LOOP_CASES_AT_SIZE[name]
@@ -288,6 +290,12 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     latents, cond, prompt = loop_case_inputs(case)
     gold = np.load(path)
     dev = torch.device("cuda", 0)
+
+    def to_dev(v):
+        if torch.is_tensor(v):
+            return v.to(dev)
+        return [to_dev(e) for e in v] if isinstance(v, (list, tuple)) else v
+    side = {k: to_dev(v) for k, v in loop_case_unet_kwargs(case, cfg).items()}
     unet = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16).to(dev)
     del sd
     den = ParallelDenoiser(unet, context_frames=case["context_frames"], context_overlap=case["context_overlap"])
@@ -296,7 +304,7 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     for _ in range(2):
         rec = []
         den(latents.to(dev), prompt.to(dev), num_inference_steps=case["num_inference_steps"], max_steps=case["steps"],
-            guidance_scale=case["guidance_scale"], condition_latents=cond.to(dev), motion_speed=8.0,
+            guidance_scale=case["guidance_scale"], condition_latents=cond.to(dev), motion_speed=8.0, unet_kwargs=side,
             callback=lambda i, t, lat: rec.append(lat.clone().view(shape).cpu()))
         torch.cuda.synchronize()
         runs.append(rec)
@@ -309,7 +317,7 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     prev = latents
     for i in range(case["steps"]):
         out = den(prev.to(dev), prompt.to(dev), num_inference_steps=case["num_inference_steps"], guidance_scale=case["guidance_scale"],
-                  condition_latents=cond.to(dev), motion_speed=8.0, start_step=i, max_steps=i + 1, reinsert_condition=False)
+                  condition_latents=cond.to(dev), motion_speed=8.0, start_step=i, max_steps=i + 1, reinsert_condition=False, unet_kwargs=side)
         want = torch.from_numpy(gold[f"latents_step{i + 1}"])
         forced.append((out.float().cpu() - want).abs().max().item())
         prev = want
