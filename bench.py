@@ -366,7 +366,9 @@ def main():
         evs = den.exchange_events[-args.steps:]
         ex_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1) if evs else 0.0
         props = torch.cuda.get_device_properties(dev)
-        ident = hash((os.uname().nodename, getattr(props, "pci_bus_id", local_rank), local_rank)) % (1 << 31)
+        import zlib
+        # a stable id of the DEVICE under this rank (hostname + the device's uuid, else its index): python's hash() is salted per process
+        ident = zlib.crc32(f"{os.uname().nodename}:{getattr(props, 'uuid', None) or torch.cuda.current_device()}".encode()) % (1 << 31)
         mine = torch.tensor([local_elapsed * 1e3 / args.steps, ex_ms, float(ident), float(len(shard_units(n_windows, 2, world)[rank]))], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine, group=group)
