@@ -453,8 +453,10 @@ def main():
         # The recorder keeps every operand of the recorded launches alive: a whole step of a many-window workload (config 4: 12
         # windows, config 5: 768 x 768) would pin hundreds of GB.  Every window issues the same launches, so ONE window is recorded
         # (12 frames) and the per-step figures are that window's times the step's window count (`recorded_windows` says so).
-        rec_lat = None if n_windows == 1 else make_latents(win)
-        rec_scale = 1 if n_windows == 1 else n_windows
+        # (one GPU only: in a sharded run a rank records its own few units, and a one-window step would leave most ranks without work)
+        one_window = n_windows > 1 and world == 1
+        rec_lat = make_latents(win) if one_window else None
+        rec_scale = n_windows if one_window else 1
         ops.GEMM_RECORD = []
         den.use_graphs = False
         sync_all()
@@ -564,7 +566,8 @@ def main():
                       "one HIP event pair (device time; no per-launch host gap)",
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
             "launches_per_step": fam_n * rec_scale,
-            "recorded_windows": f"1 of {n_windows} (every window issues the same launches; per-step figures = the recorded window x {n_windows})",
+            "recorded_windows": (f"1 of {n_windows} (every window issues the same launches; per-step figures = the recorded window x {n_windows})"
+                                 if one_window else f"all of this rank's units of the {n_windows}-window step"),
             "avg_launch_ms": fam_ms / max(fam_n, 1),
             "algorithmic_flops_per_launch": fam_flops / max(fam_n, 1),
             "family_ms_per_step": fam_ms * rec_scale,
