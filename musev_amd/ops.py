@@ -69,6 +69,22 @@ CARRY_MAX_C: int = int(os.environ.get("MUSEV_CARRY_MAX_C", "320"))
 CARRY_HITS: int = 0
 
 
+def _lo_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """the lo half riding on ``t`` (see CARRY), if it still describes the tensor: same geometry, and no in-place torch op on the hi
+    half since it was written (the torch version counter travels with the attribute, like the column statistics')"""
+    if t is None:
+        return None
+    lo = getattr(t, "_mv_lo", None)
+    if lo is None or lo.shape != t.shape or lo.stride() != t.stride() or getattr(t, "_mv_lo_version", None) != t._version:
+        return None
+    return lo
+
+
+def _set_lo(t: torch.Tensor, lo: torch.Tensor) -> None:
+    t._mv_lo = lo
+    t._mv_lo_version = t._version
+
+
 def _carry_setup(d: GemmDesc, o: torch.Tensor, residual: Optional[torch.Tensor], carry: bool, keep: tuple) -> tuple:
     """fills d.c_lo / d.residual_lo for a stream-producing launch; returns the tensors to keep alive"""
     if not (carry and CARRY) or o.shape[1] > CARRY_MAX_C or o.shape[1] % 8 or o.stride(0) % 8 or o.data_ptr() % 16:
@@ -79,11 +95,11 @@ def _carry_setup(d: GemmDesc, o: torch.Tensor, residual: Optional[torch.Tensor],
     CARRY_HITS += 1
     lo = torch.empty_strided(o.shape, o.stride(), dtype=torch.float16, device=o.device)
     d.c_lo = lo.data_ptr()
-    rlo = getattr(residual, "_mv_lo", None) if residual is not None else None
-    if rlo is not None and rlo.shape == residual.shape and rlo.stride() == residual.stride():
+    rlo = _lo_of(residual)
+    if rlo is not None:
         d.residual_lo = rlo.data_ptr()
         keep = keep + (rlo,)
-    o._mv_lo = lo
+    _set_lo(o, lo)
     return keep + (lo,)
 
 
@@ -446,11 +462,9 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
     o = _out(out, n_items * rows, c, x)
     x_lo = y_lo = None
     if carry and CARRY and x2 is None and c <= CARRY_MAX_C and o.stride(0) % 8 == 0:
-        x_lo = getattr(x, "_mv_lo", None)
-        if x_lo is not None and (x_lo.shape != x.shape or x_lo.stride() != x.stride()):
-            x_lo = None
+        x_lo = _lo_of(x)
         y_lo = torch.empty_strided(o.shape, o.stride(), dtype=torch.float16, device=o.device)
-        o._mv_lo = y_lo
+        _set_lo(o, y_lo)
     cs1 = getattr(x, "_mv_colstats", None) if COLSTATS else None
     cs2 = getattr(x2, "_mv_colstats", None) if (COLSTATS and x2 is not None) else None
     if cs1 is not None and len(cs1) > 2 and cs1[2] != x._version:
@@ -624,8 +638,8 @@ def conv3x3_cout_small(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, h: in
     if out_dtype not in (torch.float16, torch.float32):
         raise ValueError("conv3x3_cout_small: out_dtype must be fp16 or fp32")
     y = torch.empty((n_img * h * w_, cout), dtype=out_dtype, device=x.device)
-    x_lo = getattr(x, "_mv_lo", None) if CARRY else None   # two-fp16 input (groupnorm(carry=True)): the convolution reads hi + lo
-    if x_lo is not None and (x_lo.shape != x.shape or not x_lo.is_contiguous()):
+    x_lo = _lo_of(x) if CARRY else None   # two-fp16 input (groupnorm(carry=True)): the convolution reads hi + lo
+    if x_lo is not None and not x_lo.is_contiguous():
         x_lo = None
     check(_lib.load().mv_conv3x3_cout_small_f16(x.data_ptr(), _p(x_lo), cin, w.data_ptr(), _p(_vec(bias, "bias", cout)),
                                                 y.data_ptr(), int(out_dtype == torch.float32), cout, n_img, h, w_, _stream()),

@@ -84,6 +84,7 @@ def _carry_store(s32: torch.Tensor, out):
     """the carry epilogue: hi = fp16(s), lo = fp16(s - hi); lo rides on the hi tensor object (ops._carry_setup)"""
     hi = _store(s32, out)
     hi._mv_lo = (s32 - hi.float()).to(torch.float16)
+    hi._mv_lo_version = hi._version
     return hi
 
 
