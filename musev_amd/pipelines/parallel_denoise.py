@@ -259,7 +259,7 @@ class ParallelDenoiser:
                 wl = len(wins[wi])
                 tw = n_cond + wl
                 # (hi_lo: the fp32 latents as two fp16 halves -- conv_in sees them unrounded, ops.CARRY)
-                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs), hi_lo=ops.CARRY and controlnet is None)
+                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs), hi_lo=ops.CARRY and controlnet is None and 18 * c <= 128)
                 cn_ = None
                 if controlnet is not None and cn_on:
                     ctrl_bufs[wl].copy_(ctrl_frames[wi])
@@ -404,14 +404,19 @@ class ParallelDenoiser:
                 memo.on_split = lambda: split_ev.record(main)
                 e0 = one(inp[:rows], 1, embeds[hs[0]:hs[0] + 1], kws[0], hs[0], memo)
                 if not memo.closed:
-                    raise RuntimeError("the UNet forward never closed the shared CFG prefix")
-                side.wait_event(split_ev)
-                with torch.cuda.stream(side):
-                    for v in memo.store.values():
-                        for t_ in (v if isinstance(v, (tuple, list)) else (v,)):
-                            if torch.is_tensor(t_):
-                                t_.record_stream(side)
-                    e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1], memo.replay())
+                    # a model that ignores `prefix_memo` (any object with the forward_rows interface): nothing was shared, the
+                    # second half runs as a plain forward behind the first
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1])
+                else:
+                    side.wait_event(split_ev)
+                    with torch.cuda.stream(side):
+                        for v in memo.store.values():
+                            for t_ in (v if isinstance(v, (tuple, list)) else (v,)):
+                                if torch.is_tensor(t_):
+                                    t_.record_stream(side)
+                        e1 = one(inp[rows:], 1, embeds[hs[1]:hs[1] + 1], kws[1], hs[1], memo.replay())
             main.wait_stream(side)
             e1.record_stream(main)
             return torch.cat([e0, e1], dim=0)
