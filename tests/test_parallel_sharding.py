@@ -56,11 +56,30 @@ def _run_loop(group=None, scheduler=None, frames=20, schedule="uniform", window=
             setattr(ops, n, f)
 
 
+
+def _plain(v):
+    """tensors -> numpy before they go through a multiprocessing Manager: numpy arrays are pickled BY VALUE, torch tensors by shared-
+    memory file descriptor -- and a descriptor whose owner (the worker) has exited by the time the parent asks for it raises EOFError"""
+    if torch.is_tensor(v):
+        return ("__tensor__", v.detach().cpu().numpy())
+    if isinstance(v, (list, tuple)):
+        return type(v)(_plain(e) for e in v)
+    return v
+
+
+def _unplain(v):
+    if isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and v[0] == "__tensor__":
+        return torch.from_numpy(v[1])
+    if isinstance(v, (list, tuple)):
+        return type(v)(_unplain(e) for e in v)
+    return v
+
+
 def _worker(rank, world, port, ret, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out, _ = _run_loop(group=dist.group.WORLD, **(kw or {}))
-    ret[rank] = out.clone()
+    ret[rank] = _plain(out.clone())
     dist.destroy_process_group()
 
 
@@ -75,6 +94,7 @@ def test_multi_rank_gloo_matches_single_process_and_oracle(world):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
     for r in range(1, world):
         assert torch.equal(ret[0], ret[r]), "replicated latents diverged between ranks"
     # the 2-rank run exchanges fp16 predictions exactly like the 1-rank run consumes them -> identical results
@@ -123,6 +143,7 @@ def _spawn(world, kw):
     s.close()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret, kw), nprocs=world, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
     return ret
 
 
@@ -205,7 +226,7 @@ def _side_worker(rank, world, port, ret):
     tok = torch.zeros(2, 4, 768)
     down, mid, sa = get_referencenet_emb_sharded(fake_refnet if rank == 1 else None, lat if rank == 1 else None, 1, tok, None,
                                                  group=dist.group.WORLD, src=1, device=torch.device("cpu"))
-    ret[rank] = ([d.clone() for d in down], mid.clone(), len(calls))
+    ret[rank] = _plain(([d.clone() for d in down], mid.clone(), len(calls)))
     dist.destroy_process_group()
 
 
@@ -216,6 +237,7 @@ def test_side_model_outputs_are_computed_on_one_rank_and_broadcast():
     s.close()
     ret = mp.Manager().dict()
     mp.spawn(_side_worker, args=(3, port, ret), nprocs=3, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
     assert [ret[r][2] for r in range(3)] == [0, 1, 0], "the side model must run on the source rank only"
     for r in (0, 2):
         assert all(torch.equal(a, b) for a, b in zip(ret[r][0], ret[1][0])) and torch.equal(ret[r][1], ret[1][1])

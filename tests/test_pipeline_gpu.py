@@ -28,6 +28,26 @@ ARCH = dict(block_out_channels=(320, 640), layers_per_block=1,
             down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"), up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
 
 
+
+def _plain(v):
+    """tensors -> numpy before they go through a multiprocessing Manager: numpy arrays are pickled BY VALUE, torch tensors by shared-
+    memory file descriptor -- and a descriptor whose owner (the worker) has exited by the time the parent asks for it raises EOFError
+    (seen once on a GPU box, profiles/r04x: a race, not a numerical failure)"""
+    if torch.is_tensor(v):
+        return ("__tensor__", v.detach().cpu().numpy())
+    if isinstance(v, (list, tuple)):
+        return type(v)(_plain(e) for e in v)
+    return v
+
+
+def _unplain(v):
+    if isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and v[0] == "__tensor__":
+        return torch.from_numpy(v[1])
+    if isinstance(v, (list, tuple)):
+        return type(v)(_unplain(e) for e in v)
+    return v
+
+
 def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim"):
     from oracle import pipeline as opipe
     from oracle import unet3d
@@ -432,7 +452,7 @@ def _shared_gpu_worker(rank, world, port, ret, T, win, ov, schedule, scheduler):
         kw = dict(num_inference_steps=20, max_steps=3, guidance_scale=3.5, motion_speed=8.0, condition_latents=cond.to(dev))
         outs = [den(latents.to(dev), prompt.to(dev), group=dist.group.WORLD, **kw) for _ in range(2)]  # second call replays the graphs
         torch.cuda.synchronize()
-        ret[rank] = [o.float().cpu() for o in outs]
+        ret[rank] = _plain([o.float().cpu() for o in outs])
     finally:
         dist.destroy_process_group()
 
@@ -449,6 +469,7 @@ def test_ranks_sharing_the_gpu_match_the_single_process_loop(world, T, win, ov, 
     s.close()
     ret = mp.Manager().dict()
     mp.spawn(_shared_gpu_worker, args=(world, port, ret, T, win, ov, schedule, scheduler), nprocs=world, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
     for r in range(world):
         assert torch.equal(ret[r][0], ret[r][1]), "graph replay changed the result"
         assert torch.equal(ret[0][0], ret[r][0]), "replicated latents diverged between ranks"
@@ -507,7 +528,7 @@ def _rccl_one_rank_worker(rank, port, ret):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the calls bench.py makes around the timed region
         dist.barrier()
         torch.cuda.synchronize()
-        ret["local"], ret["ex1"], ret["ex2"] = local, ex1, ex2
+        ret["local"], ret["ex1"], ret["ex2"] = _plain(local), _plain(ex1), _plain(ex2)
     finally:
         dist.destroy_process_group()
 
@@ -525,6 +546,7 @@ def test_exchange_path_through_rccl_with_one_rank():
     s.close()
     ret = mp.Manager().dict()
     mp.spawn(_rccl_one_rank_worker, args=(port, ret), nprocs=1, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
     assert torch.equal(ret["ex1"], ret["ex2"])
     assert (ret["ex1"] - ret["local"]).abs().max().item() < 2e-5
 
@@ -555,7 +577,7 @@ def _rccl_all_gpus_worker(rank, world, port, ret):
         single = den(latents, prompt, **kw).float().cpu() if rank == 0 else None   # the same loop without a group, on rank 0's GPU
         dist.barrier()
         torch.cuda.synchronize()
-        ret[rank] = (outs, single)
+        ret[rank] = _plain((outs, single))
     finally:
         dist.destroy_process_group()
 
@@ -576,6 +598,7 @@ def test_rccl_ranks_on_all_visible_gpus_config4_schedule():
     s.close()
     ret = mp.Manager().dict()
     mp.spawn(_rccl_all_gpus_worker, args=(world, port, ret), nprocs=world, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
     for r in range(world):
         assert torch.equal(ret[r][0][0], ret[r][0][1]), "graph replay changed the result"
         assert torch.equal(ret[0][0][0], ret[r][0][0]), "replicated latents diverged between ranks"
