@@ -1086,7 +1086,24 @@ int launch_carry_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
 // per-shape choices measured on the MI355X (mode / N / K / geglu exact, nearest M within a factor of 3; anything else follows the
 // rules below)
 struct GemmTuned { int mode; long M; int N, K, geglu, ln, cfg, nsplit; };
+struct GemmKeyed { int mode, geglu, ln, kb, fb, cfg; };
 #include "gemm_tuned.h"
+
+// the key of a problem for sizes the table does not hold: K tiles of 64 in five classes (the level-0 projections | the 640-wide |
+// the 1280-wide | convolution K | long convolution K) and the fill of the CUs by the 128 x 160 grid in six (half a round | one |
+// two | four | sixteen | more).  tools/tile_choice_study.py:key_of is the same arithmetic (it generates kGemmKeyed).
+struct GemmKey {
+    int kb, fb;
+    bool operator==(const GemmKey& o) const { return kb == o.kb && fb == o.fb; }
+};
+inline GemmKey gemm_key(long M, int N, int K, int cus) {
+    const int nk = (K + 63) / 64;
+    const long grid2 = 2 * ((M + 127) / 128) * ((N + 159) / 160);
+    GemmKey k;
+    k.kb = (nk > 5) + (nk > 10) + (nk > 20) + (nk > 60);
+    k.fb = (grid2 > 1L * cus) + (grid2 > 2L * cus) + (grid2 > 4L * cus) + (grid2 > 8L * cus) + (grid2 > 32L * cus);
+    return k;
+}
 
 struct GemmChoice { int cfg, nsplit; };
 
@@ -1111,12 +1128,19 @@ inline int splitk_clamp(const GemmArgs& g, int nsplit) {
 inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int want_split) {
     GemmChoice ch{-1, 0};
     if (want_cfg >= 0 && gemm_cfg_applies(want_cfg, g)) ch.cfg = want_cfg;
+    const int cus = mv_num_cus();
+    const int nk = (g.K + 63) / 64;
     if (ch.cfg < 0 && want_cfg == -1) {
-        // measured table: the entry of this (mode, N, K, geglu) whose M is NEAREST on a log scale, within a factor of 3 -- the
-        // table is measured on the 512 x 512 benchmark (M = 26 or 13 frames x 4096 / 1024 / 256 / 64 rows), and other resolutions
-        // (768 x 768: x 2.25, 512 x 320: x 0.625) inherit the choice of the same layer at the nearest size instead of falling back
-        // to the rules.  An entry measured on the LayerNorm-folded form of the launch wins over a plain one at the same distance;
-        // the split factor is only inherited at (nearly) the measured M, elsewhere the split rule decides.
+        // measured table.  (1) The entry of this (mode, N, K, geglu) whose M is NEAREST on a log scale: within a factor of 1.26 it
+        // IS the measurement (tile and split factor; cfg -2 = the rules measured best).  (2) Further away -- the table is measured on
+        // the 512 x 512 and 768 x 768 benchmarks at 13 / 26 frames; 512 x 320, other window lengths and resolutions are not in it --
+        // the same layer's entry still lends its tile if it sits in the SAME key bucket (same K class, same fill of the CUs: a
+        // 256 x 320 tile tuned on a full grid is not handed to a grid of 104 blocks), (3) else the key's vote over every measured
+        // problem (kGemmKeyed), (4) else the nearest entry within a factor of 3 anyway, (5) else the rules.  Priced on held-out
+        // resolutions from the tuner's own measurements (tools/tile_choice_study.py, profiles/r04w_tile_choice_study.log): 2.2-3.1 %
+        // over a fresh tune at 2.25x / 0.44x the size, against 3.8-6.1 % for (4) alone and 11-18 % for the rules.  An entry measured
+        // on the LayerNorm-folded form of the launch wins over a plain one at the same distance; away from the measured M the
+        // split rule decides the split.
         int best = -1;
         double best_d = 1e30;
         const bool want_ln = g.ln_colsum != nullptr;
@@ -1133,13 +1157,29 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
                 best = i;
             }
         }
-        if (best >= 0 && kGemmTuned[best].cfg >= 0) {  // (cfg -2: the rules below measured best for this problem)
+        const GemmKey key = gemm_key(g.M, g.N, g.K, cus);
+        bool settled = false;
+        if (best >= 0 && best_d <= 1.26) {
+            settled = true;  // (cfg -2: the rules below measured best for this problem)
+            if (kGemmTuned[best].cfg >= 0) {
+                ch.cfg = kGemmTuned[best].cfg;
+                ch.nsplit = kGemmTuned[best].nsplit;
+            }
+        } else if (best >= 0 && kGemmTuned[best].cfg >= 0 && (kGemmTuned[best].ln != 0) == want_ln && gemm_key(kGemmTuned[best].M, g.N, g.K, cus) == key) {
+            settled = true;
             ch.cfg = kGemmTuned[best].cfg;
-            ch.nsplit = best_d <= 1.26 ? kGemmTuned[best].nsplit : 0;
         }
+        if (!settled) {
+            for (int i = 0; i < kNumGemmKeyed; ++i) {
+                const GemmKeyed& e = kGemmKeyed[i];
+                if (e.mode != mode || e.geglu != g.geglu || (e.ln != 0) != want_ln || e.kb != key.kb || e.fb != key.fb || !gemm_cfg_applies(e.cfg, g)) continue;
+                ch.cfg = e.cfg;
+                settled = true;
+                break;
+            }
+        }
+        if (!settled && best >= 0 && kGemmTuned[best].cfg >= 0) ch.cfg = kGemmTuned[best].cfg;
     }
-    const int cus = mv_num_cus();
-    const int nk = (g.K + 63) / 64;
     if (ch.cfg < 0) {
         // rules: BN = 160 when it divides N (all UNet widths are multiples of 320), else 128; BM = 128 unless that leaves the
         // CUs under-filled, then 64; GEGLU (even TN) on 128x128.  One-round grids of 8-wave 256x160 tiles on the counted-wait

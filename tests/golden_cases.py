@@ -201,7 +201,7 @@ LOOP_CASES_AT_SIZE = {
     "refnet_cfg3_loop": dict(flavour="musev_referencenet", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=9, latent_seed=33, cond_seed=34,
                              prompt_seed=35, side_seed=36, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
                              context_overlap=4),
-    # the whole 20-step schedule of config 3 (generated at the end of round 4 for the next round's first GPU call: not yet replayed by a test)
+    # the whole 20-step schedule of config 3 (generated at the end of round 4; replayed by test_config2_loop_at_size_matches_reference_unet_loop_golden)
     "refnet_cfg3_loop20": dict(flavour="musev_referencenet", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=9, latent_seed=33, cond_seed=34,
                                prompt_seed=35, side_seed=36, guidance_scale=3.5, num_inference_steps=20, steps=20, context_frames=12,
                                context_overlap=4),

@@ -282,14 +282,14 @@ def test_twenty_step_drift_against_fp16_torch_floor():
     assert max(d_hip) < FREE_RUNNING_BAR, f"|delta latent|max per step: {d_hip}"
 
 
-@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop"])
+@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop", "refnet_cfg3_loop20"])
 def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, full-width
     `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the HIP loop against those recorded by
     tests/golden/make_loop_goldens.py (oracle loop around the REFERENCE'S OWN UNet3DConditionModel, fp32 on the CPU):
     `musev_cfg2_loop20` = the WHOLE 20-step DDIM schedule, `musev_cfg2_loop` = its first 4 steps, `refnet_cfg3_loop` = the first 4
     steps of BASELINE config 3 (`musev_referencenet`: ReferenceNet features + IP-Adapter image tokens as loop-constant side
-    inputs).  Asserted: free-running
+    inputs), `refnet_cfg3_loop20` = config 3's whole 20-step schedule.  Asserted: free-running
     ABSOLUTE |delta latent|max < 1e-2 at EVERY step (the metric's output bar; the two-fp16 carry on the residual stream is what
     makes it reachable, profiles/r04b_loop_rounding_ensemble.json); every step started from the reference's latents < 1e-2; the
     graph replay is bit-identical."""
@@ -346,7 +346,8 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     os.makedirs(out_dir, exist_ok=True)
     from musev_amd import ops
     with open(os.path.join(out_dir, f"loop_at_size_{name}.json"), "w") as f:
-        json.dump({"case": name, "config": "BASELINE config 2: musev, 512x512, 12 + 1 frames, guidance 3.5, 20-step DDIM schedule",
+        json.dump({"case": name, "config": ("BASELINE config 3: musev_referencenet + IP-Adapter tokens + ReferenceNet features" if case["flavour"] != "musev"
+                                            else "BASELINE config 2: musev") + ", 512x512, 12 + 1 frames, guidance 3.5, 20-step DDIM schedule",
                    "golden": "oracle loop around the reference's own UNet3DConditionModel, fp32 CPU (tests/golden/make_loop_goldens.py)",
                    "carry": bool(ops.CARRY), "colstats": bool(ops.COLSTATS), "ln_fold": bool(ops.LN_FOLD),
                    "free_running_abs_max": errs, "per_step_from_reference_latents": forced,

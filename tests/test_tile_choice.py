@@ -1,0 +1,156 @@
+"""The tile choice for sizes that are NOT in the measured table (csrc/gemm.hip:choose_config): the library's answer through the C ABI
+(mv_gemm_choice: host-side, launches nothing) against a Python mirror of the lookup order -- the SAME code that
+tools/tile_choice_study.py prices on held-out resolutions, so the study describes what the product does.  CPU only."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import tile_choice_study as study  # noqa: E402
+
+LN_CFG = {6: 7, 4: 9, 8: 9, 5: 9}   # csrc/gemm.hip:gemm_ln_cfg
+
+
+def _tables():
+    hdr = open(os.path.join(ROOT, "musev_amd", "csrc", "gemm_tuned.h")).read()
+    rows = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"^    \{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (-?\d+), (\d+)\},", hdr, re.M)]
+    keyed = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"^    \{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", hdr, re.M)]
+    assert len(rows) == int(re.search(r"kNumGemmTuned = (\d+);", hdr).group(1)) > 100
+    assert len(keyed) == int(re.search(r"kNumGemmKeyed = (\d+);", hdr).group(1)) > 30
+    return rows, {k[:5]: k[5] for k in keyed}
+
+
+def _lib_choice(lib, GemmDesc, mode, M, N, K, geglu, ln, geom):
+    d = GemmDesc()
+    d.a, d.w, d.c = 0x10000, 0x20000, 0x30000
+    d.M, d.N, d.K, d.mode, d.geglu, d.cfg, d.splitk = M, N, K, mode, geglu, -1, 0
+    if mode == 0:
+        d.lda, d.ldc, d.c1 = K, (N // 2 if geglu else N), K
+    elif mode == 1:
+        d.lda, d.ldc, d.c1 = K // 9, N, K // 9
+        d.hin = d.win = d.hout = d.wout = geom
+        d.stride, d.upsample = 1, 0
+    else:
+        d.lda, d.ldc, d.c1 = K // 3, N, K // 3
+        d.t, d.hw = geom
+    if ln:
+        d.ln_colsum, d.ln_colbias, d.ln_eps = 0x50000, 0x60000, 1e-5
+    cfg, ns = C.c_int32(), C.c_int32()
+    rc = lib.mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns))
+    assert rc == 0, lib.mv_last_error().decode()
+    return cfg.value, ns.value
+
+
+def _mirror(rows, keyed, configs, mode, M, N, K, geglu, ln):
+    """steps (1)-(4) of choose_config; None where only the rules are left"""
+    p = dict(mode=study_mode(mode), M=M, N=N, K=K, geglu=geglu, ln=ln)
+    best, best_d = None, 1e30
+    for (m, eM, eN, eK, eg, eln, cfg, ns) in rows:
+        e = dict(mode=study_mode(m), M=eM, N=eN, K=eK, geglu=eg, ln=eln)
+        if m != mode or eN != N or eK != K or eg != geglu or not (cfg == -2 or study.applies(p, cfg, configs)) or (eln and not ln):
+            continue
+        r = M / eM
+        d = r if r > 1 else 1 / r
+        if d > 3.0:
+            continue
+        if bool(eln) != bool(ln):
+            d *= 1.0001
+        if d < best_d:
+            best, best_d = (e, cfg, ns), d
+    key = study.key_of(p)
+    pick = None
+    if best is not None and best_d <= 1.26:
+        if best[1] < 0:
+            return None
+        pick = (best[1], best[2])
+    elif best is not None and best[1] >= 0 and study.key_of(best[0]) == key:
+        pick = (best[1], 0)
+    if pick is None:
+        kk = (mode, geglu, ln) + key[3:]
+        if kk in keyed and study.applies(p, keyed[kk], configs):
+            pick = (keyed[kk], 0)
+    if pick is None and best is not None and best[1] >= 0:
+        pick = (best[1], 0)
+    if pick is None:
+        return None
+    cfg = pick[0]
+    ns = study.effective_split(p, cfg, configs, pick[1])
+    if ln:
+        cfg, ns = LN_CFG.get(cfg, cfg), 1
+    return cfg, ns
+
+
+def study_mode(m):
+    return {0: "linear", 1: "conv3x3", 2: "tconv3"}[m]
+
+
+def test_unseen_sizes_follow_the_studied_lookup_order():
+    from musev_amd import _lib
+    lib = _lib.load()
+    rows, keyed = _tables()
+    configs = json.load(open(os.path.join(ROOT, "profiles", "r04t_musev512_gemm_tune.json")))["configs"]
+    n_cfg = lib.mv_gemm_num_configs()
+    assert n_cfg == len(configs)
+    for c in range(n_cfg):   # the study's catalogue (block rows, block columns) is the library's
+        desc = (C.c_int32 * 5)()
+        assert lib.mv_gemm_config_desc(c, desc) == 0 and (desc[0], desc[1]) == (configs[c][0], configs[c][1])
+    checked = steps = 0
+    seen = {"table": 0, "bucket": 0, "keyed": 0}
+    for (mode, M, N, K, geglu, ln, cfg, ns) in rows:
+        for hw_scale, frames in ((1.0, 13), (0.625, 13), (1.0, 9), (2.25, 13), (0.25, 13), (1.0, 26)):
+            # the layer at another resolution (512 x 320: x 0.625 pixels; 768^2 from 512^2: x 2.25) or window length (8 + 1 frames)
+            base_frames = 26 if M % 26 == 0 and (M // 26) >= 25 and mode != 2 else 13
+            if M % base_frames:
+                continue
+            px = int(round(M // base_frames * hw_scale))
+            side = int(round(px ** 0.5))
+            if mode == 1:
+                if side * side != px:
+                    continue
+                geom = side
+            else:
+                geom = (frames, px)
+            M2 = px * frames
+            if M2 < 16 or (mode == 0 and ln and K % 64):
+                continue
+            want = _mirror(rows, keyed, configs, mode, M2, N, K, geglu, ln)
+            if want is None:
+                continue
+            got = _lib_choice(lib, _lib.GemmDesc, mode, M2, N, K, geglu, ln, geom)
+            assert got == want, f"mode {mode} M {M2} N {N} K {K} geglu {geglu} ln {ln}: library {got}, mirror {want}"
+            checked += 1
+            steps += got != (cfg, ns)
+    assert checked > 400 and steps > 50, (checked, steps)
+
+
+def test_keyed_table_is_what_the_committed_measurements_vote():
+    """gemm_tuned.h is regenerated bit for bit from the tuner files under profiles/ (rows AND keyed table): no hand edits"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_gemm_tune", os.path.join(ROOT, "tools", "gpu_gemm_tune.py"))
+    tune = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tune)
+    import tempfile
+    tune.PREFER_TWO_BLOCK = True
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "t.h")
+        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r04t_musev512_gemm_tune.json", "r03g_refnet512_gemm_tune.json", "r03g_refnet768_gemm_tune.json")], out)
+        assert open(out).read() == open(os.path.join(ROOT, "musev_amd", "csrc", "gemm_tuned.h")).read()
+
+
+def test_study_legs_stay_within_three_percent_of_a_fresh_tune():
+    """VERDICT r3 item 9's bar, priced from measurements: the product's lookup order on resolutions it was not trained on"""
+    files = {t: study.load(t) for t in ("r03g_musev512", "r03g_refnet512", "r03g_refnet768")}
+    configs = files["r03g_musev512"]["configs"]
+    for test_tag, train_tags in (("r03g_refnet768", ["r03g_musev512", "r03g_refnet512"]), ("r03g_refnet512", ["r03g_refnet768"]),
+                                 ("r03g_musev512", ["r03g_refnet768"])):
+        tot, miss, _ = study.evaluate(files[test_tag], [p for t in train_tags for p in files[t]["problems"]], configs)
+        assert tot["hybrid"] <= 1.03 * tot["best"], (test_tag, tot)
+        assert tot["hybrid"] < tot["inherit"] < tot["rules"], (test_tag, tot)
