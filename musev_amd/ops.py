@@ -53,6 +53,10 @@ GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
 # some other way simply has none and `groupnorm` takes its own statistics pass.
 COLSTATS: bool = os.environ.get("MUSEV_COLSTATS", "1") == "1"
 COLSTATS_HITS: int = 0   # GroupNorm calls served from producer statistics (tests / reports)
+# MUSEV_GN_FOLD_IN_APPLY=1: the fold of the column statistics runs inside the apply pass (one launch per GroupNorm instead of two
+# wherever a group has <= 2048 (row tile, channel) pairs: mv_groupnorm_cs_f16_var; bit-identical to the fold launch).  Built at the
+# end of round 4 WITHOUT a GPU left to time it: off until a same-box A/B says otherwise (tools/gpu_next_round_first.sh).
+GN_FOLD_IN_APPLY: bool = os.environ.get("MUSEV_GN_FOLD_IN_APPLY", "0") == "1"
 
 
 # Two-fp16 carry on the identity path of the residual stream (env knob for A/B runs: MUSEV_CARRY=0 switches it off).  The fp16
@@ -476,11 +480,11 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
         global COLSTATS_HITS
         COLSTATS_HITS += 1
         stat = torch.empty(n_items * 2 * groups, dtype=torch.float32, device=x.device)
-        check(lib.mv_groupnorm_cs_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
-                                      n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
-                                      o.data_ptr(), o.stride(0), cs1[0].data_ptr(), cs1[1],
-                                      cs2[0].data_ptr() if cs2 is not None else None, cs2[1] if cs2 is not None else 0,
-                                      nsplit, stat.data_ptr(), _p(x_lo), _p(y_lo), _stream()), "mv_groupnorm_cs_f16")
+        check(lib.mv_groupnorm_cs_f16_var(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
+                                          n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
+                                          o.data_ptr(), o.stride(0), cs1[0].data_ptr(), cs1[1],
+                                          cs2[0].data_ptr() if cs2 is not None else None, cs2[1] if cs2 is not None else 0,
+                                          nsplit, stat.data_ptr(), _p(x_lo), _p(y_lo), int(GN_FOLD_IN_APPLY), _stream()), "mv_groupnorm_cs_f16")
         return o
     scratch = torch.empty(n_items * nsplit * 2 * groups + n_items * 2 * groups, dtype=torch.float32, device=x.device)
     partial_ptr = scratch.data_ptr()

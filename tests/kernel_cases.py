@@ -21,6 +21,14 @@ def _rand(shape, seed, scale=1.0, dtype=torch.float16):
     return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(dtype).to(DEV)
 
 
+def unproven_on_hardware() -> bool:
+    """Kernel forms written at the end of round 4 with no GPU minutes left (default OFF in the product: MUSEV_GN_FOLD_IN_APPLY,
+    MUSEV_XATTN_RESIDENT) are exercised on the host simulator always, on the GPU only with MUSEV_TEST_UNPROVEN=1 -- which
+    tools/gpu_next_round_first.sh sets -- so that a form that never ran on hardware cannot take the round-end GPU suite down."""
+    import os
+    return DEV == "cpu" or os.environ.get("MUSEV_TEST_UNPROVEN") == "1"
+
+
 def _cmp(name, got, ref, atol, rtol=2e-3):
     got = got.float()
     ref = ref.float()
@@ -393,6 +401,16 @@ def case_colstats_groupnorm(kind="conv", n=3, h=16, w=16, cin=64, c=320, c2=0, c
     results.append(_cmp(f"groupnorm from colstats {kind} cfg{cfg} c{c}+{c2}", got, ref, atol=4e-3))
     if ops.COLSTATS_HITS != hits + 1:
         return {"name": f"colstats {kind} cfg{cfg}", "ok": False, "max_abs_err": float("nan"), "detail": "groupnorm did not take the column-statistics path"}
+    # the fold inside the apply pass (mv_groupnorm_cs_f16_var, variant 1) is the same arithmetic in the same order: bit-identical
+    if unproven_on_hardware():
+        flag = ops.GN_FOLD_IN_APPLY
+        ops.GN_FOLD_IN_APPLY = not flag
+        try:
+            other = ops.groupnorm(a, gamma, beta, n_items, rows, eps=1e-5, silu=True, x2=b)
+        finally:
+            ops.GN_FOLD_IN_APPLY = flag
+        results.append({"name": f"groupnorm fold-in-apply == fold launch {kind} cfg{cfg}", "ok": bool(torch.equal(other, got)),
+                        "max_abs_err": (other.float() - got.float()).abs().max().item()})
     # and the same through the statistics pass (a tensor object without the attribute): the two must agree closely
     plain = ops.groupnorm(a.clone(), gamma, beta, n_items, rows, eps=1e-5, silu=True, x2=None if b is None else b.clone())
     results.append(_cmp(f"groupnorm colstats vs statistics pass {kind} cfg{cfg}", got, plain.float(), atol=2e-3))

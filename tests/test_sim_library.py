@@ -29,6 +29,7 @@ CASES = {
     "colstats_conv_two_src_seam": "kc.case_colstats_groupnorm(n=2, h=8, w=16, cin=64, c=64, c2=32)",
     "colstats_tconv": "kc.case_colstats_groupnorm(kind='tconv', n=3, h=8, w=16, c=64)",
     "colstats_linear_ragged": "kc.case_colstats_groupnorm(kind='linear', n=3, h=8, w=8, cin=64, c=96, rows_mul=1)",
+    "colstats_linear_fold_of_256": "kc.case_colstats_groupnorm(kind='linear', n=1, h=96, w=96, cin=64, c=64, cfg=1)",  # 576 pairs per group: the 256-thread fold played by one wave
     "colstats_every_tile": "kc._all_ok([kc.case_colstats_groupnorm(n=2, h=8, w=16, cin=64, c=64, seed=340 + c, cfg=c) for c in range(19)])",
     "carry_linear": "kc.case_carry(kind='linear', n=2, h=8, w=12, cin=64, c=160)",
     "carry_conv": "kc.case_carry(kind='conv', n=2, h=8, w=12, cin=64, c=64)",
