@@ -225,9 +225,17 @@ typedef struct mv_attn_desc {
     mv_attn_seg seg[MV_ATTN_MAX_SEG];
     int32_t accumulate; /* 0: out = attn ; 1: out += out_scale * attn                                   */
     float out_scale;
+    /* 1: the resident-K/V kernel (ABI 8) -- a block owns whole query rows (wave = head), every head's keys / values stay in     */
+    /*   registers for the block's lifetime: the text cross-attention (77 keys + image-prompt tokens as further softmax groups),  */
+    /*   attention_processor.py:258-300.  Needs mv_attention_resident_ok(d) == 1: d in {40, 80}, heads <= 8, at most 8 key      */
+    /*   tiles of 16 over all segments, <= 4 groups, accumulate == 0, heads*d-wide LDS image of V under 160 KB.  0: the tiled    */
+    /*   kernels (any key count).                                                                                               */
+    int32_t resident_kv;
 } mv_attn_desc;
 
 int mv_attention_f16(const mv_attn_desc* d, void* stream);
+/* 1 if the problem fits the resident-K/V kernel (host-side check, launches nothing) */
+int mv_attention_resident_ok(const mv_attn_desc* d);
 
 /* ---- temporal self-attention over T <= 32 frames per pixel (K6c) -------------------------------------
  * rows are ordered (b, t, p): sequence of pixel (b, p) = rows (b*T + t)*HW + p, t = 0..T-1.

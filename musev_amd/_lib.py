@@ -65,7 +65,7 @@ class AttnDesc(C.Structure):
         ("nb", C.c_int32), ("lq", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32),
         ("scale", C.c_float), ("nseg", C.c_int32),
         ("seg", AttnSeg * MV_ATTN_MAX_SEG),
-        ("accumulate", C.c_int32), ("out_scale", C.c_float),
+        ("accumulate", C.c_int32), ("out_scale", C.c_float), ("resident_kv", C.c_int32),
     ]
 
 
@@ -92,6 +92,7 @@ SIGNATURES = {
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),
     "mv_attention_f16": (_i32, [C.POINTER(AttnDesc), _vp]),
+    "mv_attention_resident_ok": (_i32, [C.POINTER(AttnDesc)]),
     "mv_temporal_attention_f16": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _f32, _vp]),
     "mv_geglu_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),

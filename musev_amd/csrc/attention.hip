@@ -796,6 +796,231 @@ void attn3_kernel(const AttnArgs p) {
     }
 }
 
+// ---- cross-attention with RESIDENT keys / values (d = 40 / 80, at most 128 keys over all segments) -------------------------------
+// The text cross-attention (77 keys, + 4 IP-Adapter tokens, + FaceID tokens as further softmax groups) under attn3_kernel is a
+// (q block, head, frame) grid: every block fetches an 80-byte slice of each query row and writes an 80-byte slice of each output
+// row, a key tile ring is set up for two tiles, and the launch sits at ~1.5 TB/s (41-45 us at level 0 whatever the variant,
+// profiles/r03g_attn_variants.log).  Here a block owns WHOLE rows: wave h = head h, the block walks 16-row tiles of one query
+// batch; every wave holds its head's K fragments (A operand of S^T = K Q^T, loaded once from global: row-contiguous 16-byte
+// pieces) and V^T fragments (A operand of O^T = V^T P^T, once through an LDS image of V and ds_read_b64_tr_b16) in registers for
+// the block's lifetime.  Per tile a wave loads its 2 D bytes of each query row (the eight waves together: the whole row), forms
+// all scores at once (no online rescale: every key is resident), normalises per softmax group BEFORE rounding to fp16
+// (P~ = gscale_g * exp2(s - m_g) / l_g in fp32 -- the groups' weighted sum then is ONE P.V product), and stores its slice.
+// No barrier after the prologue.  HBM traffic: q read once, out written once (68 MB at level 0 = 17 us at 4 TB/s).
+struct XAttnArgs {
+    const half_t* q;
+    half_t* out;
+    int ldq, ldo, nb, lq, heads;
+    float scale_log2e;
+    int rows_per_block;   // multiple of 16
+    int ngroups;
+    float gscale[4];
+    // per key tile of 16 (tiles never straddle a segment)
+    const half_t* tk[8];
+    const half_t* tv[8];
+    int tldk[8], tldv[8], tlen[8], tdiv[8], tmul[8], tadd[8], tk0[8], tgrp[8];
+};
+
+template <int D, int KT>
+__global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
+    constexpr int NC32 = D / 32;            // whole 32-deep contraction chunks
+    constexpr bool TAIL = (D % 32) != 0;    // + one 16-deep step (d = 40: columns 32..39 | zeros; d = 80: columns 64..79)
+    constexpr int NDT = (D + 15) / 16;      // O^T d-tiles
+    constexpr int NCC = (KT + 1) / 2;       // 32-key chunks of the P.V contraction
+    static_assert(D % 8 == 0 && (D % 32 == 0 || D % 32 <= 16) && KT >= 1 && KT <= 8, "head dim / key tiles");
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];   // V image: [16 KT keys][heads * D + 8]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = head
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bpb = (p.lq + p.rows_per_block - 1) / p.rows_per_block;
+    const int n = blockIdx.x / bpb;
+    const int r_begin = (blockIdx.x - n * bpb) * p.rows_per_block;
+    const int r_end = r_begin + p.rows_per_block < p.lq ? r_begin + p.rows_per_block : p.lq;
+    const int C = p.heads * D;
+    const int vrs = C + 8;                  // LDS row stride (halfs): 16-byte rows + one pad slot
+
+    // ---- prologue 1: the V rows of every key tile -> LDS (16-byte pieces, rows past a segment's end and the pad slot zero) ----
+    {
+        const int cpr = vrs / 8;            // 16-byte slots per LDS row (the last one is the pad)
+        const int total = KT * 16 * cpr;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int row = i / cpr, slot = i - row * cpr;
+            const int t = row >> 4, r = row & 15;
+            uint4 v = uint4{0, 0, 0, 0};
+#pragma unroll
+            for (int tt = 0; tt < KT; ++tt) {
+                if (tt == t) {
+                    const int key = p.tk0[tt] + r;
+                    if (key < p.tlen[tt] && slot * 8 < C) {
+                        const long kvb = (long)(n / p.tdiv[tt]) * p.tmul[tt] + p.tadd[tt];
+                        v = *reinterpret_cast<const uint4*>(p.tv[tt] + (kvb * p.tlen[tt] + key) * p.tldv[tt] + slot * 8);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(lds + (long)row * vrs + slot * 8) = v;
+        }
+    }
+    // ---- prologue 2: this head's K fragments, straight from global ----
+    half8v kf[KT][NC32 > 0 ? NC32 : 1];
+    half4v kt16[KT];
+    int nvalid[KT];   // valid keys of the tile (16 except a segment's last tile)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int key = p.tk0[t] + l15;
+        const bool ok = key < p.tlen[t];
+        nvalid[t] = p.tlen[t] - p.tk0[t];
+        const long kvb = (long)(n / p.tdiv[t]) * p.tmul[t] + p.tadd[t];
+        const half_t* krow = p.tk[t] + (kvb * p.tlen[t] + (ok ? key : 0)) * p.tldk[t] + h * D;
+#pragma unroll
+        for (int c = 0; c < NC32; ++c) {
+            kf[t][c] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) kf[t][c] = *reinterpret_cast<const half8v*>(krow + 32 * c + 8 * g);
+        }
+        kt16[t] = half4v{0, 0, 0, 0};
+        if constexpr (TAIL) {
+            const int dcol = 32 * NC32 + 4 * g;
+            if (ok && dcol < D) kt16[t] = *reinterpret_cast<const half4v*>(krow + dcol);
+        }
+    }
+    __syncthreads();
+    // ---- prologue 3: this head's V^T fragments out of the LDS image (hardware transpose read, k-slot 8 g' + e of chunk cc =
+    // key 32 cc + 16 (e / 4) + 4 g' + e % 4: the order the score accumulators already have) ----
+    half8v vf[NDT][NCC];
+    {
+        typedef __attribute__((address_space(3))) half_t lds_half_t;
+        const lds_half_t* lds3 = (const lds_half_t*)lds;
+        const int v_lane_off = (4 * g + (l15 >> 2)) * vrs + (l15 & 3) * 4 + h * D;
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const lds_half_t* b0 = lds3 + (v_lane_off + 32 * cc * vrs + 16 * dt);
+                short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0));
+                short4v t1 = short4v{0, 0, 0, 0};
+                if (2 * cc + 1 < KT) t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(b0 + 16 * vrs));
+                typedef short short8v __attribute__((ext_vector_type(8)));
+                short8v tv = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                vf[dt][cc] = __builtin_bit_cast(half8v, tv);
+            }
+        }
+    }
+
+    // ---- the block's rows, 16 at a time; the next tile's query slice is in flight while this one is worked on ----
+    half8v qraw[NC32 > 0 ? NC32 : 1];
+    half4v qtraw = half4v{0, 0, 0, 0};
+    auto fetch_q = [&](int r0) __attribute__((always_inline)) {
+        const int qr = r0 + l15;
+        const half_t* qrow = p.q + ((long)n * p.lq + (qr < r_end ? qr : r_begin)) * p.ldq + h * D;
+#pragma unroll
+        for (int c = 0; c < NC32; ++c) qraw[c] = *reinterpret_cast<const half8v*>(qrow + 32 * c + 8 * g);
+        if constexpr (TAIL) {
+            const int dcol = 32 * NC32 + 4 * g;
+            qtraw = half4v{0, 0, 0, 0};
+            if (dcol < D) qtraw = *reinterpret_cast<const half4v*>(qrow + dcol);
+        }
+    };
+    fetch_q(r_begin);
+#pragma unroll 1
+    for (int r0 = r_begin; r0 < r_end; r0 += 16) {
+        // B operand of S^T = K Q^T, pre-multiplied by scale * log2(e)
+        half8v qf[NC32 > 0 ? NC32 : 1];
+        half4v qt16;
+#pragma unroll
+        for (int c = 0; c < NC32; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[c][e] = (half_t)((float)qraw[c][e] * p.scale_log2e);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qt16[e] = (half_t)((float)qtraw[e] * p.scale_log2e);
+        if (r0 + 16 < r_end) fetch_q(r0 + 16);
+
+        // acc[t][r] = S[q = l15][key 16 t + 4 g + r]  (log2 domain)
+        float4v acc[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC32; ++c) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][c], qf[c], acc[t], 0, 0, 0);
+            if constexpr (TAIL) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(kt16[t], qt16, acc[t], 0, 0, 0);
+            if (nvalid[t] < 16) {  // wave-uniform: a segment's last tile masks its missing keys
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r >= nvalid[t]) acc[t][r] = -INFINITY;
+            }
+        }
+        // per softmax group: maximum, exponentials, row sum; the probabilities leave normalised and weighted
+        float mg[4] = {0.f, 0.f, 0.f, 0.f}, lg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            if (gi >= p.ngroups) continue;  // wave-uniform
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+                if (p.tgrp[t] == gi) m = fmaxf(m, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            mg[gi] = m;
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int gi = p.tgrp[t];
+            const float m = gi == 0 ? mg[0] : gi == 1 ? mg[1] : gi == 2 ? mg[2] : mg[3];
+            float s4 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r] - m);
+                s4 += acc[t][r];
+            }
+            if (gi == 0) lg[0] += s4;
+            else if (gi == 1) lg[1] += s4;
+            else if (gi == 2) lg[2] += s4;
+            else lg[3] += s4;
+        }
+        float wg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            if (gi >= p.ngroups) continue;
+            float l = lg[gi];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            wg[gi] = p.gscale[gi] / l;   // every group holds at least one real key: l >= 1
+        }
+        // O^T[d][q] = sum over the key chunks of V^T P~^T
+        float4v acc_o[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) acc_o[dt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            half8v pf = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 2 * cc + half;
+                if (t < KT) {
+                    const int gi = p.tgrp[t];
+                    const float w = gi == 0 ? wg[0] : gi == 1 ? wg[1] : gi == 2 ? wg[2] : wg[3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pf[4 * half + r] = (half_t)(acc[t][r] * w);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt][cc], pf, acc_o[dt], 0, 0, 0);
+        }
+        // acc_o[dt][r] = O[q = l15][d = 16 dt + 4 g + r]
+        const int qr = r0 + l15;
+        if (qr < r_end) {
+            half_t* orow = p.out + ((long)n * p.lq + qr) * p.ldo + h * D;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int dcol = 16 * dt + 4 * g;
+                if (dcol < D) {
+                    const float4v o = acc_o[dt];
+                    *reinterpret_cast<half4v*>(orow + dcol) = half4v{(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 struct TAttnArgs {
     const half_t* q;
@@ -1044,8 +1269,104 @@ int launch_attn3(const AttnArgs& a, dim3 grid1, hipStream_t s) {
     return MV_OK;
 }
 
+
+int attn_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+// resident-K/V cross-attention (mv_attn_desc.resident_kv): eligibility is the caller's to check (mv_attention_resident_ok)
+template <int D, int KT>
+int launch_xattn(const XAttnArgs& a, unsigned grid, int smem, hipStream_t s) {
+    static int attr_smem = 0;  // idempotent one-time attribute of this instantiation (the LDS image of V: up to 160 KB)
+    if (smem > attr_smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<D, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL((xattn_kernel<D, KT>), dim3(grid), dim3(64 * a.heads), smem, s, a);
+    return MV_OK;
+}
+
+// key tiles of 16 over all segments (a tile never straddles a segment); -1 if the problem does not fit the resident kernel
+int xattn_key_tiles(const mv_attn_desc* d) {
+    if (!(d->d == 40 || d->d == 80) || d->heads < 1 || d->heads > 8 || d->accumulate || d->nseg < 1 || d->nseg > MV_ATTN_MAX_SEG) return -1;
+    if (d->ldq % 8 || d->ldo % 4) return -1;
+    int kt = 0, groups = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        if (d->seg[s].len <= 0 || d->seg[s].ldk % 8 || d->seg[s].ldv % 8) return -1;
+        kt += (d->seg[s].len + 15) / 16;
+        groups += (s == 0 || d->seg[s].new_group) ? 1 : 0;
+    }
+    if (kt > 8 || groups > 4) return -1;
+    const long smem = (long)kt * 16 * (d->heads * d->d + 8) * 2;
+    return smem <= 160 * 1024 ? kt : -1;
+}
+
+int xattn_launch(const mv_attn_desc* d, void* stream) {
+    const int kt = xattn_key_tiles(d);
+    MV_REQUIRE(kt > 0, "mv_attention_f16: resident_kv needs d in {40, 80}, heads <= 8, <= 128 keys in tiles of 16 per segment, <= 4 groups, no accumulate, "
+                       "and an LDS image of V under 160 KB (ask mv_attention_resident_ok)");
+    XAttnArgs a;
+    a.q = (const half_t*)d->q; a.out = (half_t*)d->out; a.ldq = d->ldq; a.ldo = d->ldo;
+    a.nb = d->nb; a.lq = d->lq; a.heads = d->heads;
+    a.scale_log2e = d->scale * 1.4426950408889634f;
+    int t = 0, grp = -1;
+    for (int i = 0; i < 4; ++i) a.gscale[i] = 1.0f;
+    for (int s = 0; s < d->nseg; ++s) {
+        const mv_attn_seg& g = d->seg[s];
+        MV_REQUIRE(g.k && g.v && g.div > 0, "mv_attention_f16: bad segment %d", s);
+        if (s == 0 || g.new_group) {
+            ++grp;
+            a.gscale[grp] = g.new_group ? g.group_scale : 1.0f;
+        }
+        for (int k0 = 0; k0 < g.len; k0 += 16, ++t) {
+            a.tk[t] = (const half_t*)g.k; a.tv[t] = (const half_t*)g.v;
+            a.tldk[t] = g.ldk; a.tldv[t] = g.ldv; a.tlen[t] = g.len; a.tdiv[t] = g.div; a.tmul[t] = g.mul; a.tadd[t] = g.add;
+            a.tk0[t] = k0; a.tgrp[t] = grp;
+        }
+    }
+    a.ngroups = grp + 1;
+    for (int i = t; i < 8; ++i) {
+        a.tk[i] = a.tk[0]; a.tv[i] = a.tv[0];
+        a.tldk[i] = a.tldv[i] = 0; a.tlen[i] = 0; a.tdiv[i] = 1; a.tmul[i] = a.tadd[i] = a.tk0[i] = 0; a.tgrp[i] = 0;
+    }
+    // rows per block: whole rounds of the CUs with as little idle tail as possible; the prologue (K / V fragments) costs about as
+    // much as six row tiles, so few, long blocks win over many short ones
+    const int cus = attn_num_cus();
+    int best_rt = 1;
+    long best_cost = -1;
+    for (int rt = 1; rt <= 64; ++rt) {
+        const long blocks = (long)d->nb * ((d->lq + 16 * rt - 1) / (16 * rt));
+        const long rounds = (blocks + cus - 1) / cus;
+        const long cost = rounds * (rt + 6);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rt = rt; }
+    }
+    a.rows_per_block = 16 * best_rt;
+    const long blocks = (long)d->nb * ((d->lq + a.rows_per_block - 1) / a.rows_per_block);
+    MV_REQUIRE(blocks <= 0x7fffffffL, "mv_attention_f16: grid too large");
+    const int smem = kt * 16 * (d->heads * d->d + 8) * 2;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MV_ERR_INVALID;
+    switch (kt * 100 + d->d) {
+#define MV_XA(KT_, D_) case KT_ * 100 + D_: rc = launch_xattn<D_, KT_>(a, (unsigned)blocks, smem, s); break;
+        MV_XA(1, 40) MV_XA(2, 40) MV_XA(3, 40) MV_XA(4, 40) MV_XA(5, 40) MV_XA(6, 40) MV_XA(7, 40) MV_XA(8, 40)
+        MV_XA(1, 80) MV_XA(2, 80) MV_XA(3, 80) MV_XA(4, 80) MV_XA(5, 80) MV_XA(6, 80) MV_XA(7, 80) MV_XA(8, 80)
+#undef MV_XA
+    }
+    if (rc != MV_OK) return rc;
+    MV_CHECK_LAUNCH("mv_attention_f16(resident)");
+    return MV_OK;
+}
+
 int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) {
     MV_REQUIRE(d && d->q && d->out, "mv_attention_f16: null pointer");
+    if (d->resident_kv) return xattn_launch(d, stream);
     MV_REQUIRE(d->nseg >= 1 && d->nseg <= MV_ATTN_MAX_SEG, "mv_attention_f16: nseg=%d out of range", d->nseg);
     MV_REQUIRE(d->d == 40 || d->d == 80 || d->d == 160, "mv_attention_f16: head dim %d not in {40,80,160}", d->d);
     MV_REQUIRE(d->nb > 0 && d->lq > 0 && d->heads > 0, "mv_attention_f16: empty problem");
@@ -1119,6 +1440,8 @@ int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) 
 }  // namespace
 
 extern "C" int mv_attention_f16(const mv_attn_desc* d, void* stream) { return attention_launch(d, kAttnVar40, kAttnVar80, stream); }
+
+extern "C" int mv_attention_resident_ok(const mv_attn_desc* d) { return d && d->q && d->out && d->nb > 0 && d->lq > 0 && xattn_key_tiles(d) > 0 ? 1 : 0; }
 
 #ifdef MV_EXPERIMENT
 // experiment builds only (tools/gpu_attn_bench.py): the same entry with the kernel variant chosen per call

@@ -510,6 +510,11 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 Seg = Tuple[torch.Tensor, torch.Tensor, int, int, int, int]  # (k, v, len, div, mul, add)
 # MUSEV_ATTN_GROUPS=0 (A/B runs): the image-prompt terms of the cross-attention as separate accumulate launches, as in round 2
 ATTN_GROUPS: bool = os.environ.get("MUSEV_ATTN_GROUPS", "1") == "1"
+# MUSEV_XATTN_RESIDENT=1: attentions over at most 128 keys (the text / image-prompt cross-attention at head dims 40 / 80) run on the
+# resident-K/V kernel (mv_attn_desc.resident_kv: whole query rows per block, q read once, out written once).  Built at the end of
+# round 4 WITHOUT a GPU left to time it: off until a same-box A/B says otherwise (tools/gpu_next_round_first.sh).
+XATTN_RESIDENT: bool = os.environ.get("MUSEV_XATTN_RESIDENT", "0") == "1"
+XATTN_RESIDENT_HITS: int = 0
 
 
 def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int, d: int, scale: float, *,
@@ -544,7 +549,12 @@ def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int
                 raise ValueError("attention: group_scales needs one entry per segment, the first one a weight")
             if group_scales[i] is not None:
                 s.new_group, s.group_scale = 1, float(group_scales[i])
-    check(_lib.load().mv_attention_f16(C.byref(ds), _stream()), "mv_attention_f16")
+    lib = _lib.load()
+    if XATTN_RESIDENT and not accumulate and lib.mv_attention_resident_ok(C.byref(ds)):
+        global XATTN_RESIDENT_HITS
+        XATTN_RESIDENT_HITS += 1
+        ds.resident_kv = 1
+    check(lib.mv_attention_f16(C.byref(ds), _stream()), "mv_attention_f16")
     return o
 
 

@@ -29,6 +29,15 @@ def unproven_on_hardware() -> bool:
     return DEV == "cpu" or os.environ.get("MUSEV_TEST_UNPROVEN") == "1"
 
 
+def _unproven(fn):
+    """a case of a kernel form that has not run on hardware yet: skipped (reported ok) on the GPU unless MUSEV_TEST_UNPROVEN=1"""
+    def run():
+        if not unproven_on_hardware():
+            return {"name": "skipped: kernel form not yet run on hardware (MUSEV_TEST_UNPROVEN=1 runs it)", "ok": True, "max_abs_err": 0.0}
+        return fn()
+    return run
+
+
 def _cmp(name, got, ref, atol, rtol=2e-3):
     got = got.float()
     ref = ref.float()
@@ -511,6 +520,52 @@ def case_attention_groups(d=40, nb=6, t=3, lq=130, lk=77, seed=75, spike=False):
     return _cmp(f"attention groups d{d} nb{nb} lq{lq} lk{lk} spike{int(spike)}", got, ref, atol=3e-3)
 
 
+def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True, heads=8):
+    """the resident-K/V kernel (mv_attn_desc.resident_kv, ops.XATTN_RESIDENT): text cross-attention (two segments of one softmax
+    group) [+ 0.7 x IP-Adapter (4 tokens) + 0.4 x FaceID (16 tokens) as further groups] against the fp32 sum of softmax attentions,
+    and against the tiled kernel on the same operands"""
+    from musev_amd import ops
+    c = heads * d
+    b = nb // t
+    q = _rand((nb * lq, c), seed)
+    kv = _rand((b * lk, 2 * c), seed + 1)
+    kv[lk - 3, :c] *= 4.0   # one dominant late key
+    k, v = kv[:, :c], kv[:, c:]
+    kvi = _rand((b * 4, 2 * c), seed + 2)
+    kvf = _rand((b * 16, 2 * c), seed + 3)
+    scale = d ** -0.5
+    bidx = [n // t for n in range(nb)]
+    k3, v3 = k.reshape(b, lk, c), v.reshape(b, lk, c)
+    q3 = q.reshape(nb, lq, c)
+    ref = _attn_ref(q3, k3[bidx], v3[bidx], heads, d, scale)
+    if groups:
+        l1 = 40   # the text keys as two segments of one group (d = 80: one segment and no FaceID group -- the LDS image of V of
+        ka, va = k3[:, :l1].reshape(b * l1, c).contiguous(), v3[:, :l1].reshape(b * l1, c).contiguous()   # 8 key tiles x 640 columns
+        kb, vb = k3[:, l1:].reshape(b * (lk - l1), c).contiguous(), v3[:, l1:].reshape(b * (lk - l1), c).contiguous()   # exceeds 160 KB)
+        segs = ([(ka, va, l1, t, 1, 0), (kb, vb, lk - l1, t, 1, 0)] if d == 40 else [(k, v, lk, t, 1, 0)]) + [(kvi[:, :c], kvi[:, c:], 4, t, 1, 0)]
+        gs = ([1.0, None] if d == 40 else [1.0]) + [0.7]
+        ref = ref + 0.7 * _attn_ref(q3, kvi[:, :c].reshape(b, 4, c)[bidx], kvi[:, c:].reshape(b, 4, c)[bidx], heads, d, scale)
+        if d == 40:
+            segs.append((kvf[:, :c], kvf[:, c:], 16, t, 1, 0))
+            gs.append(0.4)
+            ref = ref + 0.4 * _attn_ref(q3, kvf[:, :c].reshape(b, 16, c)[bidx], kvf[:, c:].reshape(b, 16, c)[bidx], heads, d, scale)
+    else:
+        segs, gs = [(k, v, lk, t, 1, 0)], None
+    flag, hits = ops.XATTN_RESIDENT, ops.XATTN_RESIDENT_HITS
+    try:
+        ops.XATTN_RESIDENT = True
+        got = ops.attention(q, segs, nb, lq, heads, d, scale, group_scales=gs)
+        took = ops.XATTN_RESIDENT_HITS == hits + 1
+        ops.XATTN_RESIDENT = False
+        tiled = ops.attention(q, segs, nb, lq, heads, d, scale, group_scales=gs)
+    finally:
+        ops.XATTN_RESIDENT = flag
+    name = f"attention resident d{d} nb{nb} lq{lq} lk{lk} groups{int(groups)}"
+    if not took:
+        return {"name": name, "ok": False, "max_abs_err": float("nan"), "detail": "the launch did not take the resident-K/V kernel"}
+    return _all_ok([_cmp(name, got, ref, atol=3e-3), _cmp(name + " vs tiled", got, tiled.float(), atol=3e-3)])
+
+
 def case_attention_spike(d=40):
     """forces online-softmax rescales: one key per 64-key tile has a much larger score than everything before it."""
     from musev_amd import ops
@@ -822,6 +877,11 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_groups_d40", case_attention_groups),
     ("attention_groups_d80", lambda: case_attention_groups(d=80, lq=100, seed=76)),
     ("attention_groups_d40_spike", lambda: case_attention_groups(d=40, lq=300, lk=200, seed=77, spike=True)),
+    ("attention_resident_d40_groups", _unproven(case_attention_resident)),
+    ("attention_resident_d40_text", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=1000, groups=False, seed=95))),
+    ("attention_resident_d80_groups", _unproven(lambda: case_attention_resident(d=80, nb=4, t=2, lq=260, groups=True, seed=91))),
+    ("attention_resident_128_keys", _unproven(lambda: case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94))),
+    ("attention_resident_5_heads", _unproven(lambda: case_attention_resident(d=40, nb=3, t=3, lq=17, lk=5, groups=False, seed=93, heads=5))),
     ("attention_spike", case_attention_spike),
     ("temporal_attention", case_temporal_attention),
     ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),
@@ -908,6 +968,9 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_level0", case_attention_level0),
     ("attention_groups_l0_half", lambda: case_attention_groups(d=40, nb=13, t=13, lq=4096, seed=78)),   # level-0 cross attention, one CFG half
     ("attention_groups_l1_half", lambda: case_attention_groups(d=80, nb=13, t=13, lq=1024, seed=79)),
+    ("attention_resident_l0_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, seed=96))),   # level-0 cross attention, one CFG half
+    ("attention_resident_l0_text_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, groups=False, seed=97))),
+    ("attention_resident_l1_half", _unproven(lambda: case_attention_resident(d=80, nb=13, t=13, lq=1024, seed=98))),
     ("groupnorm_l0", lambda: case_groupnorm(n=26, rows=4096, c1=320, seed=230)),
     ("groupnorm_l0_tconv", lambda: case_groupnorm(n=2, rows=13 * 4096, c1=320, seed=231)),       # statistics over T*H*W
     ("layernorm_l0", lambda: case_layernorm(rows=106496, c=320, seed=232)),
