@@ -97,6 +97,11 @@ typedef struct mv_gemm_desc {
     /* every block (16-byte epilogue, one K slice, no GEGLU / LayerNorm folding; leading dimensions ldc / ldr as c / residual).    */
     const void* residual_lo; /* fp16 [M][ldr] or NULL (a residual without a lo half)                                              */
     void* c_lo;              /* fp16 [M][ldc] or NULL (no carry)                                                                   */
+    /* workgroup -> tile order (ABI 8).  0: m-major in groups of 8 m-tiles (an XCD's id range = a few m-tiles x all n-tiles).        */
+    /* 1: ALLOW the weight-stationary order -- an XCD's id range = a few n-tiles x ALL m-tiles (and all K slices): each XCD streams */
+    /*    only its share of the weight matrix -- taken where N*K >= 2 * M*(c1 + c2), i.e. on the small-M levels.  Results are       */
+    /*    identical (every tile is still reduced over K in the same order by one block).                                           */
+    int32_t tile_order;
 } mv_gemm_desc;
 
 /* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K
@@ -120,7 +125,8 @@ int mv_gemm_config_desc(int cfg, int32_t* desc5);
 /* workgroup -> output-tile order of the implicit-GEMM kernel: logical ids (contiguous per XCD) walk groups of `group`
  * m-tiles m-fastest when the grid is more than `group` n-tiles wide, so that the ~64 blocks resident on one XCD cover
  * ~8 x 8 tiles (what its L2 must fetch per window) instead of 1-3 m-tiles x the whole weight matrix (the kernel uses
- * group 8).  Results are independent of the order.
+ * group 8; group -1 = the weight-stationary order of mv_gemm_desc.tile_order: n-major, a contiguous id range = a few
+ * n-tiles x all m-tiles).  Results are independent of the order.
  * Host-side evaluation of that map (launches nothing): tile_m[b], tile_n[b] of workgroup b, for b < tiles_m*tiles_n */
 int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int32_t* tile_n);
 

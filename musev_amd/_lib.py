@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_colbias", C.c_void_p), ("ln_eps", C.c_float), ("reserved0", C.c_int32),
         ("colstats", C.c_void_p), ("colstats_floats", C.c_int64),
         ("residual_lo", C.c_void_p), ("c_lo", C.c_void_p),
+        ("tile_order", C.c_int32),
     ]
 
 

@@ -112,6 +112,12 @@ __host__ __device__ __forceinline__ int mv_xcd_remap(int bid, int nwg) {
 // bijection onto the tile grid, each tile is still reduced over K in the same order by one block: results do not change.
 #define MV_TILE_GROUP 8
 __host__ __device__ __forceinline__ void mv_tile_order(int id, int tiles_m, int tiles_n, int group, int* tile_m, int* tile_n) {
+    if (group < 0) {  // weight-stationary (mv_gemm_desc.tile_order): n-major, a contiguous id range = a few n-tiles x ALL m-tiles
+        const int tn = id / tiles_m;
+        *tile_n = tn;
+        *tile_m = id - tn * tiles_m;
+        return;
+    }
     if (group <= 1 || tiles_n <= group) {
         const int tm = id / tiles_n;
         *tile_m = tm;

@@ -46,6 +46,7 @@ struct GemmArgs {
     int t, hw;
     int rows_per_group, act, geglu;
     int tiles_m, tiles_n;
+    int n_major;               // weight-stationary order: an XCD's contiguous id range = a few n-tiles x ALL m-tiles (mv_gemm_desc.tile_order)
     int nsplit, kt_per_split;  // split-K: blockIdx.y owns K tiles [y * kt_per_split, (y + 1) * kt_per_split)
     float* ws;                 // split-K workspace [nsplit][M][N] fp32
     // LayerNorm folded into the projection (LINEAR mode): w holds gamma-scaled weights, the block forms the row statistics of its A
@@ -516,7 +517,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = mv_xcd_remap(blockIdx.x, nwg);
     int tile_m, tile_n;
-    mv_tile_order(id, p.tiles_m, p.tiles_n, MV_TILE_GROUP, &tile_m, &tile_n);
+    // (n_major, block-uniform: small M under a large weight matrix -- every XCD streams ITS n-tiles' weights only)
+    mv_tile_order(id, p.tiles_m, p.tiles_n, p.n_major ? -1 : MV_TILE_GROUP, &tile_m, &tile_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int Mi = (int)p.M;
@@ -1238,7 +1240,7 @@ extern "C" int mv_gemm_config_desc(int cfg, int32_t* desc5) {
 // host-side evaluation of the workgroup -> tile map the kernel uses (the same inline functions): introspection for
 // tests and for reasoning about L2 locality; launches nothing
 extern "C" int mv_gemm_tile_order(int tiles_m, int tiles_n, int group, int32_t* tile_m, int32_t* tile_n) {
-    MV_REQUIRE(tiles_m > 0 && tiles_n > 0 && (long)tiles_m * tiles_n < (1L << 31) && tile_m && tile_n && group >= 0,
+    MV_REQUIRE(tiles_m > 0 && tiles_n > 0 && (long)tiles_m * tiles_n < (1L << 31) && tile_m && tile_n && group >= -1,
                "mv_gemm_tile_order: bad args");
     const int nwg = tiles_m * tiles_n;
     for (int b = 0; b < nwg; ++b) {
@@ -1290,6 +1292,10 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     a.t = d->t; a.hw = d->hw;
     a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.act = d->act; a.geglu = d->geglu;
     a.tiles_m = a.tiles_n = 0;
+    // weight-stationary tile order (mv_gemm_desc.tile_order = 1 ALLOWS it; taken where the weight matrix is at least twice the
+    // activations it multiplies -- the 16 x 16 / 8 x 8-latent levels, where every XCD otherwise streams the whole matrix through
+    // its 4 MB L2: 3.4-8.6 x the algorithmic bytes, profiles/r04z_pmc_by_problem.log)
+    a.n_major = (d->tile_order == 1 && (long)d->N * d->K >= 2L * d->M * cin) ? 1 : 0;
     a.nsplit = 1; a.kt_per_split = 0; a.ws = nullptr;
     a.ln_colsum = d->ln_colsum; a.ln_colbias = d->ln_colbias; a.ln_eps = d->ln_eps;
     a.colstats = nullptr;  // (set by mv_gemm_f16 once the choice is known to support it)

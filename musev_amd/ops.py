@@ -45,6 +45,10 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
+# MUSEV_GEMM_WEIGHT_STATIONARY=1: mv_gemm_desc.tile_order = 1 -- on the small-M levels (N*K >= 2 M*cin) an XCD's workgroups cover a few
+# n-tiles x all m-tiles, so each XCD streams 1/8 of the weight matrix instead of all of it (the 3.4-8.6 x traffic ratios of
+# profiles/r04z_pmc_by_problem.log).  Same results bit for bit.  Built at the end of round 4 WITHOUT a GPU left to time it: off.
+GEMM_WEIGHT_STATIONARY: bool = os.environ.get("MUSEV_GEMM_WEIGHT_STATIONARY", "0") == "1"
 
 
 # Producer-side GroupNorm statistics (env knob for A/B runs: MUSEV_COLSTATS=0 keeps the statistics pass of mv_groupnorm_f16):
@@ -110,6 +114,7 @@ def _carry_setup(d: GemmDesc, o: torch.Tensor, residual: Optional[torch.Tensor],
 def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None) -> None:
     lib = _lib.load()
     d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
+    d.tile_order = int(GEMM_WEIGHT_STATIONARY)
     pending_stats = None
     if colstats_for is not None and COLSTATS:
         rpt, nfl = C.c_int32(), C.c_int64()

@@ -520,6 +520,31 @@ def case_attention_groups(d=40, nb=6, t=3, lq=130, lk=77, seed=75, spike=False):
     return _cmp(f"attention groups d{d} nb{nb} lq{lq} lk{lk} spike{int(spike)}", got, ref, atol=3e-3)
 
 
+def case_gemm_weight_stationary(M=200, N=1280, K=640, seed=880, splitk=0):
+    """mv_gemm_desc.tile_order = 1 (ops.GEMM_WEIGHT_STATIONARY): the n-major workgroup order of the small-M levels is a bijection onto
+    the same tiles -- bit-identical output, with and without a K split; conv3x3 and the linear mode"""
+    from musev_amd import ops
+    x = _rand((M, K), seed)
+    w = _rand((N, K), seed + 1, 1.0 / math.sqrt(K))
+    bias = _rand((N,), seed + 2)
+    n_img, h, wd, cin = 2, 8, 8, 64
+    xc = _rand((n_img * h * wd, cin), seed + 3)
+    wc = ops.pack_conv_weight(_rand((N, cin, 3, 3), seed + 4, 1.0 / math.sqrt(9 * cin)))
+    flag, sk = ops.GEMM_WEIGHT_STATIONARY, ops.GEMM_SPLITK
+    try:
+        ops.GEMM_SPLITK = splitk
+        ops.GEMM_WEIGHT_STATIONARY = False
+        a0, c0 = ops.gemm(x, w, bias=bias), ops.conv3x3(xc, wc, n_img, h, wd)
+        ops.GEMM_WEIGHT_STATIONARY = True
+        a1, c1 = ops.gemm(x, w, bias=bias), ops.conv3x3(xc, wc, n_img, h, wd)
+    finally:
+        ops.GEMM_WEIGHT_STATIONARY, ops.GEMM_SPLITK = flag, sk
+    ref = x.float() @ w.float().t() + bias.float()
+    return _all_ok([_cmp(f"gemm weight-stationary M{M} N{N} K{K} split{splitk}", a1, ref, atol=4e-3),
+                    {"name": "weight-stationary order == default order (linear)", "ok": bool(torch.equal(a0, a1)), "max_abs_err": (a0.float() - a1.float()).abs().max().item()},
+                    {"name": "weight-stationary order == default order (conv3x3)", "ok": bool(torch.equal(c0, c1)), "max_abs_err": (c0.float() - c1.float()).abs().max().item()}])
+
+
 def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True, heads=8):
     """the resident-K/V kernel (mv_attn_desc.resident_kv, ops.XATTN_RESIDENT): text cross-attention (two segments of one softmax
     group) [+ 0.7 x IP-Adapter (4 tokens) + 0.4 x FaceID (16 tokens) as further groups] against the fp32 sum of softmax attentions,
@@ -877,6 +902,8 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_groups_d40", case_attention_groups),
     ("attention_groups_d80", lambda: case_attention_groups(d=80, lq=100, seed=76)),
     ("attention_groups_d40_spike", lambda: case_attention_groups(d=40, lq=300, lk=200, seed=77, spike=True)),
+    ("gemm_weight_stationary", _unproven(case_gemm_weight_stationary)),
+    ("gemm_weight_stationary_split", _unproven(lambda: case_gemm_weight_stationary(M=300, K=2560, splitk=4, seed=885))),
     ("attention_resident_d40_groups", _unproven(case_attention_resident)),
     ("attention_resident_d40_text", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=1000, groups=False, seed=95))),
     ("attention_resident_d80_groups", _unproven(lambda: case_attention_resident(d=80, nb=4, t=2, lq=260, groups=True, seed=91))),

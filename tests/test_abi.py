@@ -93,6 +93,25 @@ def test_tile_order_is_a_bijection(group):
             assert (tm == tm0).all() and (tn == tn0).all()
 
 
+def test_weight_stationary_order_gives_every_xcd_its_own_n_tiles():
+    """group -1 = mv_gemm_desc.tile_order 1 on the small-M levels: a bijection, and the workgroups of one XCD (ids = xcd mod 8) cover
+    ~tiles_n / 8 n-tiles x all m-tiles -- its L2 streams 1/8 of the weight matrix (m-major: every XCD touches every n-tile)"""
+    import numpy as np
+    for tiles_m, tiles_n in [(7, 8), (13, 8), (26, 10), (7, 80), (13, 24), (3, 100), (1, 37), (52, 8)]:
+        tm, tn = _tile_order(tiles_m, tiles_n, -1)
+        flat = tm.astype(np.int64) * tiles_n + tn
+        assert len(np.unique(flat)) == tiles_m * tiles_n
+        tm0, tn0 = _tile_order(tiles_m, tiles_n, 8)
+        ids = np.arange(tiles_m * tiles_n)
+        for xcd in range(8):
+            mine = ids % 8 == xcd
+            if not mine.any():
+                continue
+            n_ws, n_mm = len(np.unique(tn[mine])), len(np.unique(tn0[mine]))
+            assert n_ws <= -(-tiles_n // 8) + 1, (tiles_m, tiles_n, xcd, n_ws)
+            assert n_ws <= n_mm
+
+
 def test_tile_order_window_locality():
     """what an XCD's L2 must fetch for the ~64 workgroups resident on it: (distinct m-tiles + distinct n-tiles) of 64
     consecutive workgroups of ONE XCD (workgroup ids = xcd mod 8).  Wide grids: ~16 tile-slabs grouped vs ~(1 + 64)
