@@ -1,0 +1,92 @@
+"""Text (+ image-prompt) cross-attention: the resident-K/V kernel (mv_attn_desc.resident_kv, ops.XATTN_RESIDENT) against the tiled
+kernel it would replace, on the level-0 / level-1 shapes of config 2 (one CFG half: 13 frames) and config 3 (IP-Adapter tokens as a
+second softmax group), plus the GroupNorm fold inside the apply pass on the level-0 per-frame norm (run on the MI355X):
+
+    python tools/gpu_xattn_bench.py
+
+Prints microseconds per launch, the effective HBM rate over the algorithmic bytes (q read once + out written once) and the
+max |difference| between the two kernels."""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from musev_amd import ops  # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.float16).to(dev)
+
+
+def timed(fn, reps=30):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    heads, lk = 8, 77
+    for d, lq, nb, ip in ((40, 4096, 13, False), (40, 4096, 13, True), (40, 4096, 26, False), (80, 1024, 13, False), (80, 1024, 13, True),
+                          (40, 9216, 13, True)):
+        c = heads * d
+        qs = [rnd((nb * lq, c), 20 + i) for i in range(4)]   # cycled: the query tensor of a launch comes from HBM, not from the L2s
+        kv = rnd((lk, 2 * c), 30)
+        kvi = rnd((4, 2 * c), 31)
+        segs = [(kv[:, :c], kv[:, c:], lk, nb, 1, 0)]
+        gs = None
+        if ip:
+            segs.append((kvi[:, :c], kvi[:, c:], 4, nb, 1, 0))
+            gs = [1.0, 0.8]
+        outs = [torch.empty_like(qs[0]) for _ in range(2)]
+        k = [0]
+        res = {}
+        for resident in (False, True):
+            ops.XATTN_RESIDENT = resident
+            hits = ops.XATTN_RESIDENT_HITS
+
+            def run():
+                k[0] += 1
+                ops.attention(qs[k[0] % 4], segs, nb, lq, heads, d, d ** -0.5, out=outs[int(resident)], group_scales=gs)
+            us = timed(run)
+            if resident and ops.XATTN_RESIDENT_HITS == hits:
+                print(f"d {d} lq {lq} nb {nb}: the resident kernel did not take the launch")
+                continue
+            k[0] = 0
+            run()
+            res[resident] = us
+        torch.cuda.synchronize()
+        ops.XATTN_RESIDENT = False
+        mb = 2 * nb * lq * c * 2 / 1e6
+        diff = (outs[0].float() - outs[1].float()).abs().max().item()
+        print(f"cross-attention d {d} rows {nb} x {lq} keys {lk}{' + 4 (group)' if ip else ''}: tiled {res.get(False, float('nan')):7.1f} us "
+              f"({mb / res.get(False, math.nan) :5.2f} TB/s)   resident {res.get(True, float('nan')):7.1f} us ({mb / res.get(True, math.nan):5.2f} TB/s)"
+              f"   max |diff| {diff:.2e}")
+    # GroupNorm from producer column statistics, per-frame norm at level 0: fold launch + apply against the fold inside the apply
+    n, hw, cch = 13, 4096, 320
+    x = rnd((n * hw, cch), 40)
+    w = ops.pack_conv_weight(rnd((cch, cch, 3, 3), 41, 1.0 / math.sqrt(9 * cch)))
+    y = ops.conv3x3(x, w, n, 64, 64)
+    gamma, beta = rnd((cch,), 42, 0.2) + 1, rnd((cch,), 43, 0.2)
+    out = torch.empty_like(y)
+    res = {}
+    for fold in (False, True):
+        ops.GN_FOLD_IN_APPLY = fold
+        res[fold] = timed(lambda: ops.groupnorm(y, gamma, beta, n, hw, eps=1e-5, silu=True, out=out))
+    ops.GN_FOLD_IN_APPLY = False
+    print(f"groupnorm from column statistics, {n} x {hw} x {cch}: fold launch + apply {res[False]:6.1f} us   fold inside apply {res[True]:6.1f} us")
+
+
+if __name__ == "__main__":
+    main()
