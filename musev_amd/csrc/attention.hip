@@ -821,7 +821,9 @@ struct XAttnArgs {
     int tldk[8], tldv[8], tlen[8], tdiv[8], tmul[8], tadd[8], tk0[8], tgrp[8];
 };
 
-template <int D, int KT>
+// ONEG: a single softmax group (the text-only cross-attention of `musev`): no group selects, the weight gscale / l is applied to
+// the 4 NDT output accumulators instead of the 4 KT probabilities.
+template <int D, int KT, bool ONEG>
 __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
     constexpr int NC32 = D / 32;            // whole 32-deep contraction chunks
     constexpr bool TAIL = (D % 32) != 0;    // + one 16-deep step (d = 40: columns 32..39 | zeros; d = 80: columns 64..79)
@@ -861,7 +863,8 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
             *reinterpret_cast<uint4*>(lds + (long)row * vrs + slot * 8) = v;
         }
     }
-    // ---- prologue 2: this head's K fragments, straight from global ----
+    // ---- prologue 2: this head's K fragments, straight from global, pre-multiplied by scale * log2(e) (once per block: the
+    // query fragments then go into the matrix pipe as loaded, the scores come out in the log2 domain) ----
     half8v kf[KT][NC32 > 0 ? NC32 : 1];
     half4v kt16[KT];
     int nvalid[KT];   // valid keys of the tile (16 except a segment's last tile)
@@ -875,12 +878,20 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
 #pragma unroll
         for (int c = 0; c < NC32; ++c) {
             kf[t][c] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) kf[t][c] = *reinterpret_cast<const half8v*>(krow + 32 * c + 8 * g);
+            if (ok) {
+                const half8v raw = *reinterpret_cast<const half8v*>(krow + 32 * c + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[t][c][e] = (half_t)((float)raw[e] * p.scale_log2e);
+            }
         }
         kt16[t] = half4v{0, 0, 0, 0};
         if constexpr (TAIL) {
             const int dcol = 32 * NC32 + 4 * g;
-            if (ok && dcol < D) kt16[t] = *reinterpret_cast<const half4v*>(krow + dcol);
+            if (ok && dcol < D) {
+                const half4v raw = *reinterpret_cast<const half4v*>(krow + dcol);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kt16[t][e] = (half_t)((float)raw[e] * p.scale_log2e);
+            }
         }
     }
     __syncthreads();
@@ -923,15 +934,11 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
     fetch_q(r_begin);
 #pragma unroll 1
     for (int r0 = r_begin; r0 < r_end; r0 += 16) {
-        // B operand of S^T = K Q^T, pre-multiplied by scale * log2(e)
+        // B operand of S^T = K Q^T (the scale sits in the K fragments)
         half8v qf[NC32 > 0 ? NC32 : 1];
-        half4v qt16;
 #pragma unroll
-        for (int c = 0; c < NC32; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[c][e] = (half_t)((float)qraw[c][e] * p.scale_log2e);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) qt16[e] = (half_t)((float)qtraw[e] * p.scale_log2e);
+        for (int c = 0; c < NC32; ++c) qf[c] = qraw[c];
+        const half4v qt16 = qtraw;
         if (r0 + 16 < r_end) fetch_q(r0 + 16);
 
         // acc[t][r] = S[q = l15][key 16 t + 4 g + r]  (log2 domain)
@@ -948,44 +955,62 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
                     if (4 * g + r >= nvalid[t]) acc[t][r] = -INFINITY;
             }
         }
-        // per softmax group: maximum, exponentials, row sum; the probabilities leave normalised and weighted
-        float mg[4] = {0.f, 0.f, 0.f, 0.f}, lg[4] = {0.f, 0.f, 0.f, 0.f};
+        // softmax: per group maximum, exponentials, row sum.  Per-tile maxima / sums first, then the groups pick their tiles
+        // (wave-uniform selects): ~2 VALU per (group, tile) instead of a pass over the tile's scores per group
+        float tmax[KT];
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            if (gi >= p.ngroups) continue;  // wave-uniform
-            float m = -INFINITY;
+        for (int t = 0; t < KT; ++t) tmax[t] = fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3]));
+        float mg[4] = {0.f, 0.f, 0.f, 0.f}, wg[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ONEG) {
+            float m = tmax[0];
 #pragma unroll
-            for (int t = 0; t < KT; ++t)
-                if (p.tgrp[t] == gi) m = fmaxf(m, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
+            for (int t = 1; t < KT; ++t) m = fmaxf(m, tmax[t]);
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
-            mg[gi] = m;
+            mg[0] = m;
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < 3; ++gi) {   // branch-free: an absent group comes out as m = -inf, l = 0 and is never selected
+                float m = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) m = p.tgrp[t] == gi ? fmaxf(m, tmax[t]) : m;
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                mg[gi] = m;
+            }
         }
+        float tsum[KT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            const int gi = p.tgrp[t];
-            const float m = gi == 0 ? mg[0] : gi == 1 ? mg[1] : gi == 2 ? mg[2] : mg[3];
-            float s4 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r] - m);
-                s4 += acc[t][r];
+            float m = mg[0];
+            if constexpr (!ONEG) {
+                const int gi = p.tgrp[t];
+                m = gi == 0 ? mg[0] : gi == 1 ? mg[1] : mg[2];
             }
-            if (gi == 0) lg[0] += s4;
-            else if (gi == 1) lg[1] += s4;
-            else if (gi == 2) lg[2] += s4;
-            else lg[3] += s4;
-        }
-        float wg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            if (gi >= p.ngroups) continue;
-            float l = lg[gi];
+            for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r] - m);
+            tsum[t] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+        }
+        if constexpr (ONEG) {
+            float l = tsum[0];
+#pragma unroll
+            for (int t = 1; t < KT; ++t) l += tsum[t];
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
-            wg[gi] = p.gscale[gi] / l;   // every group holds at least one real key: l >= 1
+            wg[0] = p.gscale[0] / l;   // a group holds at least one real key: l >= 1
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < 3; ++gi) {
+                float l = 0.f;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) l += p.tgrp[t] == gi ? tsum[t] : 0.f;
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                wg[gi] = p.gscale[gi] / l;
+            }
         }
-        // O^T[d][q] = sum over the key chunks of V^T P~^T
+        // O^T[d][q] = sum over the key chunks of V^T P^T  (several groups: P leaves normalised and weighted, P~ = w_g P, so that the
+        // groups' weighted sum is this one product; one group: the weight goes on the output accumulators)
         float4v acc_o[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) acc_o[dt] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -996,14 +1021,21 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
             for (int half = 0; half < 2; ++half) {
                 const int t = 2 * cc + half;
                 if (t < KT) {
-                    const int gi = p.tgrp[t];
-                    const float w = gi == 0 ? wg[0] : gi == 1 ? wg[1] : gi == 2 ? wg[2] : wg[3];
+                    float w = 1.0f;
+                    if constexpr (!ONEG) {
+                        const int gi = p.tgrp[t];
+                        w = gi == 0 ? wg[0] : gi == 1 ? wg[1] : wg[2];
+                    }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pf[4 * half + r] = (half_t)(acc[t][r] * w);
+                    for (int r = 0; r < 4; ++r) pf[4 * half + r] = (half_t)(ONEG ? acc[t][r] : acc[t][r] * w);
                 }
             }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt][cc], pf, acc_o[dt], 0, 0, 0);
+        }
+        if constexpr (ONEG) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) acc_o[dt] *= wg[0];
         }
         // acc_o[dt][r] = O[q = l15][d = 16 dt + 4 g + r]
         const int qr = r0 + l15;
@@ -1281,15 +1313,15 @@ int attn_num_cus() {
 }
 
 // resident-K/V cross-attention (mv_attn_desc.resident_kv): eligibility is the caller's to check (mv_attention_resident_ok)
-template <int D, int KT>
+template <int D, int KT, bool ONEG>
 int launch_xattn(const XAttnArgs& a, unsigned grid, int smem, hipStream_t s) {
     static int attr_smem = 0;  // idempotent one-time attribute of this instantiation (the LDS image of V: up to 160 KB)
     if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<D, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<D, KT, ONEG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_smem = smem;
     }
-    hipLaunchKernelGGL((xattn_kernel<D, KT>), dim3(grid), dim3(64 * a.heads), smem, s, a);
+    hipLaunchKernelGGL((xattn_kernel<D, KT, ONEG>), dim3(grid), dim3(64 * a.heads), smem, s, a);
     return MV_OK;
 }
 
@@ -1303,14 +1335,14 @@ int xattn_key_tiles(const mv_attn_desc* d) {
         kt += (d->seg[s].len + 15) / 16;
         groups += (s == 0 || d->seg[s].new_group) ? 1 : 0;
     }
-    if (kt > 8 || groups > 4) return -1;
+    if (kt > 8 || groups > 3) return -1;
     const long smem = (long)kt * 16 * (d->heads * d->d + 8) * 2;
     return smem <= 160 * 1024 ? kt : -1;
 }
 
 int xattn_launch(const mv_attn_desc* d, void* stream) {
     const int kt = xattn_key_tiles(d);
-    MV_REQUIRE(kt > 0, "mv_attention_f16: resident_kv needs d in {40, 80}, heads <= 8, <= 128 keys in tiles of 16 per segment, <= 4 groups, no accumulate, "
+    MV_REQUIRE(kt > 0, "mv_attention_f16: resident_kv needs d in {40, 80}, heads <= 8, <= 128 keys in tiles of 16 per segment, <= 3 groups, no accumulate, "
                        "and an LDS image of V under 160 KB (ask mv_attention_resident_ok)");
     XAttnArgs a;
     a.q = (const half_t*)d->q; a.out = (half_t*)d->out; a.ldq = d->ldq; a.ldo = d->ldo;
@@ -1354,7 +1386,7 @@ int xattn_launch(const mv_attn_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = MV_ERR_INVALID;
     switch (kt * 100 + d->d) {
-#define MV_XA(KT_, D_) case KT_ * 100 + D_: rc = launch_xattn<D_, KT_>(a, (unsigned)blocks, smem, s); break;
+#define MV_XA(KT_, D_) case KT_ * 100 + D_: rc = a.ngroups == 1 ? launch_xattn<D_, KT_, true>(a, (unsigned)blocks, smem, s) : launch_xattn<D_, KT_, false>(a, (unsigned)blocks, smem, s); break;
         MV_XA(1, 40) MV_XA(2, 40) MV_XA(3, 40) MV_XA(4, 40) MV_XA(5, 40) MV_XA(6, 40) MV_XA(7, 40) MV_XA(8, 40)
         MV_XA(1, 80) MV_XA(2, 80) MV_XA(3, 80) MV_XA(4, 80) MV_XA(5, 80) MV_XA(6, 80) MV_XA(7, 80) MV_XA(8, 80)
 #undef MV_XA
