@@ -241,46 +241,39 @@ __global__ void gn_apply_kernel(const GnArgs a) {
         if (wave < nfull) {
             for (int gI = wave; gI < a.groups; gI += nfull) {
                 const int c0 = gI * cpg;
-                double ts[4] = {0.0, 0.0, 0.0, 0.0}, tss[4] = {0.0, 0.0, 0.0, 0.0};
+                double s2 = 0.0, ss2 = 0.0;
+                // the played waves one after the other (two doubles live, not eight: the apply loop keeps its occupancy)
+#pragma unroll 1
+                for (int v = 0; v < nv; ++v) {
+                    double ts = 0.0, tss = 0.0;
 #pragma unroll
-                for (int src = 0; src < 2; ++src) {
-                    const float* cs = src ? a.cs2 : a.cs1;
-                    const int cb = src ? a.c1 : 0, cn = src ? a.c2 : a.c1;
-                    const int lo = c0 > cb ? c0 : cb, hi = (c0 + cpg < cb + cn) ? c0 + cpg : cb + cn;
-                    if (!cs || lo >= hi) continue;
-                    const int rpt = src ? a.rpt2 : a.rpt1;
-                    const long tiles = a.rows / rpt;
-                    const int w = hi - lo;
-                    const float* base = cs + (item * tiles * cn + (lo - cb)) * 2;
-                    const long total = tiles * w;
-                    for (long k0 = 0; k0 < total; k0 += a.fold_threads) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const long k = k0 + v * 64 + lane;
-                            if (v < nv && k < total) {
-                                const long tile = k / w;
-                                const int c = (int)(k - tile * w);
-                                const float2v x = *reinterpret_cast<const float2v*>(base + (tile * cn + c) * 2);
-                                ts[v] += (double)x[0];
-                                tss[v] += (double)x[1];
-                            }
+                    for (int src = 0; src < 2; ++src) {
+                        const float* cs = src ? a.cs2 : a.cs1;
+                        const int cb = src ? a.c1 : 0, cn = src ? a.c2 : a.c1;
+                        const int lo = c0 > cb ? c0 : cb, hi = (c0 + cpg < cb + cn) ? c0 + cpg : cb + cn;
+                        if (!cs || lo >= hi) continue;
+                        const int rpt = src ? a.rpt2 : a.rpt1;
+                        const int tiles = (int)(a.rows / rpt);   // (32-bit index arithmetic: the launcher bounds the pairs per group)
+                        const int w = hi - lo;
+                        const float* base = cs + (item * tiles * cn + (lo - cb)) * 2;
+                        const int total = tiles * w;
+                        for (int k = v * 64 + lane; k < total; k += a.fold_threads) {
+                            const int tile = k / w;
+                            const int c = k - tile * w;
+                            const float2v x = *reinterpret_cast<const float2v*>(base + (tile * cn + c) * 2);
+                            ts += (double)x[0];
+                            tss += (double)x[1];
                         }
                     }
-                }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) {
-                        ts[v] += __shfl_xor(ts[v], off, 64);
-                        tss[v] += __shfl_xor(tss[v], off, 64);
+                        ts += __shfl_xor(ts, off, 64);
+                        tss += __shfl_xor(tss, off, 64);
                     }
+                    s2 += ts;   // the fold block's `for (w2 ...) s += red[w2]`: waves in order, starting from 0.0
+                    ss2 += tss;
                 }
                 if (lane == 0) {
-                    double s2 = 0.0, ss2 = 0.0;
-                    for (int v = 0; v < nv; ++v) {
-                        s2 += ts[v];
-                        ss2 += tss[v];
-                    }
                     gn_emit_stat(s2, ss2, cpg, a.rows, a.eps, sstat[gI][0], sstat[gI][1]);
                 }
             }
@@ -643,7 +636,7 @@ int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32
         const int cpg = C / num_groups;
         const long per_block = (rows / rpt1) * (long)cpg;
         const int threads = per_block <= 512 ? 64 : per_block <= 2048 ? 256 : 1024;
-        if ((variant & 1) && threads <= 256 && num_groups <= 64 && bs >= 64) {  // the fold rides in the apply pass
+        if ((variant & 1) && threads <= 256 && num_groups <= 64 && bs >= 64 && rows / (rpt2 > 0 && c2 ? (rpt2 < rpt1 ? rpt2 : rpt1) : rpt1) * (long)C < 0x7fffffffL) {  // the fold rides in the apply pass
             a.fold_threads = threads;
             hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
             MV_CHECK_LAUNCH("mv_groupnorm_cs_f16(fold + apply)");
