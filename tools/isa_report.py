@@ -7,7 +7,8 @@ Per kernel: VGPRs (arch + accumulator), SGPRs, scratch bytes (spills), static LD
 the instruction mix of its HOTTEST LOOP (among the backward branches whose body holds matrix instructions, the one with the highest
 MFMA density -- the K loop / key-tile loop, not the outer loop that also spans the epilogue; kernels without MFMAs: the longest
 loop): MFMA, transcendental (v_exp / v_rcp / ...), conversions, other VALU, LDS, global / buffer memory, scratch (spill traffic INSIDE
-that loop), scalar, waits.  What it is for: the counters of
+that loop), scalar, waits.  The mix counts every instruction in the loop's address range, i.e. also blocks the common path branches
+around (attn3: the rescale and the partial-tile masking): an upper bound per iteration.  What it is for: the counters of
 profiles/*_sq_counters.log say which pipe is busy; this says why (e.g. attn3<40>: VALU / MFMA instruction ratio), and it is the only
 evidence available for a kernel form written while no GPU is at hand (spills, register budget, a loop the compiler bloated)."""
 from __future__ import annotations
