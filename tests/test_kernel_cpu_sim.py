@@ -511,16 +511,20 @@ def test_gemm_new_configurations_conv_on_the_host(gemm_sim, cfg):
 
 def test_gemm_tuned_table_lookup_on_the_host(tmp_path_factory):
     """the measured table of gemm_tuned.h (written by tools/gpu_gemm_tune.py; {mode, M, N, K, geglu, ln, cfg, nsplit}, looked up by
-    exact (mode, N, K, geglu) and the nearest M within a factor of 3): a build with a two-entry table must send the matching problems
-    -- and the same layer at a nearby M -- to the listed configurations, problems more than 3x away in M to the rules, with unchanged
-    results; cfg = -2 (rules only) and a forced id through the descriptor"""
+    exact (mode, N, K, geglu) and the nearest M within a factor of 3, then the keyed table {mode, geglu, ln, K bucket, fill bucket,
+    cfg}): a build with a two-entry table and one keyed entry must send the matching problems -- and the same layer at a nearby M in
+    the same key bucket -- to the listed configurations, a problem more than 3x away in M to the rules, a problem of ANOTHER layer
+    that falls on the keyed entry to that entry's tile, with unchanged results; cfg = -2 (rules only) and a forced id through the
+    descriptor"""
     if not os.path.exists(CLANG):
         pytest.skip("ROCm host clang not available")
     import sim_lib
     work = tmp_path_factory.mktemp("gemm_sim_tuned")
     table = work / "gemm_tuned_test.h"
     table.write_text("static const GemmTuned kGemmTuned[] = {\n    {0, 300, 320, 192, 0, 0, 6, 1},\n    {0, 140, 512, 64, 1, 0, 7, 1},\n"
-                     "    {-1, 0, 0, 0, 0, 0, -1, 0},\n};\nstatic const int kNumGemmTuned = 2;\n")
+                     "    {-1, 0, 0, 0, 0, 0, -1, 0},\n};\nstatic const int kNumGemmTuned = 2;\n"
+                     # K = 512 -> 8 K tiles = bucket 1; 90 x 320 under 256 CUs = fill bucket 0 -> catalogue id 13 (64 x 80 tiles, 2 waves)
+                     "static const GemmKeyed kGemmKeyed[] = {\n    {0, 0, 0, 1, 0, 13},\n    {-1, 0, 0, 0, 0, -1},\n};\nstatic const int kNumGemmKeyed = 1;\n")
     src = open(os.path.join(ROOT, "musev_amd", "csrc", "gemm.hip")).read().replace('#include "gemm_tuned.h"', f'#include "{table}"')
     (work / "gemm_sim.inc").write_text(sim_lib.transform(src))
     shutil.copy(os.path.join(SIM, "gemm_main.cpp"), work / "gemm_main.cpp")
@@ -545,3 +549,9 @@ def test_gemm_tuned_table_lookup_on_the_host(tmp_path_factory):
     got = _run_gemm_job(work, exe, "tmiss", dict(a=a[:90], w=w), dict(base, M=90), 1, trace=trace)
     assert "block 256 " in trace[0], trace[0]
     _close(got, ref[:90])
+    # a layer the table does not hold at all (K = 512), in the bucket of the keyed entry: that entry's tile (2 waves)
+    a2, w2 = _rnd((90, 512), 122), _rnd((N, 512), 123, 1 / math.sqrt(512))
+    trace = []
+    got = _run_gemm_job(work, exe, "tkeyed", dict(a=a2, w=w2), dict(base, M=90, K=512, lda=512, c1=512), 1, trace=trace)
+    assert "block 128 " in trace[0], trace[0]
+    _close(got, a2.float() @ w2.float().t())
