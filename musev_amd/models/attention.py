@@ -45,8 +45,8 @@ class BasicTransformerBlock(HipModule):
     # ---- spatial: rows = (frame n, pixel p), sequences = the HW pixels of one frame ----
     def hip_forward_spatial(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool, use_ip: bool) -> torch.Tensor:
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
-        if ctx.refer_self is not None:
-            ctx.split()  # refer_self_attn_emb is handed over per CFG half
+        if ctx.refer_self is not None or ctx.refer_self_write is not None:
+            ctx.split()  # refer_self_attn_emb is handed over (or collected) per CFG half
         x_in = x
         x, q = ctx.shared((id(self), "attn1+q"), lambda: self._self_attention_and_query(x_in, ctx, geo, reference_only))
         ctx.split()  # the text (and the image-prompt tokens) differ between the CFG halves from here on
@@ -57,6 +57,12 @@ class BasicTransformerBlock(HipModule):
         does not see the text (shared by the CFG halves in the first block of the network, runtime.PrefixMemo)"""
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
         a1 = self.attn1
+        if ctx.refer_self_write is not None:
+            # attention.py:240-259 + transformer_2d.py:340-359 ("write"): the self-attention's INPUT (norm1's output) of this block goes
+            # into the caller's list as [(b t), c, h, w] -- the one place the normalised rows are materialised (elsewhere norm1 is
+            # folded into the q / k / v projection)
+            nrm = ops.layernorm(x, self.norm1.weight.detach().to(torch.float16), self.norm1.bias.detach().to(torch.float16), self.norm1.eps)
+            ctx.refer_self_write[self.spatial_self_attn_idx] = nrm.view(geo.n, geo.h, geo.w, c).permute(0, 3, 1, 2).contiguous()
         qkv = ln_linear(a1, "qkv", x, self.norm1, a1.build_qkv)  # norm1 folded into the fused q/k/v projection where it pays
         k, v = qkv[:, c:2 * c], qkv[:, 2 * c:]
         segs = [(k, v, geo.hw, 1, 1, 0)]

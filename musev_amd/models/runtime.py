@@ -98,6 +98,7 @@ class Ctx:
     face_scale: float = 0.0
     face_src: Optional[torch.Tensor] = None
     refer_self: Optional[List[torch.Tensor]] = None  # refer_self_attn_emb ("read"): per spatial block [b, c, t, h, w]
+    refer_self_write: Optional[list] = None          # refer_self_attn_emb ("write"): the caller's list, filled per spatial block
     # every ResnetBlock2D.time_emb_proj / TransformerTemporalModel.frame_emb_proj of the network applied in ONE GEMM at
     # the top of the forward ([frames, sum of C_out]); a block takes its column slice.  (39 one-tile launches with
     # M = 26 rows, each a serial 20-step K loop, become 2 launches that fill the chip.)

@@ -404,16 +404,23 @@ class UNet3DConditionModel(HipModule):
                 raise NotImplementedError("vision_clip_emb must be [b, n, q]")
             clip = vision_clip_emb.to(dtype=torch.float16).reshape(-1, vision_clip_emb.shape[-1]).contiguous()
             clip_len = vision_clip_emb.shape[1]
-        refer_self = None
+        refer_self = refer_self_write = None
         if refer_self_attn_emb is not None:
             # attention.py:261-289 ("read"): block i's reference-only self-attention also attends to the tokens of
-            # refer_self_attn_emb[i] ([b, c, t, h, w]: a ReferenceNet's self-attention inputs).  "write" is the producer side of
-            # the same list (a ReferenceNet run with need_self_attn_block_embs, which no shipped flavour enables): not built.
-            if str(refer_self_attn_emb_mode).lower() != "read":
-                raise NotImplementedError("refer_self_attn_emb_mode='write' (producing the embeddings) is not built; 'read' is")
+            # refer_self_attn_emb[i] ([b, c, t, h, w]: a ReferenceNet's self-attention inputs).  "write" (attention.py:240-259,
+            # transformer_2d.py:340-359) is the producer side of the same list: block i leaves the input of its self-attention in
+            # the CALLER'S list as [(b t), c, h, w] (no shipped flavour runs the UNet3D in this mode).
+            mode = str(refer_self_attn_emb_mode).lower()
+            if mode not in ("read", "write"):
+                raise ValueError(f"refer_self_attn_emb_mode {refer_self_attn_emb_mode!r}")
             if not hasattr(self._spatial_blocks()[0][1], "spatial_self_attn_idx"):
                 raise ValueError("must call unet.insert_spatial_self_attn_idx to generate spatial attn index")
-            refer_self = list(refer_self_attn_emb)
+            if mode == "read":
+                refer_self = list(refer_self_attn_emb)
+            else:
+                if not isinstance(refer_self_attn_emb, list):
+                    raise ValueError("refer_self_attn_emb_mode='write' fills the list it is given: pass a list (one slot per spatial block)")
+                refer_self_write = refer_self_attn_emb
         face, face_len = None, 0
         if self.need_t2i_ip_adapter_face and ip_adapter_face_emb is not None:   # (:1000-1006; ignored by models built without it)
             if ip_adapter_face_emb.ndim != 3 or ip_adapter_face_emb.shape[0] != b:
@@ -424,7 +431,8 @@ class UNet3DConditionModel(HipModule):
         ctx = Ctx(emb_proj=emb_proj, temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
                   clip=clip, clip_len=clip_len, ip_scale=float(ip_adapter_scale), skip_temporal=False,
                   text_src=encoder_hidden_states, clip_src=vision_clip_emb, face=face, face_len=face_len,
-                  face_scale=float(ip_adapter_face_scale), face_src=ip_adapter_face_emb, refer_self=refer_self, memo=prefix_memo)
+                  face_scale=float(ip_adapter_face_scale), face_src=ip_adapter_face_emb, refer_self=refer_self, refer_self_write=refer_self_write,
+                  memo=prefix_memo)
 
         # ---- 2. pre-process (:1008-1063) ----
         pose = None

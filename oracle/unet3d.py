@@ -466,6 +466,8 @@ def basic_block_spatial(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dic
     The CFG recompute at :319-334 writes a value that is never read (dead) and is not restated."""
     n = _ln(sd, p + ".norm1", x)
     refer_emb = None
+    if ctx.get("refer_self_attn_emb_write") is not None:   # attention.py:240-259 ("write"): norm_hidden_states, [bt, hw, c] here
+        ctx["refer_self_attn_emb_write"][ctx["spatial_idx"][p]] = n
     if ctx.get("refer_self_attn_emb") is not None:   # attention.py:261-289: indexed by the block's spatial_self_attn_idx
         refer_emb = ctx["refer_self_attn_emb"][ctx["spatial_idx"][p]]
     x = _h("stream_inner", attn_self_reference_only(sd, p + ".attn1", n, heads, ctx["num_frames"], ctx["vis_idx"], refer_emb) + x)
@@ -492,6 +494,9 @@ def transformer_2d(sd, p: str, x: Tensor, ehs: Tensor, heads: int, ctx: dict) ->
     y = _h("gemm", F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"]))
     y = y.permute(0, 2, 3, 1).reshape(b, h * w, c)
     y = basic_block_spatial(sd, p + ".transformer_blocks.0", y, ehs, heads, ctx)
+    if ctx.get("refer_self_attn_emb_write") is not None:   # transformer_2d.py:340-359: "bt (h w) c -> bt c h w"
+        i = ctx["spatial_idx"][p + ".transformer_blocks.0"]
+        ctx["refer_self_attn_emb_write"][i] = ctx["refer_self_attn_emb_write"][i].reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
     y = y.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
     y = _h("gemm", F.conv2d(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]))
     return _h("stream_outer", y + res)
@@ -547,8 +552,9 @@ def unet3d_forward(
 ) -> Tensor:
     """UNet3DConditionModel.forward (unet_3d_condition.py:773-1280).  sample [b, c, t, h, w] -> same shape.
     `collect` (optional dict) receives named intermediate activations for block-level parity tests."""
-    if refer_self_attn_emb is not None and refer_self_attn_emb_mode.lower() != "read":
-        raise NotImplementedError("refer_self_attn_emb_mode='write' is the ReferenceNet's side of the hand-over (not restated)")
+    if refer_self_attn_emb is not None and refer_self_attn_emb_mode.lower() not in ("read", "write"):
+        raise ValueError(f"refer_self_attn_emb_mode {refer_self_attn_emb_mode!r}")
+    write_embs = refer_self_attn_emb is not None and refer_self_attn_emb_mode.lower() == "write"
     ch = cfg["block_out_channels"]
     heads = cfg["attention_head_dim"]
     L = cfg["layers_per_block"]
@@ -584,7 +590,10 @@ def unet3d_forward(
                ip_adapter_face_scale=ip_adapter_face_scale,
                # refer_self_attn_emb ("read"): the spatial blocks are numbered in the sorted order of their module names
                # (insert_spatial_self_attn_idx, unet_3d_condition.py:1663-1686)
-               refer_self_attn_emb=refer_self_attn_emb,
+               refer_self_attn_emb=None if write_embs else refer_self_attn_emb,
+               # "write" (attention.py:240-259, transformer_2d.py:340-359): every spatial block leaves the INPUT of its self-attention
+               # (norm1's output) in the caller's list, as [(b t), c, h, w]
+               refer_self_attn_emb_write=refer_self_attn_emb if write_embs else None,
                # -- every BasicTransformerBlock outside "temp_attentions", i.e. incl. transformer_in's (get_attns' exclude test
                # overwrites its include test, :1720-1726)
                spatial_idx={k: i for i, k in enumerate(sorted({key[:-len(".norm1.weight")] for key in sd

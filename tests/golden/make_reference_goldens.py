@@ -94,8 +94,12 @@ def gen_unet(cases=None):
             if case.get("check_cfg_flag"):
                 out_cfg = model(x, t, encoder_hidden_states=ehs, return_dict=False, do_classifier_free_guidance=True, **kw)[0]
                 extra["cfg_flag_max_abs_diff"] = np.float32((out - out_cfg).abs().max().item())
+        if case.get("refer_self_write"):   # the list the reference's forward filled (fp16 storage: these are LayerNorm outputs, O(1))
+            for i, e in enumerate(kw["refer_self_attn_emb"]):
+                if e is not None:
+                    extra[f"emb{i}"] = e.numpy().astype(np.float16)
         np.savez_compressed(os.path.join(HERE, f"reference_unet_{name}.npz"), out=out.numpy().astype(np.float32), **extra)
-        print("unet", name, tuple(out.shape), "absmax", out.abs().max().item(), {k: float(v) for k, v in extra.items()},
+        print("unet", name, tuple(out.shape), "absmax", out.abs().max().item(), {k: float(v) for k, v in extra.items() if np.ndim(v) == 0},
               f"{time.time() - t_start:.0f} s", flush=True)
         del model, sd
 

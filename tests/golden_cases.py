@@ -48,6 +48,10 @@ UNET_CASES = {
     # reference embedding [b, c, t_ref, h_ref, w_ref] (here 1 x 4 x 4 reference tokens per block)
     "musev_hipw_refer_self": dict(flavour="musev", arch=_HIPW, b=2, t=4, h=16, w=16, n_cond=1, weight_seed=13, input_seed=23, timestep=501,
                                   refer_self=True),
+    # ... and in "write" mode (attention.py:240-259, transformer_2d.py:340-359): every spatial block leaves the input of its self-attention
+    # (norm1's output) in the caller's list as [(b t), c, h, w]; the golden holds the output AND the list
+    "musev_hipw_refer_self_write": dict(flavour="musev", arch=_HIPW, b=1, t=2, h=8, w=8, n_cond=1, weight_seed=14, input_seed=24, timestep=401,
+                                        refer_self=True, refer_self_write=True),
     "refnet_hipw_faceid": dict(flavour="musev_referencenet", arch=dict(_HIPW3, need_t2i_ip_adapter_face=True), b=2, t=4, h=16, w=16,
                                n_cond=1, weight_seed=12, input_seed=22, timestep=301, face=True),
 }
@@ -117,6 +121,9 @@ def case_inputs(case: dict, cfg: dict):
         tin = [ch[0]] if cfg["need_transformer_in"] else []
         kw["refer_self_attn_emb"] = [0.5 * torch.randn(b, c, 1, 4, 4, generator=g) for c in widths + tin + ups]
         kw["refer_self_attn_emb_mode"] = "read"
+        if case.get("refer_self_write"):
+            kw["refer_self_attn_emb"] = [None] * len(widths + tin + ups)   # (a fresh list per call: the forward fills it)
+            kw["refer_self_attn_emb_mode"] = "write"
     if case.get("face"):
         kw["ip_adapter_face_emb"] = torch.randn(b, 4, cfg["cross_attention_dim"], generator=g)
         kw["ip_adapter_face_scale"] = 0.6
@@ -206,6 +213,22 @@ LOOP_CASES_AT_SIZE = {
                                prompt_seed=35, side_seed=36, guidance_scale=3.5, num_inference_steps=20, steps=20, context_frames=12,
                                context_overlap=4),
 }
+
+
+def check_written_refer_embs(name: str, embs, golden, tol: float) -> float:
+    """"write" mode cases: the list the forward filled against the golden's emb<i> arrays (slots the reference leaves None -- the
+    transformer_in quirk -- must stay None); returns the largest deviation"""
+    worst = 0.0
+    for i, e in enumerate(embs):
+        key = f"emb{i}"
+        if key not in golden:
+            assert e is None, f"{name}: slot {i} must stay empty"
+            continue
+        want = torch.from_numpy(golden[key]).float()
+        assert e is not None and tuple(e.shape) == tuple(want.shape), f"{name}: slot {i}: {None if e is None else tuple(e.shape)} vs {tuple(want.shape)}"
+        worst = max(worst, (e.detach().float().cpu() - want).abs().max().item())
+    assert worst < tol, f"{name}: written refer_self_attn_emb deviates by {worst}"
+    return worst
 
 
 def loop_case_inputs(case: dict):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import emu_ops
-from golden_cases import (POSEGUIDER_CASES, REFNET_CASES, UNET_CASES, case_config, case_inputs, poseguider_case_inputs,
+from golden_cases import (POSEGUIDER_CASES, REFNET_CASES, UNET_CASES, case_config, case_inputs, check_written_refer_embs, poseguider_case_inputs,
                           refnet_case_inputs)
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -81,6 +81,8 @@ def test_unet_wiring_matches_reference_golden(name, emulated):
     assert got.shape == want.shape and torch.isfinite(got).all()
     err = (got.float() - want).abs().max().item()
     assert err < TOL, f"{name}: |delta|max = {err}"
+    if case.get("refer_self_write"):   # "write" mode: the caller's list now holds every spatial block's self-attention input
+        check_written_refer_embs(name, kw["refer_self_attn_emb"], np.load(os.path.join(GOLDEN, f"reference_unet_{name}.npz")), TOL)
     # second call: cached K/V projections / packed weights must give the same result
     again = model(x, t, encoder_hidden_states=ehs, return_dict=False, **kw)[0]
     assert torch.equal(got, again)

@@ -15,7 +15,7 @@ def test_unet_parity(name, fn):
 
 
 # ---- HIP model vs the outputs of the REFERENCE'S OWN SOURCE (tests/golden/make_reference_goldens.py) -------------------
-from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, UNET_CASES_AT_SIZE_CFG5, case_config, case_inputs  # noqa: E402
+from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, UNET_CASES_AT_SIZE_CFG5, case_config, case_inputs, check_written_refer_embs  # noqa: E402
 
 HIP_GOLDEN_CASES = [n for n, c in UNET_CASES.items() if c["arch"]["block_out_channels"][0] == 320]  # head dims 40 / 80
 # BASELINE-size cases: the 1.42 B-parameter model on the tensors of configs 2 and 3 (B 2, T 13, 64x64 latents) -- every tile
@@ -43,7 +43,8 @@ def test_unet_matches_reference_golden(name):
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # seeded CPU weight generation (1.42 B normals at full width)
     sd = unet3d.init_state_dict(cfg, case["weight_seed"])
     x, t, ehs, kw = case_inputs(case, cfg)
-    want = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_unet_{name}.npz"))["out"]).float()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"reference_unet_{name}.npz"))
+    want = torch.from_numpy(gold["out"]).float()
     model = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16, **case["arch"]).to("cuda")
     del sd
 
@@ -54,10 +55,12 @@ def test_unet_matches_reference_golden(name):
             return [dev(u) for u in v]
         return v
 
-    got = model(x.to("cuda"), t.to("cuda"), encoder_hidden_states=ehs.to("cuda"), return_dict=False,
-                **{k: dev(v) for k, v in kw.items()})[0]
+    dkw = {k: dev(v) for k, v in kw.items()}
+    got = model(x.to("cuda"), t.to("cuda"), encoder_hidden_states=ehs.to("cuda"), return_dict=False, **dkw)[0]
     torch.cuda.synchronize()
     err = (got.float().cpu() - want).abs().max().item()
     print(f"{name}: |delta|max = {err:.3e}, |want|max = {want.abs().max().item():.3f}, rms = {want.pow(2).mean().sqrt().item():.3f}")
     assert torch.isfinite(got).all()
     assert err < 1e-2, f"{name}: |delta|max = {err}"
+    if case.get("refer_self_write"):   # refer_self_attn_emb_mode="write": the list the forward filled
+        print(f"{name}: written refer_self_attn_emb |delta|max = {check_written_refer_embs(name, dkw['refer_self_attn_emb'], gold, 1e-2):.3e}")

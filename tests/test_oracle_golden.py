@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, case_config, case_inputs
+from golden_cases import UNET_CASES, UNET_CASES_AT_SIZE, case_config, case_inputs, check_written_refer_embs
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -34,6 +34,8 @@ def test_oracle_unet_matches_reference(name):
     err = (got - want).abs().max().item()
     print(f"{name}: oracle vs reference |delta|max = {err:.3e}")
     assert err < 2e-4, f"{name}: oracle deviates from the reference by {err}"
+    if case.get("refer_self_write"):   # the list the forward filled ("write" mode) against the reference's (stored as fp16)
+        print(f"{name}: written refer_self_attn_emb |delta|max = {check_written_refer_embs(name, kw['refer_self_attn_emb'], g, 2e-3):.3e}")
     if "cfg_flag_max_abs_diff" in g:
         # the reference's do_classifier_free_guidance recompute (attention.py:319-334) must be dead code
         assert float(g["cfg_flag_max_abs_diff"]) == 0.0
