@@ -821,10 +821,14 @@ struct XAttnArgs {
     int tldk[8], tldv[8], tlen[8], tdiv[8], tmul[8], tadd[8], tk0[8], tgrp[8];
 };
 
-// ONEG: a single softmax group (the text-only cross-attention of `musev`): no group selects, the weight gscale / l is applied to
-// the 4 NDT output accumulators instead of the 4 KT probabilities.
-template <int D, int KT, bool ONEG>
+// G2 (compile-time group layout): 0 = a single softmax group (the text-only cross-attention of `musev`: no group selects, the
+// weight gscale / l goes on the 4 NDT output accumulators instead of the 4 KT probabilities); KT - 1 = two groups, the second one
+// exactly the LAST key tile (text + up to 16 IP-Adapter tokens, `musev_referencenet`: group membership is `t >= G2`, no selects);
+// -1 = any layout of up to three groups (membership from XAttnArgs::tgrp, wave-uniform selects).
+template <int D, int KT, int G2>
 __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
+    constexpr bool ONEG = G2 == 0;
+    constexpr bool TWOG = G2 > 0;
     constexpr int NC32 = D / 32;            // whole 32-deep contraction chunks
     constexpr bool TAIL = (D % 32) != 0;    // + one 16-deep step (d = 40: columns 32..39 | zeros; d = 80: columns 64..79)
     constexpr int NDT = (D + 15) / 16;      // O^T d-tiles
@@ -968,6 +972,17 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             mg[0] = m;
+        } else if constexpr (TWOG) {
+            float m0 = tmax[0], m1 = tmax[G2];
+#pragma unroll
+            for (int t = 1; t < KT; ++t) {
+                if (t < G2) m0 = fmaxf(m0, tmax[t]);
+                else if (t > G2) m1 = fmaxf(m1, tmax[t]);
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
+            mg[0] = fmaxf(m0, __shfl_xor(m0, 32, 64));
+            mg[1] = fmaxf(m1, __shfl_xor(m1, 32, 64));
         } else {
 #pragma unroll
             for (int gi = 0; gi < 3; ++gi) {   // branch-free: an absent group comes out as m = -inf, l = 0 and is never selected
@@ -983,7 +998,9 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             float m = mg[0];
-            if constexpr (!ONEG) {
+            if constexpr (TWOG) {
+                m = t >= G2 ? mg[1] : mg[0];
+            } else if constexpr (!ONEG) {
                 const int gi = p.tgrp[t];
                 m = gi == 0 ? mg[0] : gi == 1 ? mg[1] : mg[2];
             }
@@ -998,6 +1015,19 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
             wg[0] = p.gscale[0] / l;   // a group holds at least one real key: l >= 1
+        } else if constexpr (TWOG) {
+            float l0 = tsum[0], l1 = tsum[G2];
+#pragma unroll
+            for (int t = 1; t < KT; ++t) {
+                if (t < G2) l0 += tsum[t];
+                else if (t > G2) l1 += tsum[t];
+            }
+            l0 += __shfl_xor(l0, 16, 64);
+            l1 += __shfl_xor(l1, 16, 64);
+            l0 += __shfl_xor(l0, 32, 64);
+            l1 += __shfl_xor(l1, 32, 64);
+            wg[0] = p.gscale[0] / l0;
+            wg[1] = p.gscale[1] / l1;
         } else {
 #pragma unroll
             for (int gi = 0; gi < 3; ++gi) {
@@ -1022,7 +1052,9 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
                 const int t = 2 * cc + half;
                 if (t < KT) {
                     float w = 1.0f;
-                    if constexpr (!ONEG) {
+                    if constexpr (TWOG) {
+                        w = t >= G2 ? wg[1] : wg[0];
+                    } else if constexpr (!ONEG) {
                         const int gi = p.tgrp[t];
                         w = gi == 0 ? wg[0] : gi == 1 ? wg[1] : wg[2];
                     }
@@ -1313,15 +1345,15 @@ int attn_num_cus() {
 }
 
 // resident-K/V cross-attention (mv_attn_desc.resident_kv): eligibility is the caller's to check (mv_attention_resident_ok)
-template <int D, int KT, bool ONEG>
+template <int D, int KT, int G2>
 int launch_xattn(const XAttnArgs& a, unsigned grid, int smem, hipStream_t s) {
     static int attr_smem = 0;  // idempotent one-time attribute of this instantiation (the LDS image of V: up to 160 KB)
     if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<D, KT, ONEG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<D, KT, G2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         MV_REQUIRE(e == hipSuccess, "mv_attention_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_smem = smem;
     }
-    hipLaunchKernelGGL((xattn_kernel<D, KT, ONEG>), dim3(grid), dim3(64 * a.heads), smem, s, a);
+    hipLaunchKernelGGL((xattn_kernel<D, KT, G2>), dim3(grid), dim3(64 * a.heads), smem, s, a);
     return MV_OK;
 }
 
@@ -1385,8 +1417,15 @@ int xattn_launch(const mv_attn_desc* d, void* stream) {
     const int smem = kt * 16 * (d->heads * d->d + 8) * 2;
     hipStream_t s = (hipStream_t)stream;
     int rc = MV_ERR_INVALID;
+    // the group layout the kernel is compiled for: one group; two groups with the second one = the last key tile; anything else
+    const bool last_tile_group = a.ngroups == 2 && kt >= 2 && a.tgrp[kt - 1] == 1 && a.tgrp[kt - 2] == 0;
     switch (kt * 100 + d->d) {
-#define MV_XA(KT_, D_) case KT_ * 100 + D_: rc = a.ngroups == 1 ? launch_xattn<D_, KT_, true>(a, (unsigned)blocks, smem, s) : launch_xattn<D_, KT_, false>(a, (unsigned)blocks, smem, s); break;
+#define MV_XA(KT_, D_)                                                                                                  \
+    case KT_ * 100 + D_:                                                                                                \
+        rc = a.ngroups == 1 ? launch_xattn<D_, KT_, 0>(a, (unsigned)blocks, smem, s)                                    \
+             : (last_tile_group && KT_ >= 2) ? launch_xattn<D_, KT_, (KT_ >= 2 ? KT_ - 1 : -1)>(a, (unsigned)blocks, smem, s)  \
+                                             : launch_xattn<D_, KT_, -1>(a, (unsigned)blocks, smem, s);                 \
+        break;
         MV_XA(1, 40) MV_XA(2, 40) MV_XA(3, 40) MV_XA(4, 40) MV_XA(5, 40) MV_XA(6, 40) MV_XA(7, 40) MV_XA(8, 40)
         MV_XA(1, 80) MV_XA(2, 80) MV_XA(3, 80) MV_XA(4, 80) MV_XA(5, 80) MV_XA(6, 80) MV_XA(7, 80) MV_XA(8, 80)
 #undef MV_XA

@@ -545,7 +545,7 @@ def case_gemm_weight_stationary(M=200, N=1280, K=640, seed=880, splitk=0):
                     {"name": "weight-stationary order == default order (conv3x3)", "ok": bool(torch.equal(c0, c1)), "max_abs_err": (c0.float() - c1.float()).abs().max().item()}])
 
 
-def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True, heads=8):
+def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True, heads=8, face=True):
     """the resident-K/V kernel (mv_attn_desc.resident_kv, ops.XATTN_RESIDENT): text cross-attention (two segments of one softmax
     group) [+ 0.7 x IP-Adapter (4 tokens) + 0.4 x FaceID (16 tokens) as further groups] against the fp32 sum of softmax attentions,
     and against the tiled kernel on the same operands"""
@@ -570,7 +570,7 @@ def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True
         segs = ([(ka, va, l1, t, 1, 0), (kb, vb, lk - l1, t, 1, 0)] if d == 40 else [(k, v, lk, t, 1, 0)]) + [(kvi[:, :c], kvi[:, c:], 4, t, 1, 0)]
         gs = ([1.0, None] if d == 40 else [1.0]) + [0.7]
         ref = ref + 0.7 * _attn_ref(q3, kvi[:, :c].reshape(b, 4, c)[bidx], kvi[:, c:].reshape(b, 4, c)[bidx], heads, d, scale)
-        if d == 40:
+        if d == 40 and face:   # (without it: two groups, the second one the last key tile -- the kernel's compile-time layout)
             segs.append((kvf[:, :c], kvf[:, c:], 16, t, 1, 0))
             gs.append(0.4)
             ref = ref + 0.4 * _attn_ref(q3, kvf[:, :c].reshape(b, 16, c)[bidx], kvf[:, c:].reshape(b, 16, c)[bidx], heads, d, scale)
@@ -905,6 +905,7 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("gemm_weight_stationary", _unproven(case_gemm_weight_stationary)),
     ("gemm_weight_stationary_split", _unproven(lambda: case_gemm_weight_stationary(M=300, K=2560, splitk=4, seed=885))),
     ("attention_resident_d40_groups", _unproven(case_attention_resident)),
+    ("attention_resident_d40_text_ip", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=200, groups=True, face=False, seed=99))),
     ("attention_resident_d40_text", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=1000, groups=False, seed=95))),
     ("attention_resident_d80_groups", _unproven(lambda: case_attention_resident(d=80, nb=4, t=2, lq=260, groups=True, seed=91))),
     ("attention_resident_128_keys", _unproven(lambda: case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94))),
@@ -996,6 +997,7 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_groups_l0_half", lambda: case_attention_groups(d=40, nb=13, t=13, lq=4096, seed=78)),   # level-0 cross attention, one CFG half
     ("attention_groups_l1_half", lambda: case_attention_groups(d=80, nb=13, t=13, lq=1024, seed=79)),
     ("attention_resident_l0_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, seed=96))),   # level-0 cross attention, one CFG half
+    ("attention_resident_l0_text_ip_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, face=False, seed=100))),
     ("attention_resident_l0_text_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, groups=False, seed=97))),
     ("attention_resident_l1_half", _unproven(lambda: case_attention_resident(d=80, nb=13, t=13, lq=1024, seed=98))),
     ("groupnorm_l0", lambda: case_groupnorm(n=26, rows=4096, c1=320, seed=230)),

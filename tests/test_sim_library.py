@@ -55,6 +55,7 @@ CASES = {
     "gemm_weight_stationary": "kc.case_gemm_weight_stationary(M=200, N=640, K=256)",
     "gemm_weight_stationary_split": "kc.case_gemm_weight_stationary(M=130, N=640, K=1024, splitk=4, seed=885)",
     "attention_resident": "kc.case_attention_resident(d=40, nb=4, t=2, lq=70)",
+    "attention_resident_text_ip": "kc.case_attention_resident(d=40, nb=4, t=2, lq=70, face=False, seed=99)",
     "attention_resident_d80": "kc.case_attention_resident(d=80, nb=4, t=2, lq=50, groups=True, seed=91)",
     "attention_resident_text_128": "kc.case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94)",
     "attention_resident_5_heads": "kc.case_attention_resident(d=40, nb=3, t=3, lq=17, lk=5, groups=False, seed=93, heads=5)",
@@ -97,7 +98,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_5_heads", "gemm_weight_stationary",
+    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
