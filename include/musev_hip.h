@@ -235,7 +235,8 @@ typedef struct mv_attn_desc {
     /*   registers for the block's lifetime: the text cross-attention (77 keys + image-prompt tokens as further softmax groups),  */
     /*   attention_processor.py:258-300.  Needs mv_attention_resident_ok(d) == 1: d in {40, 80}, heads <= 8, at most 8 key      */
     /*   tiles of 16 over all segments, <= 3 groups, accumulate == 0, heads*d-wide LDS image of V under 160 KB.  0: the tiled    */
-    /*   kernels (any key count).                                                                                               */
+    /*   kernels (any key count).  >= 16: the same with this many query rows per block (a multiple of 16) instead of the launcher's   */
+    /*   choice (whole rounds of the CUs).                                                                                       */
     int32_t resident_kv;
 } mv_attn_desc;
 

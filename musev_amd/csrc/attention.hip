@@ -1412,6 +1412,7 @@ int xattn_launch(const mv_attn_desc* d, void* stream) {
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rt = rt; }
     }
     a.rows_per_block = 16 * best_rt;
+    if (d->resident_kv >= 16) a.rows_per_block = d->resident_kv / 16 * 16;  // the caller's choice (tuning: tools/gpu_xattn_bench.py sweeps it)
     const long blocks = (long)d->nb * ((d->lq + a.rows_per_block - 1) / a.rows_per_block);
     MV_REQUIRE(blocks <= 0x7fffffffL, "mv_attention_f16: grid too large");
     const int smem = kt * 16 * (d->heads * d->d + 8) * 2;

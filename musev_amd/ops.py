@@ -518,7 +518,8 @@ ATTN_GROUPS: bool = os.environ.get("MUSEV_ATTN_GROUPS", "1") == "1"
 # MUSEV_XATTN_RESIDENT=1: attentions over at most 128 keys (the text / image-prompt cross-attention at head dims 40 / 80) run on the
 # resident-K/V kernel (mv_attn_desc.resident_kv: whole query rows per block, q read once, out written once).  Built at the end of
 # round 4 WITHOUT a GPU left to time it: off until a same-box A/B says otherwise (tools/gpu_next_round_first.sh).
-XATTN_RESIDENT: bool = os.environ.get("MUSEV_XATTN_RESIDENT", "0") == "1"
+# (a value >= 16 = that many query rows per block instead of the launcher's choice: a tuning hook)
+XATTN_RESIDENT: int = int(os.environ.get("MUSEV_XATTN_RESIDENT", "0"))
 XATTN_RESIDENT_HITS: int = 0
 
 
@@ -558,7 +559,7 @@ def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int
     if XATTN_RESIDENT and not accumulate and lib.mv_attention_resident_ok(C.byref(ds)):
         global XATTN_RESIDENT_HITS
         XATTN_RESIDENT_HITS += 1
-        ds.resident_kv = 1
+        ds.resident_kv = max(1, int(XATTN_RESIDENT))
     check(lib.mv_attention_f16(C.byref(ds), _stream()), "mv_attention_f16")
     return o
 

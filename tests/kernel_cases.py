@@ -545,7 +545,7 @@ def case_gemm_weight_stationary(M=200, N=1280, K=640, seed=880, splitk=0):
                     {"name": "weight-stationary order == default order (conv3x3)", "ok": bool(torch.equal(c0, c1)), "max_abs_err": (c0.float() - c1.float()).abs().max().item()}])
 
 
-def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True, heads=8, face=True):
+def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True, heads=8, face=True, rows=True):
     """the resident-K/V kernel (mv_attn_desc.resident_kv, ops.XATTN_RESIDENT): text cross-attention (two segments of one softmax
     group) [+ 0.7 x IP-Adapter (4 tokens) + 0.4 x FaceID (16 tokens) as further groups] against the fp32 sum of softmax attentions,
     and against the tiled kernel on the same operands"""
@@ -578,7 +578,7 @@ def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True
         segs, gs = [(k, v, lk, t, 1, 0)], None
     flag, hits = ops.XATTN_RESIDENT, ops.XATTN_RESIDENT_HITS
     try:
-        ops.XATTN_RESIDENT = True
+        ops.XATTN_RESIDENT = rows   # True / 1: the launcher's rows per block; >= 16: that many
         got = ops.attention(q, segs, nb, lq, heads, d, scale, group_scales=gs)
         took = ops.XATTN_RESIDENT_HITS == hits + 1
         ops.XATTN_RESIDENT = False
@@ -908,6 +908,7 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_resident_d40_text_ip", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=200, groups=True, face=False, seed=99))),
     ("attention_resident_d40_text", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=1000, groups=False, seed=95))),
     ("attention_resident_d80_groups", _unproven(lambda: case_attention_resident(d=80, nb=4, t=2, lq=260, groups=True, seed=91))),
+    ("attention_resident_rows_per_block", _unproven(lambda: _all_ok([case_attention_resident(d=40, nb=4, t=2, lq=300, groups=False, seed=101, rows=r) for r in (16, 48, 512)]))),
     ("attention_resident_128_keys", _unproven(lambda: case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94))),
     ("attention_resident_5_heads", _unproven(lambda: case_attention_resident(d=40, nb=3, t=3, lq=17, lk=5, groups=False, seed=93, heads=5))),
     ("attention_spike", case_attention_spike),

@@ -52,27 +52,31 @@ def main():
         outs = [torch.empty_like(qs[0]) for _ in range(2)]
         k = [0]
         res = {}
-        for resident in (False, True):
+        sweep = {}
+        for resident in (0, 1, 64, 128, 256, 512):   # 0: tiled; 1: the launcher's rows per block; else that many rows per block
             ops.XATTN_RESIDENT = resident
             hits = ops.XATTN_RESIDENT_HITS
 
             def run():
                 k[0] += 1
-                ops.attention(qs[k[0] % 4], segs, nb, lq, heads, d, d ** -0.5, out=outs[int(resident)], group_scales=gs)
+                ops.attention(qs[k[0] % 4], segs, nb, lq, heads, d, d ** -0.5, out=outs[int(resident == 1)], group_scales=gs)
             us = timed(run)
             if resident and ops.XATTN_RESIDENT_HITS == hits:
                 print(f"d {d} lq {lq} nb {nb}: the resident kernel did not take the launch")
                 continue
             k[0] = 0
             run()
-            res[resident] = us
+            if resident > 1:
+                sweep[resident] = round(us, 1)
+            else:
+                res[bool(resident)] = us
         torch.cuda.synchronize()
-        ops.XATTN_RESIDENT = False
+        ops.XATTN_RESIDENT = 0
         mb = 2 * nb * lq * c * 2 / 1e6
         diff = (outs[0].float() - outs[1].float()).abs().max().item()
         print(f"cross-attention d {d} rows {nb} x {lq} keys {lk}{' + 4 (group)' if ip else ''}: tiled {res.get(False, float('nan')):7.1f} us "
               f"({mb / res.get(False, math.nan) :5.2f} TB/s)   resident {res.get(True, float('nan')):7.1f} us ({mb / res.get(True, math.nan):5.2f} TB/s)"
-              f"   max |diff| {diff:.2e}")
+              f"   max |diff| {diff:.2e}   rows per block -> us: {sweep}")
     # GroupNorm from producer column statistics, per-frame norm at level 0: fold launch + apply against the fold inside the apply
     n, hw, cch = 13, 4096, 320
     x = rnd((n * hw, cch), 40)
