@@ -175,3 +175,39 @@ def test_unproven_kernel_forms_cannot_fail_the_gpu_suite(monkeypatch):
     import os
     for env, flag in (("MUSEV_XATTN_RESIDENT", ops.XATTN_RESIDENT), ("MUSEV_GN_FOLD_IN_APPLY", ops.GN_FOLD_IN_APPLY), ("MUSEV_GEMM_WEIGHT_STATIONARY", ops.GEMM_WEIGHT_STATIONARY)):
         assert bool(flag) == (os.environ.get(env, "0") not in ("0", ""))
+
+
+def test_choice_is_valid_for_arbitrary_sizes():
+    """fuzz of the host-side chooser (table rows, key buckets, keyed votes, rules, LayerNorm / GEGLU constraints, split clamp): any
+    size gets a configuration of the catalogue whose epilogue can run it, a split that fits the workspace cap, and a consistent
+    statistics layout -- sizes far outside anything the table or the key buckets were measured on included"""
+    import random
+    from musev_amd import _lib
+    lib = _lib.load()
+    n_cfg = lib.mv_gemm_num_configs()
+    tn_even = []
+    for c in range(n_cfg):
+        desc = (C.c_int32 * 5)()
+        assert lib.mv_gemm_config_desc(c, desc) == 0
+        tn_even.append(desc[1] % 128 == 0)   # 128 / 256-column tiles: even TN (the GEGLU gate pairs 16-column tiles)
+    rng = random.Random(5)
+    widths = [64, 128, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 10240]
+    for _ in range(3000):
+        mode = rng.choice([0, 0, 0, 1, 2])
+        frames = rng.choice([1, 2, 5, 9, 13, 17, 26])
+        side = rng.choice([4, 5, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128])
+        px = side * side
+        M = frames * px
+        N = rng.choice(widths)
+        geglu = int(mode == 0 and N % 256 == 0 and rng.random() < 0.25)
+        cin = rng.choice([64, 128, 320, 640, 1280, 2560])
+        K = cin * (9 if mode == 1 else 3 if mode == 2 else 1)
+        ln = int(mode == 0 and not geglu and rng.random() < 0.3)
+        geom = side if mode == 1 else (frames, px)
+        if M * cin * 2 >= (1 << 31) or M * N * 2 >= (1 << 31):
+            continue   # an operand of 2 GiB or more is refused by the library (32-bit descriptor offsets): the caller splits the call
+        cfg, ns = _lib_choice(lib, _lib.GemmDesc, mode, M, N, K, geglu, ln, geom)
+        assert 0 <= cfg < n_cfg, (mode, M, N, K, geglu, ln, cfg)
+        assert not geglu or tn_even[cfg], (mode, M, N, K, "GEGLU on an odd-TN tile", cfg)
+        nk = (K + 63) // 64
+        assert 1 <= ns <= max(1, nk) and (ns == 1 or (ns * M * N * 4 <= (64 << 20) and not geglu and not ln)), (mode, M, N, K, geglu, ln, cfg, ns)
