@@ -99,8 +99,9 @@ typedef struct mv_gemm_desc {
     void* c_lo;              /* fp16 [M][ldc] or NULL (no carry)                                                                   */
     /* workgroup -> tile order (ABI 8).  0: m-major in groups of 8 m-tiles (an XCD's id range = a few m-tiles x all n-tiles).        */
     /* 1: ALLOW the weight-stationary order -- an XCD's id range = a few n-tiles x ALL m-tiles (and all K slices): each XCD streams */
-    /*    only its share of the weight matrix -- taken where N*K >= 2 * M*(c1 + c2), i.e. on the small-M levels.  Results are       */
-    /*    identical (every tile is still reduced over K in the same order by one block).                                           */
+    /*    only its share of the weight matrix -- taken where the fetch model (distinct A row blocks + distinct weight column       */
+    /*    blocks per XCD) says the XCDs fetch at least 5 % less that way (mv_gemm_weight_stationary reports it): the small-M       */
+    /*    levels.  Results are identical (every tile is still reduced over K in the same order by one block).                      */
     int32_t tile_order;
 } mv_gemm_desc;
 
@@ -110,6 +111,9 @@ typedef struct mv_gemm_desc {
 int mv_gemm_f16(const mv_gemm_desc* d, void* stream);
 /* bytes of workspace mv_gemm_f16 needs for this descriptor (0 = none; -1 = invalid descriptor, see mv_last_error) */
 int64_t mv_gemm_workspace_bytes(const mv_gemm_desc* d);
+/* 1 if mv_gemm_f16 would run this descriptor in the weight-stationary workgroup order (tile_order = 1 and the fetch model prefers
+ * it), 0 if not, -1 = invalid descriptor: introspection, launches nothing */
+int mv_gemm_weight_stationary(const mv_gemm_desc* d);
 /* the (tile configuration id, K slices) mv_gemm_f16 would use for this descriptor: introspection for tuners and tests */
 int mv_gemm_choice(const mv_gemm_desc* d, int32_t* cfg, int32_t* nsplit);
 /* output statistics this descriptor's launch can emit (d->colstats itself is ignored here): *col_rows_per_tile = rows per

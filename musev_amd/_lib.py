@@ -79,6 +79,7 @@ SIGNATURES = {
     "mv_ffn_geglu_f16": (_i32, [C.POINTER(FfnDesc), _vp]),
     "mv_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
     "mv_gemm_choice": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
+    "mv_gemm_weight_stationary": (_i32, [C.POINTER(GemmDesc)]),
     "mv_gemm_stats_layout": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
     "mv_gemm_num_configs": (_i32, []),
     "mv_gemm_config_desc": (_i32, [_i32, _vp]),

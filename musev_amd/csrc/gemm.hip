@@ -955,6 +955,35 @@ int mv_num_cus() {
     return n;
 }
 
+// What the 8 XCDs fetch for one K slice of a launch under a workgroup -> tile order: workgroup b runs on XCD b % 8 and produces
+// the tile mv_tile_order gives it; an XCD fetches every DISTINCT A row block and every DISTINCT weight column block its workgroups
+// touch once (they are co-resident and walk K together).  tools/gemm_traffic_model.py holds this model against the per-problem PMC
+// bytes of profiles/r04z_pmc_by_problem.log: within 5 % on the small-M levels (every XCD streams the whole weight matrix there:
+// 3.4-8.6 x the algorithmic bytes).  The weight-stationary (n-major) order is taken where it fetches at least 5 % less.
+inline double order_fetch_bytes(int tiles_m, int tiles_n, int group, double a_tile, double w_tile) {
+    const int nwg = tiles_m * tiles_n;
+    double total = 0.0;
+    for (int x = 0; x < 8; ++x) {
+        // the ids of XCD x are a contiguous logical range (mv_xcd_remap): count the distinct tiles by walking it in order
+        unsigned long long seen_m[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seen_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // bitmaps: up to 512 tiles per axis
+        int nm = 0, nn = 0;
+        for (int b = x; b < nwg; b += 8) {
+            int tm, tn;
+            mv_tile_order(mv_xcd_remap(b, nwg), tiles_m, tiles_n, group, &tm, &tn);
+            if (!((seen_m[(tm >> 6) & 7] >> (tm & 63)) & 1ull)) { seen_m[(tm >> 6) & 7] |= 1ull << (tm & 63); ++nm; }
+            if (!((seen_n[(tn >> 6) & 7] >> (tn & 63)) & 1ull)) { seen_n[(tn >> 6) & 7] |= 1ull << (tn & 63); ++nn; }
+        }
+        total += nm * a_tile + nn * w_tile;
+    }
+    return total;
+}
+inline bool ws_model_prefers(long M, int N, int K, int cin, int bm, int bn) {
+    const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (N + bn - 1) / bn;
+    if (tiles_m > 512 || tiles_n > 512 || (long)tiles_m * tiles_n > 8192) return false;  // large grids: the activations dominate anyway
+    const double a_tile = (double)(M < bm ? M : bm) * cin * 2.0, w_tile = (double)(N < bn ? N : bn) * K * 2.0;
+    return order_fetch_bytes(tiles_m, tiles_n, -1, a_tile, w_tile) < 0.95 * order_fetch_bytes(tiles_m, tiles_n, MV_TILE_GROUP, a_tile, w_tile);
+}
+
 template <int MODE, int TM, int TN, int WGM, int WGN, int SCHED, bool LNF = false, bool CARRY = false>
 int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
@@ -968,6 +997,7 @@ int launch_cfg2s(const GemmArgs2& a0, hipStream_t stream) {
     GemmArgs2 a = a0;
     a.g.tiles_m = (int)((a.g.M + BM - 1) / BM);
     a.g.tiles_n = (a.g.N + BN - 1) / BN;
+    if (a.g.n_major) a.g.n_major = ws_model_prefers(a.g.M, a.g.N, a.g.K, a.g.cin, BM, BN) ? 1 : 0;  // (allowed -> taken)
     const int nk = (a.g.K + 63) / 64;
     a.g.kt_per_split = (nk + a.g.nsplit - 1) / a.g.nsplit;
     static bool attr_done = false;  // idempotent one-time attribute of this instantiation (not tuning state)
@@ -1292,10 +1322,9 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     a.t = d->t; a.hw = d->hw;
     a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.act = d->act; a.geglu = d->geglu;
     a.tiles_m = a.tiles_n = 0;
-    // weight-stationary tile order (mv_gemm_desc.tile_order = 1 ALLOWS it; taken where the weight matrix is at least twice the
-    // activations it multiplies -- the 16 x 16 / 8 x 8-latent levels, where every XCD otherwise streams the whole matrix through
-    // its 4 MB L2: 3.4-8.6 x the algorithmic bytes, profiles/r04z_pmc_by_problem.log)
-    a.n_major = (d->tile_order == 1 && (long)d->N * d->K >= 2L * d->M * cin) ? 1 : 0;
+    // weight-stationary tile order: mv_gemm_desc.tile_order = 1 ALLOWS it; the launcher takes it where the traffic model says the
+    // XCDs fetch less that way (ws_model_prefers, once the tile shape is known)
+    a.n_major = d->tile_order == 1 ? 1 : 0;
     a.nsplit = 1; a.kt_per_split = 0; a.ws = nullptr;
     a.ln_colsum = d->ln_colsum; a.ln_colbias = d->ln_colbias; a.ln_eps = d->ln_eps;
     a.colstats = nullptr;  // (set by mv_gemm_f16 once the choice is known to support it)
@@ -1355,6 +1384,15 @@ extern "C" int mv_gemm_choice(const mv_gemm_desc* d, int32_t* cfg, int32_t* nspl
     *cfg = ch.cfg;
     *nsplit = ch.nsplit;
     return MV_OK;
+}
+
+extern "C" int mv_gemm_weight_stationary(const mv_gemm_desc* d) {
+    GemmArgs2 b;
+    if (gemm_prepare(d, b, "mv_gemm_weight_stationary") != MV_OK) return -1;
+    if (!b.g.n_major) return 0;
+    GemmChoice ch = choose_config(d->mode, b.g, d->cfg, d->splitk);
+    const GemmCfgDesc& c = kGemmCfgs[ch.cfg];
+    return ws_model_prefers(b.g.M, b.g.N, b.g.K, b.g.cin, 16 * c.tm * c.wgm, 16 * c.tn * c.wgn) ? 1 : 0;
 }
 
 // output statistics a launch can emit: the staged (16-byte) epilogue of an unsplit, non-GEGLU launch
