@@ -52,10 +52,10 @@ CASES = {
     "layernorm": "kc.case_layernorm(rows=99, c=64)",
     "attention_self": "kc.case_attention_self(d=40, b=1, t=2, lq=70, cond_idx=1)",
     "attention_groups": "kc.case_attention_groups(d=40, nb=4, t=2, lq=70)",
-    "gemm_weight_stationary": "kc.case_gemm_weight_stationary(M=200, N=640, K=256)",
+    "gemm_weight_stationary": "kc.case_gemm_weight_stationary(M=200, N=640, K=128)",
     "gemm_weight_stationary_split": "kc.case_gemm_weight_stationary(M=130, N=640, K=1024, splitk=4, seed=885)",
-    "attention_resident": "kc.case_attention_resident(d=40, nb=4, t=2, lq=70)",
-    "attention_resident_text_ip": "kc.case_attention_resident(d=40, nb=4, t=2, lq=70, face=False, seed=99)",
+    "attention_resident": "kc.case_attention_resident(d=40, nb=2, t=2, lq=36)",
+    "attention_resident_text_ip": "kc.case_attention_resident(d=40, nb=2, t=2, lq=36, face=False, seed=99)",
     "attention_resident_rows_per_block": "kc._all_ok([kc.case_attention_resident(d=40, nb=2, t=2, lq=70, groups=False, seed=101, rows=r) for r in (16, 48, 512)])",
     "attention_resident_d80": "kc.case_attention_resident(d=80, nb=4, t=2, lq=50, groups=True, seed=91)",
     "attention_resident_text_128": "kc.case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94)",
