@@ -141,20 +141,31 @@ def measured_traffic(workload: str):
     FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command, gfx950 read correction x2 applied by
     tools/pmc_summary.py) and committed as profiles/hbm_traffic.json -- a counter pass cannot run inside the timed
     process.  The file records the hash of the kernel sources it was measured on: a measurement of OTHER code is not
-    reported (None), so `traffic` is reproducible from profiles/ or absent."""
+    reported (None), so `traffic` is reproducible from profiles/ or absent -- except for a build the file itself declares as
+    differing only by code the default path does not run (`carried_over_to`; `traffic_source` then starts with CARRIED OVER)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         ent = rec.get(workload, {})
         fam = ent.get("gemm")
-        if fam is None or ent.get("kernel_source_hash") != kernel_source_hash():
-            return None, (f"profiles/hbm_traffic.json holds no PMC measurement of this build (kernel sources {kernel_source_hash()}, "
+        here = kernel_source_hash()
+        carried = None
+        if fam is not None and ent.get("kernel_source_hash") != here:
+            # a build that differs from the measured one ONLY by code the default path does not run may be declared in the file
+            # (carried_over_to: its source hash + the reason); the bench line then says so in traffic_source.  Anything else: None.
+            carried = next((c for c in ent.get("carried_over_to", []) if c.get("kernel_source_hash") == here), None)
+        if fam is None or (ent.get("kernel_source_hash") != here and carried is None):
+            return None, (f"profiles/hbm_traffic.json holds no PMC measurement of this build (kernel sources {here}, "
                           f"file: {ent.get('kernel_source_hash')})")
         per_step = ent.get("gemm_family", {}).get("hbm_bytes_per_step")
         if per_step is None:  # (a round-3 summary: split-K reduces counted as gemm dispatches over 2 profiled steps)
             per_step = fam["hbm_bytes_per_launch"] * fam["launches"] / 2.0
-        return per_step, ent.get("source")
+        src = ent.get("source")
+        if carried is not None:
+            src = (f"CARRIED OVER from the build with kernel sources {ent.get('kernel_source_hash')} (not re-measured on {here}): "
+                   f"{carried.get('reason')} | {src}")
+        return per_step, src
     except (OSError, ValueError, KeyError):
         return None, None
 
