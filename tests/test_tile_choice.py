@@ -211,3 +211,33 @@ def test_choice_is_valid_for_arbitrary_sizes():
         assert not geglu or tn_even[cfg], (mode, M, N, K, "GEGLU on an odd-TN tile", cfg)
         nk = (K + 63) // 64
         assert 1 <= ns <= max(1, nk) and (ns == 1 or (ns * M * N * 4 <= (64 << 20) and not geglu and not ln)), (mode, M, N, K, geglu, ln, cfg, ns)
+
+
+def test_weight_stationary_decision_is_the_traffic_models():
+    """mv_gemm_weight_stationary (csrc/gemm.hip:ws_model_prefers) against the Python side of tools/gemm_traffic_model.py -- the model that
+    is held against the measured per-problem PMC bytes: distinct A row blocks + distinct weight column blocks per XCD under either
+    order, the n-major order taken where it fetches at least 5 % less"""
+    import numpy as np
+    import gemm_traffic_model as tm
+    from musev_amd import _lib
+    lib = _lib.load()
+    configs = json.load(open(os.path.join(ROOT, "profiles", "r04t_musev512_gemm_tune.json")))["configs"]
+    took = 0
+    for mode, M, N, K, cfg in (("conv3x3", 832, 1280, 11520, 15), ("conv3x3", 3328, 1280, 11520, 15), ("tconv3", 832, 1280, 3840, 3),
+                               ("linear", 3328, 1280, 5120, 0), ("linear", 3328, 10240, 1280, 2), ("linear", 3328, 3840, 1280, 15),
+                               ("linear", 13312, 640, 640, 15), ("conv3x3", 13312, 640, 5760, 11), ("linear", 832, 1280, 5120, 1),
+                               ("linear", 53248, 320, 320, 6), ("conv3x3", 13312, 1280, 11520, 6), ("tconv3", 3328, 1280, 3840, 0)):
+        bm, bn = configs[cfg][0], configs[cfg][1]
+        cin = K // tm.TAPS[mode]
+        tiles_m, tiles_n = -(-M // bm), -(-N // bn)
+
+        def fetch(group):
+            a, b = tm.tile_maps(lib, tiles_m, tiles_n, group)
+            ids = np.arange(tiles_m * tiles_n)
+            return sum(len(np.unique(a[ids % 8 == x])) * min(bm, M) * cin * 2 + len(np.unique(b[ids % 8 == x])) * min(bn, N) * K * 2
+                       for x in range(8) if (ids % 8 == x).any())
+        want = fetch(-1) < 0.95 * fetch(8)
+        got = tm.ws_applies(lib, dict(mode=mode, M=M, N=N, K=K, epilogue="geglu" if (mode, N) == ("linear", 10240) else "-", cfg=cfg, nsplit=1))
+        assert got == want, (mode, M, N, K, cfg, got, want)
+        took += got
+    assert 3 <= took <= 10, took
