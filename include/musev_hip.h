@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 8
+#define MV_ABI_VERSION 9
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -185,14 +185,6 @@ int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, 
                         const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
                         const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, int32_t nsplit, float* stat,
                         const void* x1_lo, void* y_lo, void* stream);
-/* the same, with variant bit 0: the fold runs INSIDE the apply pass (one launch instead of two; every block folds its item's groups
- * itself, bit-identical to the fold launch) wherever a group has at most 2048 (row tile, channel) pairs -- the per-frame norms;
- * larger folds (the temporal norms, statistics over T*H*W) keep the fold launch.  variant 0 == mv_groupnorm_cs_f16. */
-int mv_groupnorm_cs_f16_var(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
-                            int64_t n_items, int64_t rows, int32_t num_groups, float eps,
-                            const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
-                            const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, int32_t nsplit, float* stat,
-                            const void* x1_lo, void* y_lo, int32_t variant, void* stream);
 /* scratch size (in floats) of `partial` for the call above */
 int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_groups, int32_t nsplit);
 int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c);

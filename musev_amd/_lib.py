@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "l
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 8
+MV_ABI_VERSION = 9
 
 
 class MuseVHipError(RuntimeError):
@@ -88,8 +88,6 @@ SIGNATURES = {
                                 _vp, _i32, _vp, _vp, _vp, _vp]),
     "mv_groupnorm_cs_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
                             _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "mv_groupnorm_cs_f16_var": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
-                                _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mv_groupnorm_partial_floats": (_i64, [_i64, _i32, _i32]),
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),

@@ -867,8 +867,8 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
             *reinterpret_cast<uint4*>(lds + (long)row * vrs + slot * 8) = v;
         }
     }
-    // ---- prologue 2: this head's K fragments, straight from global, pre-multiplied by scale * log2(e) (once per block: the
-    // query fragments then go into the matrix pipe as loaded, the scores come out in the log2 domain) ----
+    // ---- prologue 2: this head's K fragments, straight from global, as loaded (scale * log2(e) goes on the fp32 scores, inside the
+    // fused multiply-add that subtracts the row maximum: no fp16 rounding of a pre-scaled operand, no conversions here) ----
     half8v kf[KT][NC32 > 0 ? NC32 : 1];
     half4v kt16[KT];
     int nvalid[KT];   // valid keys of the tile (16 except a segment's last tile)
@@ -882,20 +882,12 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
 #pragma unroll
         for (int c = 0; c < NC32; ++c) {
             kf[t][c] = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const half8v raw = *reinterpret_cast<const half8v*>(krow + 32 * c + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[t][c][e] = (half_t)((float)raw[e] * p.scale_log2e);
-            }
+            if (ok) kf[t][c] = *reinterpret_cast<const half8v*>(krow + 32 * c + 8 * g);
         }
         kt16[t] = half4v{0, 0, 0, 0};
         if constexpr (TAIL) {
             const int dcol = 32 * NC32 + 4 * g;
-            if (ok && dcol < D) {
-                const half4v raw = *reinterpret_cast<const half4v*>(krow + dcol);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) kt16[t][e] = (half_t)((float)raw[e] * p.scale_log2e);
-            }
+            if (ok && dcol < D) kt16[t] = *reinterpret_cast<const half4v*>(krow + dcol);
         }
     }
     __syncthreads();
@@ -945,14 +937,21 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
         const half4v qt16 = qtraw;
         if (r0 + 16 < r_end) fetch_q(r0 + 16);
 
-        // acc[t][r] = S[q = l15][key 16 t + 4 g + r]  (log2 domain)
+        // acc[t][r] = S[q = l15][key 16 t + 4 g + r]  (raw dot products: the scale goes into the exponential's fused multiply-add)
         float4v acc[KT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NC32; ++c) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][c], qf[c], acc[t], 0, 0, 0);
-            if constexpr (TAIL) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(kt16[t], qt16, acc[t], 0, 0, 0);
+            // the 16-deep tail goes into its OWN accumulator and is added on the vector ALU: a v_mfma_f32_16x16x16_f16 issued right
+            // behind the v_mfma_f32_16x16x32_f16 whose result it accumulates onto read a half-written accumulator on the MI355X
+            // (profiles/r05d_debug_dump.log: registers 0 and 1 of the 4-register result wrong, run-to-run and wave-to-wave different,
+            // right whenever the SIMD's other wave happened to issue in between) -- hipcc inserts no wait states between the two
+            if constexpr (TAIL) {
+                const float4v tl = __builtin_amdgcn_mfma_f32_16x16x16f16(kt16[t], qt16, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc[t] += tl;
+            }
             if (nvalid[t] < 16) {  // wave-uniform: a segment's last tile masks its missing keys
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1004,8 +1003,9 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
                 const int gi = p.tgrp[t];
                 m = gi == 0 ? mg[0] : gi == 1 ? mg[1] : mg[2];
             }
+            const float nms = -m * p.scale_log2e;   // (scale > 0: the maximum of the raw scores is the maximum of the scaled ones)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r] - m);
+            for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_amdgcn_exp2f(fmaf(acc[t][r], p.scale_log2e, nms));
             tsum[t] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
         }
         if constexpr (ONEG) {

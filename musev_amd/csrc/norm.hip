@@ -39,7 +39,6 @@ struct GnArgs {
     // two-fp16 carry through the apply pass (single source): x = x1 + x1_lo in fp32, y = fp16(v), y_lo = fp16(v - y)
     const half_t* x1_lo;
     half_t* y_lo;
-    int fold_threads;  // gn_apply_kernel<true>: the block size the fold launch would have had (64 or 256)
 };
 
 __device__ __forceinline__ const half_t* gn_src(const GnArgs& a, long item, long row, int o) {
@@ -219,13 +218,6 @@ __global__ void gn_finalize_cs_kernel(const GnArgs a) {
     }
 }
 
-// FOLD (mv_groupnorm_cs_f16_var, variant bit 0): the fold of the column statistics runs INSIDE the apply pass -- every block folds
-// the (few) pairs of its item's groups itself and the gn_finalize_cs launch (pure launch + dependent-load latency: 0.73 of its
-// cycles in waits, profiles/r04z_sq_counters.log) disappears.  Bit-identical to the fold kernel by construction: a full wave plays
-// the NV = fold_threads / 64 waves of the fold block (lane l = threads l, l + 64, ... of it: the same pairs in the same order, the
-// same xor tree per played wave, the waves folded in order); the launcher takes this form only where the fold block would have
-// had 64 or 256 threads (<= 2048 pairs per group: every per-frame norm of the UNet; the temporal norms keep the fold launch).
-template <bool FOLD>
 __global__ void gn_apply_kernel(const GnArgs a) {
     const int C = a.oc * 8;
     const int o = threadIdx.x % a.oc, rl = threadIdx.x / a.oc;
@@ -233,53 +225,6 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     const long per = (a.rows + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * per;
     const long r1 = (r0 + per < a.rows) ? r0 + per : a.rows;
-    __shared__ float sstat[FOLD ? 64 : 1][2];
-    if constexpr (FOLD) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nfull = blockDim.x >> 6;  // a trailing partial wave sits out
-        const int cpg = C / a.groups;
-        const int nv = a.fold_threads >> 6;  // 1 or 4
-        if (wave < nfull) {
-            for (int gI = wave; gI < a.groups; gI += nfull) {
-                const int c0 = gI * cpg;
-                double s2 = 0.0, ss2 = 0.0;
-                // the played waves one after the other (two doubles live, not eight: the apply loop keeps its occupancy)
-#pragma unroll 1
-                for (int v = 0; v < nv; ++v) {
-                    double ts = 0.0, tss = 0.0;
-#pragma unroll
-                    for (int src = 0; src < 2; ++src) {
-                        const float* cs = src ? a.cs2 : a.cs1;
-                        const int cb = src ? a.c1 : 0, cn = src ? a.c2 : a.c1;
-                        const int lo = c0 > cb ? c0 : cb, hi = (c0 + cpg < cb + cn) ? c0 + cpg : cb + cn;
-                        if (!cs || lo >= hi) continue;
-                        const int rpt = src ? a.rpt2 : a.rpt1;
-                        const int tiles = (int)(a.rows / rpt);   // (32-bit index arithmetic: the launcher bounds the pairs per group)
-                        const int w = hi - lo;
-                        const float* base = cs + (item * tiles * cn + (lo - cb)) * 2;
-                        const int total = tiles * w;
-                        for (int k = v * 64 + lane; k < total; k += a.fold_threads) {
-                            const int tile = k / w;
-                            const int c = k - tile * w;
-                            const float2v x = *reinterpret_cast<const float2v*>(base + (tile * cn + c) * 2);
-                            ts += (double)x[0];
-                            tss += (double)x[1];
-                        }
-                    }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        ts += __shfl_xor(ts, off, 64);
-                        tss += __shfl_xor(tss, off, 64);
-                    }
-                    s2 += ts;   // the fold block's `for (w2 ...) s += red[w2]`: waves in order, starting from 0.0
-                    ss2 += tss;
-                }
-                if (lane == 0) {
-                    gn_emit_stat(s2, ss2, cpg, a.rows, a.eps, sstat[gI][0], sstat[gI][1]);
-                }
-            }
-        }
-        __syncthreads();
-    }
     float sc[8], sh[8];
     {
         const int cpg = C / a.groups;
@@ -288,7 +233,7 @@ __global__ void gn_apply_kernel(const GnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int gI = (o * 8 + j) / cpg;  // groups of 30 / 60 channels straddle octets
-            const float* st = FOLD ? &sstat[gI][0] : a.stat + (item * a.groups + gI) * 2;
+            const float* st = a.stat + (item * a.groups + gI) * 2;
             sc[j] = st[1] * (float)gm[j];
             sh[j] = (float)bt[j] - st[0] * sc[j];
         }
@@ -580,7 +525,7 @@ namespace {
 int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2, int64_t n_items,
               int64_t rows, int32_t num_groups, float eps, const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
               float* partial, int32_t nsplit, float* stat, const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2,
-              const void* x1_lo, void* y_lo, int variant, void* stream) {
+              const void* x1_lo, void* y_lo, void* stream) {
     MV_REQUIRE(x1 && y && gamma && beta && stat && (partial || cs1), "%s: null pointer", who);
     MV_REQUIRE((!x1_lo && !y_lo) || !x2, "%s: the carried form (x1_lo / y_lo) takes one source", who);
     MV_REQUIRE(((reinterpret_cast<uintptr_t>(x1_lo) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0, "%s: x1_lo / y_lo must be 16-byte aligned", who);
@@ -612,7 +557,6 @@ int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32
     a.groups = num_groups; a.eps = eps;
     a.cs1 = cs1; a.cs2 = c2 ? cs2 : nullptr; a.rpt1 = rpt1; a.rpt2 = rpt2;
     a.x1_lo = (const half_t*)x1_lo; a.y_lo = (half_t*)y_lo;
-    a.fold_threads = 0;
     hipStream_t s = (hipStream_t)stream;
     if (!x1_lo && !y_lo) {   // small slabs: one launch (see gn_small_kernel); the carried form always takes the apply pass
         const int cpg = C / num_groups;
@@ -636,12 +580,6 @@ int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32
         const int cpg = C / num_groups;
         const long per_block = (rows / rpt1) * (long)cpg;
         const int threads = per_block <= 512 ? 64 : per_block <= 2048 ? 256 : 1024;
-        if ((variant & 1) && threads <= 256 && num_groups <= 64 && bs >= 64 && rows / (rpt2 > 0 && c2 ? (rpt2 < rpt1 ? rpt2 : rpt1) : rpt1) * (long)C < 0x7fffffffL) {  // the fold rides in the apply pass
-            a.fold_threads = threads;
-            hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
-            MV_CHECK_LAUNCH("mv_groupnorm_cs_f16(fold + apply)");
-            return MV_OK;
-        }
         hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3((unsigned)pairs), dim3(threads), 0, s, a);
         MV_CHECK_LAUNCH("mv_groupnorm_cs_f16(fold)");
     } else {
@@ -651,7 +589,7 @@ int gn_launch(const char* who, const void* x1, const void* x2, int32_t c1, int32
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a);
         MV_CHECK_LAUNCH("mv_groupnorm_f16(finalize)");
     }
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, (unsigned)n_items), dim3(bs), 0, s, a);
     MV_CHECK_LAUNCH("mv_groupnorm_f16(apply)");
     return MV_OK;
 }
@@ -663,7 +601,7 @@ extern "C" int mv_groupnorm_f16(const void* x1, const void* x2, int32_t c1, int3
                                 float* stat, const void* x1_lo, void* y_lo, void* stream) {
     MV_REQUIRE(partial, "mv_groupnorm_f16: null pointer");
     return gn_launch("mv_groupnorm_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, partial,
-                     nsplit, stat, nullptr, 0, nullptr, 0, x1_lo, y_lo, 0, stream);
+                     nsplit, stat, nullptr, 0, nullptr, 0, x1_lo, y_lo, stream);
 }
 
 extern "C" int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
@@ -672,18 +610,7 @@ extern "C" int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, i
                                    const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, const void* x1_lo, void* y_lo, void* stream) {
     MV_REQUIRE(cs1, "mv_groupnorm_cs_f16: null column statistics");
     return gn_launch("mv_groupnorm_cs_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, nullptr,
-                     nsplit, stat, cs1, rpt1, cs2, rpt2, x1_lo, y_lo, 0, stream);
-}
-
-extern "C" int mv_groupnorm_cs_f16_var(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t ld1, int32_t ld2,
-                                       int64_t n_items, int64_t rows, int32_t num_groups, float eps, const void* gamma,
-                                       const void* beta, int32_t silu, void* y, int32_t ldy, const float* cs1, int32_t rpt1,
-                                       const float* cs2, int32_t rpt2, int32_t nsplit, float* stat, const void* x1_lo, void* y_lo,
-                                       int32_t variant, void* stream) {
-    MV_REQUIRE(cs1, "mv_groupnorm_cs_f16_var: null column statistics");
-    MV_REQUIRE(variant >= 0 && variant <= 1, "mv_groupnorm_cs_f16_var: unknown variant %d", variant);
-    return gn_launch("mv_groupnorm_cs_f16_var", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, nullptr,
-                     nsplit, stat, cs1, rpt1, cs2, rpt2, x1_lo, y_lo, variant, stream);
+                     nsplit, stat, cs1, rpt1, cs2, rpt2, x1_lo, y_lo, stream);
 }
 
 extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t c,

@@ -316,7 +316,7 @@ class UNet3DConditionModel(HipModule):
         if sample.ndim != 5:
             raise ValueError(f"sample must be b c t h w, got ndim={sample.ndim}")
         b, _, t, h, w = sample.shape
-        if sample.dtype == torch.float32 and ops.CARRY and pose_guider_emb is None:
+        if sample.dtype == torch.float32 and ops.CARRY and pose_guider_emb is None and 18 * self.conv_in.in_channels <= 128:
             # an fp32 sample enters conv_in unrounded, as two fp16 halves (what the denoise loop does through window_gather)
             x_rows = ops.split_hi_lo(sample.permute(0, 2, 3, 4, 1).reshape(-1, sample.shape[1]))
         else:

@@ -43,27 +43,28 @@ GEMM_RECORD: Optional[list] = None
 # itself keeps no such state -- the choice travels in each call's descriptor).  Read once at import:
 #   MUSEV_GEMM_CFG    -1 = measured per-shape table, then rules (default); -2 = rules only; >= 0 = that catalogue id
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
+#   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
+#                      COLSTATS, CARRY, FFN_FUSED, LN_FOLD, ATTN_GROUPS, XATTN_RESIDENT, GEMM_WEIGHT_STATIONARY); applied at the
+#                      bottom of this file
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
-# MUSEV_GEMM_WEIGHT_STATIONARY=1: mv_gemm_desc.tile_order = 1 -- on the small-M levels (N*K >= 2 M*cin) an XCD's workgroups cover a few
-# n-tiles x all m-tiles, so each XCD streams 1/8 of the weight matrix instead of all of it (the 3.4-8.6 x traffic ratios of
-# profiles/r04z_pmc_by_problem.log).  Same results bit for bit.  Built at the end of round 4 WITHOUT a GPU left to time it: off.
-GEMM_WEIGHT_STATIONARY: bool = os.environ.get("MUSEV_GEMM_WEIGHT_STATIONARY", "0") == "1"
+# mv_gemm_desc.tile_order = 1: the library MAY take the weight-stationary workgroup order -- an XCD's workgroups cover a few n-tiles x
+# all m-tiles, so each XCD streams 1/8 of the weight matrix instead of all of it -- and takes it where its fetch model says the XCDs
+# fetch >= 5 % less (the small grids of the 8 x 8-latent level under a K split).  Same results bit for bit.  Round 5, same-box
+# (profiles/r05f_ab_config2.log): time-neutral in the two-stream step (52.33 / 52.32 against 52.30 / 52.13 / 52.52); kept on for the
+# HBM bytes it saves.
+GEMM_WEIGHT_STATIONARY: bool = True
 
 
-# Producer-side GroupNorm statistics (env knob for A/B runs: MUSEV_COLSTATS=0 keeps the statistics pass of mv_groupnorm_f16):
+# Producer-side GroupNorm statistics (A/B: MUSEV_OPS="COLSTATS=0" keeps the statistics pass of mv_groupnorm_f16):
 # the convolutions / proj_out launches whose output a GroupNorm reads next also emit per-row-tile column sums from their epilogue
 # (mv_gemm_desc.colstats); the buffer rides on the output tensor OBJECT (`_mv_colstats`), so a view, a copy or any tensor produced
 # some other way simply has none and `groupnorm` takes its own statistics pass.
-COLSTATS: bool = os.environ.get("MUSEV_COLSTATS", "1") == "1"
+COLSTATS: bool = True
 COLSTATS_HITS: int = 0   # GroupNorm calls served from producer statistics (tests / reports)
-# MUSEV_GN_FOLD_IN_APPLY=1: the fold of the column statistics runs inside the apply pass (one launch per GroupNorm instead of two
-# wherever a group has <= 2048 (row tile, channel) pairs: mv_groupnorm_cs_f16_var; bit-identical to the fold launch).  Built at the
-# end of round 4 WITHOUT a GPU left to time it: off until a same-box A/B says otherwise (tools/gpu_next_round_first.sh).
-GN_FOLD_IN_APPLY: bool = os.environ.get("MUSEV_GN_FOLD_IN_APPLY", "0") == "1"
 
 
-# Two-fp16 carry on the identity path of the residual stream (env knob for A/B runs: MUSEV_CARRY=0 switches it off).  The fp16
+# Two-fp16 carry on the identity path of the residual stream (A/B: MUSEV_OPS="CARRY=0" switches it off).  The fp16
 # rounding of the stream at every `x + f(x)` is the largest single contribution to the forward's error against the fp32 reference
 # (profiles/r04a_attribution.log: 5.2e-3 of 5.6e-3 |delta eps|max alone) -- and it sits at level 0, where the network's largest values
 # live.  With the carry the epilogue of a stream-producing launch (conv_in, ResnetBlock2D.conv2 + shortcut, the temporal convolution's
@@ -72,8 +73,8 @@ GN_FOLD_IN_APPLY: bool = os.environ.get("MUSEV_GN_FOLD_IN_APPLY", "0") == "1"
 # again (the lo tensor rides on the hi tensor OBJECT as `_mv_lo`, like the column statistics: a view / copy / tensor produced some
 # other way has none).  Applied where the stream is at most CARRY_MAX_C channels wide (level 0 of SD-1.5: 320; the deeper levels add
 # nothing measurable, profiles/r04b_attribution_carry.log).
-CARRY: bool = os.environ.get("MUSEV_CARRY", "1") == "1"
-CARRY_MAX_C: int = int(os.environ.get("MUSEV_CARRY_MAX_C", "320"))
+CARRY: bool = True
+CARRY_MAX_C: int = 320
 CARRY_HITS: int = 0
 
 
@@ -113,7 +114,7 @@ def _carry_setup(d: GemmDesc, o: torch.Tensor, residual: Optional[torch.Tensor],
 
 def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), colstats_for: Optional[torch.Tensor] = None) -> None:
     lib = _lib.load()
-    d.cfg, d.splitk = GEMM_CFG, GEMM_SPLITK
+    d.cfg, d.splitk = GEMM_CFG, (0 if d.c_lo else GEMM_SPLITK)   # (a carry launch is never split: a forced split would be refused)
     d.tile_order = int(GEMM_WEIGHT_STATIONARY)
     pending_stats = None
     if colstats_for is not None and COLSTATS:
@@ -286,11 +287,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     return o
 
 
-# The level-0 feed-forward as one launch (mv_ffn_geglu_f16; env knob for A/B runs: MUSEV_FFN_FUSED=0 keeps LayerNorm + the GEGLU
-# projection + the output projection)
-FFN_FUSED: bool = os.environ.get("MUSEV_FFN_FUSED", "1") == "1"
+# The level-0 feed-forward as one launch (mv_ffn_geglu_f16; A/B: MUSEV_OPS="FFN_FUSED=0" keeps LayerNorm + the GEGLU projection + the
+# output projection)
+FFN_FUSED: bool = True
 FFN_FUSED_HITS: int = 0
-FFN_ROTATE: bool = os.environ.get("MUSEV_FFN_ROTATE", "1") == "1"   # mv_ffn_desc.flags bit 0
+FFN_ROTATE: bool = True   # mv_ffn_desc.flags bit 0
 
 
 def ffn_fused_applies(c: int, hidden: int) -> bool:
@@ -348,8 +349,8 @@ def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], rep
     return e0.elapsed_time(e1)
 
 
-# LayerNorm folding (env knob for A/B runs: MUSEV_LN_FOLD=0 keeps mv_layernorm_f16 + the plain projection everywhere)
-LN_FOLD: bool = os.environ.get("MUSEV_LN_FOLD", "1") == "1"
+# LayerNorm folding (A/B: MUSEV_OPS="LN_FOLD=0" keeps mv_layernorm_f16 + the plain projection everywhere)
+LN_FOLD: bool = True
 _ln_fold_cache: dict = {}
 
 
@@ -485,11 +486,11 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
         global COLSTATS_HITS
         COLSTATS_HITS += 1
         stat = torch.empty(n_items * 2 * groups, dtype=torch.float32, device=x.device)
-        check(lib.mv_groupnorm_cs_f16_var(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
-                                          n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
-                                          o.data_ptr(), o.stride(0), cs1[0].data_ptr(), cs1[1],
-                                          cs2[0].data_ptr() if cs2 is not None else None, cs2[1] if cs2 is not None else 0,
-                                          nsplit, stat.data_ptr(), _p(x_lo), _p(y_lo), int(GN_FOLD_IN_APPLY), _stream()), "mv_groupnorm_cs_f16")
+        check(lib.mv_groupnorm_cs_f16(x.data_ptr(), _p(x2), c1, c2, x.stride(0), x2.stride(0) if x2 is not None else 0,
+                                      n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
+                                      o.data_ptr(), o.stride(0), cs1[0].data_ptr(), cs1[1],
+                                      cs2[0].data_ptr() if cs2 is not None else None, cs2[1] if cs2 is not None else 0,
+                                      nsplit, stat.data_ptr(), _p(x_lo), _p(y_lo), _stream()), "mv_groupnorm_cs_f16")
         return o
     scratch = torch.empty(n_items * nsplit * 2 * groups + n_items * 2 * groups, dtype=torch.float32, device=x.device)
     partial_ptr = scratch.data_ptr()
@@ -513,13 +514,14 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 Seg = Tuple[torch.Tensor, torch.Tensor, int, int, int, int]  # (k, v, len, div, mul, add)
-# MUSEV_ATTN_GROUPS=0 (A/B runs): the image-prompt terms of the cross-attention as separate accumulate launches, as in round 2
-ATTN_GROUPS: bool = os.environ.get("MUSEV_ATTN_GROUPS", "1") == "1"
-# MUSEV_XATTN_RESIDENT=1: attentions over at most 128 keys (the text / image-prompt cross-attention at head dims 40 / 80) run on the
-# resident-K/V kernel (mv_attn_desc.resident_kv: whole query rows per block, q read once, out written once).  Built at the end of
-# round 4 WITHOUT a GPU left to time it: off until a same-box A/B says otherwise (tools/gpu_next_round_first.sh).
-# (a value >= 16 = that many query rows per block instead of the launcher's choice: a tuning hook)
-XATTN_RESIDENT: int = int(os.environ.get("MUSEV_XATTN_RESIDENT", "0"))
+# ATTN_GROUPS = False (A/B): the image-prompt terms of the cross-attention as separate accumulate launches, as in round 2
+ATTN_GROUPS: bool = True
+# Attentions over at most 128 keys (the text / image-prompt cross-attention at head dims 40 / 80) run on the resident-K/V kernel
+# (mv_attn_desc.resident_kv: whole query rows per block, q read once, out written once).  Round 5 (profiles/r05f_xattn_bench.log):
+# level 0, 13 frames: 30.4 us against 43.1 tiled (text), 35.5 against 64.6 (text + IP-Adapter group); level 1: 20.7 / 22.6; in the
+# two-stream step within noise at config 2, -0.15 ms at config 3 (r05f_ab_config*.log).  0 = the tiled kernel; a value >= 16 = that
+# many query rows per block instead of the launcher's choice (tools/gpu_xattn_bench.py sweeps it).
+XATTN_RESIDENT: int = 1
 XATTN_RESIDENT_HITS: int = 0
 
 
@@ -815,3 +817,18 @@ def probe_tr16(image: torch.Tensor) -> torch.Tensor:
     out = torch.empty((64, 4), dtype=torch.int16, device=image.device)
     check(_lib.load().mv_probe_tr16(image.data_ptr(), out.data_ptr(), _stream()), "mv_probe_tr16")
     return out
+
+
+def _apply_env_overrides() -> None:
+    """MUSEV_OPS="NAME=VALUE,...": the one environment hook for A/B runs of this module's switches (ints; booleans as 0 / 1)"""
+    spec = os.environ.get("MUSEV_OPS", "")
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        name, _, val = item.partition("=")
+        if name not in ("COLSTATS", "CARRY", "CARRY_MAX_C", "FFN_FUSED", "FFN_ROTATE", "LN_FOLD", "ATTN_GROUPS", "XATTN_RESIDENT",
+                        "GEMM_WEIGHT_STATIONARY"):
+            raise ValueError(f"MUSEV_OPS: unknown switch {name!r}")
+        cur = globals()[name]
+        globals()[name] = bool(int(val)) if isinstance(cur, bool) else int(val)
+
+
+_apply_env_overrides()

@@ -68,7 +68,7 @@ class ParallelDenoiser:
 
     def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, *, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
-                 context_batch_size: int = 1, use_graphs: bool = True):
+                 context_batch_size: int = 1, use_graphs: bool = True, share_cfg_prefix: bool = True, odd_unit_lane: bool = True):
         self.unet = unet
         self.exchange_events = []
         # hipGraph capture of the per-window UNet forward (~1 500 kernel launches): replayed once per window and step,
@@ -78,14 +78,14 @@ class ParallelDenoiser:
         # the two CFG halves of a window as two batch-1 forwards on two HIP streams (+2.7 % frames/s at config 2,
         # profiles/r01j): MUSEV_HALF_STREAMS=0 restores the single batch-2 forward (per-kernel profiling)
         self.half_streams = os.environ.get("MUSEV_HALF_STREAMS", "1") == "1"
-        # the half-independent front of the network once for both CFG halves of a window (see _unet_rows; MUSEV_SHARE_PREFIX=0: A/B)
-        self.share_cfg_prefix = os.environ.get("MUSEV_SHARE_PREFIX", "1") == "1"
+        # the half-independent front of the network once for both CFG halves of a window (see _unet_rows)
+        self.share_cfg_prefix = share_cfg_prefix
         # A rank with an ODD number of units (24 units over 8 GPUs = 3) owns one two-half window and one lone half.  Run one after
         # the other the lone batch-1 forward has the GPU to itself at ~0.65 of a pair's time; run CONCURRENTLY with the neighbouring
         # pair (its graph replayed on a third stream) three half-forwards share the GPU like a pair and a half.  Used from the second
         # executed step of a call on (every signature captured by then), with graphs, without a ControlNet (whose per-length static
-        # control-frame buffer is shared by the groups).  MUSEV_ODD_UNIT_LANE=0 keeps the groups one after the other.
-        self.odd_unit_lane = os.environ.get("MUSEV_ODD_UNIT_LANE", "1") == "1"
+        # control-frame buffer is shared by the groups).  odd_unit_lane=False keeps the groups one after the other.
+        self.odd_unit_lane = odd_unit_lane
         self._side = {}
         self._lane = {}
         self._t_bufs: Dict[str, torch.Tensor] = {}

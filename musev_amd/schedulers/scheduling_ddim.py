@@ -39,9 +39,15 @@ class DDIMScheduler:
     order = 1
 
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
-                 beta_schedule: str = "scaled_linear", clip_sample: bool = False, set_alpha_to_one: bool = False,
+                 beta_schedule: str = "scaled_linear", clip_sample: bool = False, set_alpha_to_one: Optional[bool] = None,
                  steps_offset: int = 1, prediction_type: str = "epsilon", timestep_spacing: str = "leading",
                  rescale_betas_zero_snr: bool = False):
+        # set_alpha_to_one = None resolves to what the reference ends up with for the same keywords: False for the SD-1.5
+        # scheduler_config.json the MuseV checkpoints ship (leading spacing, no beta rescale -- the value that file sets), True
+        # -- diffusers' constructor default, which the reference's DDIMScheduler(...) call relies on -- for the zero-SNR / trailing
+        # configuration (trailing spacing steps to prev_timestep < 0 on the last step, where final_alpha_cumprod is used)
+        if set_alpha_to_one is None:
+            set_alpha_to_one = bool(rescale_betas_zero_snr or timestep_spacing == "trailing")
         # constants are built with torch on the host exactly like diffusers does (fp32 linspace / cumprod), so that
         # alpha_bar_t matches the reference bit for bit
         if beta_schedule == "scaled_linear":

@@ -21,23 +21,6 @@ def _rand(shape, seed, scale=1.0, dtype=torch.float16):
     return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(dtype).to(DEV)
 
 
-def unproven_on_hardware() -> bool:
-    """Kernel forms written at the end of round 4 with no GPU minutes left (default OFF in the product: MUSEV_GN_FOLD_IN_APPLY,
-    MUSEV_XATTN_RESIDENT) are exercised on the host simulator always, on the GPU only with MUSEV_TEST_UNPROVEN=1 -- which
-    tools/gpu_next_round_first.sh sets -- so that a form that never ran on hardware cannot take the round-end GPU suite down."""
-    import os
-    return DEV == "cpu" or os.environ.get("MUSEV_TEST_UNPROVEN") == "1"
-
-
-def _unproven(fn):
-    """a case of a kernel form that has not run on hardware yet: skipped (reported ok) on the GPU unless MUSEV_TEST_UNPROVEN=1"""
-    def run():
-        if not unproven_on_hardware():
-            return {"name": "skipped: kernel form not yet run on hardware (MUSEV_TEST_UNPROVEN=1 runs it)", "ok": True, "max_abs_err": 0.0}
-        return fn()
-    return run
-
-
 def _cmp(name, got, ref, atol, rtol=2e-3):
     got = got.float()
     ref = ref.float()
@@ -410,16 +393,6 @@ def case_colstats_groupnorm(kind="conv", n=3, h=16, w=16, cin=64, c=320, c2=0, c
     results.append(_cmp(f"groupnorm from colstats {kind} cfg{cfg} c{c}+{c2}", got, ref, atol=4e-3))
     if ops.COLSTATS_HITS != hits + 1:
         return {"name": f"colstats {kind} cfg{cfg}", "ok": False, "max_abs_err": float("nan"), "detail": "groupnorm did not take the column-statistics path"}
-    # the fold inside the apply pass (mv_groupnorm_cs_f16_var, variant 1) is the same arithmetic in the same order: bit-identical
-    if unproven_on_hardware():
-        flag = ops.GN_FOLD_IN_APPLY
-        ops.GN_FOLD_IN_APPLY = not flag
-        try:
-            other = ops.groupnorm(a, gamma, beta, n_items, rows, eps=1e-5, silu=True, x2=b)
-        finally:
-            ops.GN_FOLD_IN_APPLY = flag
-        results.append({"name": f"groupnorm fold-in-apply == fold launch {kind} cfg{cfg}", "ok": bool(torch.equal(other, got)),
-                        "max_abs_err": (other.float() - got.float()).abs().max().item()})
     # and the same through the statistics pass (a tensor object without the attribute): the two must agree closely
     plain = ops.groupnorm(a.clone(), gamma, beta, n_items, rows, eps=1e-5, silu=True, x2=None if b is None else b.clone())
     results.append(_cmp(f"groupnorm colstats vs statistics pass {kind} cfg{cfg}", got, plain.float(), atol=2e-3))
@@ -520,9 +493,12 @@ def case_attention_groups(d=40, nb=6, t=3, lq=130, lk=77, seed=75, spike=False):
     return _cmp(f"attention groups d{d} nb{nb} lq{lq} lk{lk} spike{int(spike)}", got, ref, atol=3e-3)
 
 
-def case_gemm_weight_stationary(M=200, N=1280, K=640, seed=880, splitk=0):
+def case_gemm_weight_stationary(M=200, N=1280, K=640, seed=880, splitk=0, cfg=17):
     """mv_gemm_desc.tile_order = 1 (ops.GEMM_WEIGHT_STATIONARY): the n-major workgroup order of the small-M levels is a bijection onto
-    the same tiles -- bit-identical output, with and without a K split; conv3x3 and the linear mode"""
+    the same tiles -- bit-identical output, with and without a K split; conv3x3 and the linear mode.  The tile is forced (64 x 160:
+    4 x 8 tiles here, the grid shape of the 8 x 8-latent level) so that the problem is one where the library's fetch model takes the
+    order; the first GPU run of this case (r05a) used the table's 128 x 128 tile, for which the default order already is
+    weight-stationary, and reported exactly that."""
     from musev_amd import ops
     x = _rand((M, K), seed)
     w = _rand((N, K), seed + 1, 1.0 / math.sqrt(K))
@@ -530,22 +506,22 @@ def case_gemm_weight_stationary(M=200, N=1280, K=640, seed=880, splitk=0):
     n_img, h, wd, cin = 2, 8, 8, 64
     xc = _rand((n_img * h * wd, cin), seed + 3)
     wc = ops.pack_conv_weight(_rand((N, cin, 3, 3), seed + 4, 1.0 / math.sqrt(9 * cin)))
-    flag, sk = ops.GEMM_WEIGHT_STATIONARY, ops.GEMM_SPLITK
+    flag, sk, cf = ops.GEMM_WEIGHT_STATIONARY, ops.GEMM_SPLITK, ops.GEMM_CFG
     try:
-        ops.GEMM_SPLITK = splitk
+        ops.GEMM_SPLITK, ops.GEMM_CFG = splitk, cfg
         ops.GEMM_WEIGHT_STATIONARY = False
         a0, c0 = ops.gemm(x, w, bias=bias), ops.conv3x3(xc, wc, n_img, h, wd)
         ops.GEMM_WEIGHT_STATIONARY = True
         a1, c1 = ops.gemm(x, w, bias=bias), ops.conv3x3(xc, wc, n_img, h, wd)
     finally:
-        ops.GEMM_WEIGHT_STATIONARY, ops.GEMM_SPLITK = flag, sk
+        ops.GEMM_WEIGHT_STATIONARY, ops.GEMM_SPLITK, ops.GEMM_CFG = flag, sk, cf
     ref = x.float() @ w.float().t() + bias.float()
     # the linear problem must really run in the n-major order (the library takes it only where its fetch model prefers it)
     import ctypes as C
     from musev_amd import _lib
     d = _lib.GemmDesc()
     d.a, d.w, d.c, d.M, d.N, d.K, d.lda, d.ldc, d.c1 = 0x10000, 0x20000, 0x30000, M, N, K, K, N, K
-    d.mode, d.cfg, d.splitk, d.tile_order = 0, -1, splitk, 1
+    d.mode, d.cfg, d.splitk, d.tile_order = 0, cfg, splitk, 1
     if _lib.load().mv_gemm_weight_stationary(C.byref(d)) != 1:
         return {"name": "gemm weight-stationary", "ok": False, "max_abs_err": float("nan"), "detail": "the case's problem does not take the weight-stationary order"}
     return _all_ok([_cmp(f"gemm weight-stationary M{M} N{N} K{K} split{splitk}", a1, ref, atol=4e-3),
@@ -910,15 +886,15 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_groups_d40", case_attention_groups),
     ("attention_groups_d80", lambda: case_attention_groups(d=80, lq=100, seed=76)),
     ("attention_groups_d40_spike", lambda: case_attention_groups(d=40, lq=300, lk=200, seed=77, spike=True)),
-    ("gemm_weight_stationary", _unproven(case_gemm_weight_stationary)),
-    ("gemm_weight_stationary_split", _unproven(lambda: case_gemm_weight_stationary(M=300, K=2560, splitk=4, seed=885))),
-    ("attention_resident_d40_groups", _unproven(case_attention_resident)),
-    ("attention_resident_d40_text_ip", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=200, groups=True, face=False, seed=99))),
-    ("attention_resident_d40_text", _unproven(lambda: case_attention_resident(d=40, nb=4, t=2, lq=1000, groups=False, seed=95))),
-    ("attention_resident_d80_groups", _unproven(lambda: case_attention_resident(d=80, nb=4, t=2, lq=260, groups=True, seed=91))),
-    ("attention_resident_rows_per_block", _unproven(lambda: _all_ok([case_attention_resident(d=40, nb=4, t=2, lq=300, groups=False, seed=101, rows=r) for r in (16, 48, 512)]))),
-    ("attention_resident_128_keys", _unproven(lambda: case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94))),
-    ("attention_resident_5_heads", _unproven(lambda: case_attention_resident(d=40, nb=3, t=3, lq=17, lk=5, groups=False, seed=93, heads=5))),
+    ("gemm_weight_stationary", case_gemm_weight_stationary),
+    ("gemm_weight_stationary_split", lambda: case_gemm_weight_stationary(M=300, K=2560, splitk=4, seed=885)),
+    ("attention_resident_d40_groups", case_attention_resident),
+    ("attention_resident_d40_text_ip", lambda: case_attention_resident(d=40, nb=4, t=2, lq=200, groups=True, face=False, seed=99)),
+    ("attention_resident_d40_text", lambda: case_attention_resident(d=40, nb=4, t=2, lq=1000, groups=False, seed=95)),
+    ("attention_resident_d80_groups", lambda: case_attention_resident(d=80, nb=4, t=2, lq=260, groups=True, seed=91)),
+    ("attention_resident_rows_per_block", lambda: _all_ok([case_attention_resident(d=40, nb=4, t=2, lq=300, groups=False, seed=101, rows=r) for r in (16, 48, 512)])),
+    ("attention_resident_128_keys", lambda: case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94)),
+    ("attention_resident_5_heads", lambda: case_attention_resident(d=40, nb=3, t=3, lq=17, lk=5, groups=False, seed=93, heads=5)),
     ("attention_spike", case_attention_spike),
     ("temporal_attention", case_temporal_attention),
     ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),
@@ -1005,10 +981,10 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_level0", case_attention_level0),
     ("attention_groups_l0_half", lambda: case_attention_groups(d=40, nb=13, t=13, lq=4096, seed=78)),   # level-0 cross attention, one CFG half
     ("attention_groups_l1_half", lambda: case_attention_groups(d=80, nb=13, t=13, lq=1024, seed=79)),
-    ("attention_resident_l0_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, seed=96))),   # level-0 cross attention, one CFG half
-    ("attention_resident_l0_text_ip_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, face=False, seed=100))),
-    ("attention_resident_l0_text_half", _unproven(lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, groups=False, seed=97))),
-    ("attention_resident_l1_half", _unproven(lambda: case_attention_resident(d=80, nb=13, t=13, lq=1024, seed=98))),
+    ("attention_resident_l0_half", lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, seed=96)),   # level-0 cross attention, one CFG half
+    ("attention_resident_l0_text_ip_half", lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, face=False, seed=100)),
+    ("attention_resident_l0_text_half", lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, groups=False, seed=97)),
+    ("attention_resident_l1_half", lambda: case_attention_resident(d=80, nb=13, t=13, lq=1024, seed=98)),
     ("groupnorm_l0", lambda: case_groupnorm(n=26, rows=4096, c1=320, seed=230)),
     ("groupnorm_l0_tconv", lambda: case_groupnorm(n=2, rows=13 * 4096, c1=320, seed=231)),       # statistics over T*H*W
     ("layernorm_l0", lambda: case_layernorm(rows=106496, c=320, seed=232)),

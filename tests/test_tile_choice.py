@@ -156,27 +156,6 @@ def test_study_legs_stay_within_three_percent_of_a_fresh_tune():
         assert tot["hybrid"] < tot["inherit"] < tot["rules"], (test_tag, tot)
 
 
-def test_unproven_kernel_forms_cannot_fail_the_gpu_suite(monkeypatch):
-    """cases of kernel forms that never ran on hardware (written with no GPU minutes left) report ok on the GPU unless
-    MUSEV_TEST_UNPROVEN=1; on the host simulator (DEV = cpu) they always run"""
-    import kernel_cases as kc
-    called = []
-    probe = kc._unproven(lambda: called.append(1) or {"name": "x", "ok": False, "max_abs_err": 1.0})
-    monkeypatch.setattr(kc, "DEV", "cuda")
-    monkeypatch.delenv("MUSEV_TEST_UNPROVEN", raising=False)
-    assert probe()["ok"] and not called
-    monkeypatch.setenv("MUSEV_TEST_UNPROVEN", "1")
-    assert not probe()["ok"] and called
-    monkeypatch.delenv("MUSEV_TEST_UNPROVEN")
-    monkeypatch.setattr(kc, "DEV", "cpu")
-    assert not probe()["ok"]
-    # and the product switches are off unless asked for
-    from musev_amd import ops
-    import os
-    for env, flag in (("MUSEV_XATTN_RESIDENT", ops.XATTN_RESIDENT), ("MUSEV_GN_FOLD_IN_APPLY", ops.GN_FOLD_IN_APPLY), ("MUSEV_GEMM_WEIGHT_STATIONARY", ops.GEMM_WEIGHT_STATIONARY)):
-        assert bool(flag) == (os.environ.get(env, "0") not in ("0", ""))
-
-
 def test_choice_is_valid_for_arbitrary_sizes():
     """fuzz of the host-side chooser (table rows, key buckets, keyed votes, rules, LayerNorm / GEGLU constraints, split clamp): any
     size gets a configuration of the catalogue whose epilogue can run it, a split that fits the workspace cap, and a consistent

@@ -77,19 +77,6 @@ def main():
         print(f"cross-attention d {d} rows {nb} x {lq} keys {lk}{' + 4 (group)' if ip else ''}: tiled {res.get(False, float('nan')):7.1f} us "
               f"({mb / res.get(False, math.nan) :5.2f} TB/s)   resident {res.get(True, float('nan')):7.1f} us ({mb / res.get(True, math.nan):5.2f} TB/s)"
               f"   max |diff| {diff:.2e}   rows per block -> us: {sweep}")
-    # GroupNorm from producer column statistics, per-frame norm at level 0: fold launch + apply against the fold inside the apply
-    n, hw, cch = 13, 4096, 320
-    x = rnd((n * hw, cch), 40)
-    w = ops.pack_conv_weight(rnd((cch, cch, 3, 3), 41, 1.0 / math.sqrt(9 * cch)))
-    y = ops.conv3x3(x, w, n, 64, 64)
-    gamma, beta = rnd((cch,), 42, 0.2) + 1, rnd((cch,), 43, 0.2)
-    out = torch.empty_like(y)
-    res = {}
-    for fold in (False, True):
-        ops.GN_FOLD_IN_APPLY = fold
-        res[fold] = timed(lambda: ops.groupnorm(y, gamma, beta, n, hw, eps=1e-5, silu=True, out=out))
-    ops.GN_FOLD_IN_APPLY = False
-    print(f"groupnorm from column statistics, {n} x {hw} x {cch}: fold launch + apply {res[False]:6.1f} us   fold inside apply {res[True]:6.1f} us")
 
 
 if __name__ == "__main__":
