@@ -212,6 +212,13 @@ LOOP_CASES_AT_SIZE = {
     "refnet_cfg3_loop20": dict(flavour="musev_referencenet", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=9, latent_seed=33, cond_seed=34,
                                prompt_seed=35, side_seed=36, guidance_scale=3.5, num_inference_steps=20, steps=20, context_frames=12,
                                context_overlap=4),
+    # config 5's resolution and side inputs: 768 x 768 (96 x 96 latents), one 12-frame window + the condition
+    # frame, `musev_referencenet_pose` inputs -- ReferenceNet features, IP-Adapter tokens, ControlNet residuals on every skip + mid
+    # block and the PoseGuider embedding, constant over the window as a pipeline with pre-computed control features hands them over --
+    # first 4 of 20 DDIM steps (the reference's own UNet3DConditionModel inside the oracle loop; ~1 h of CPU)
+    "refnet_pose_cfg5_loop": dict(flavour="musev_referencenet", arch={}, T=12, h=96, w=96, n_cond=1, weight_seed=11, latent_seed=37, cond_seed=38,
+                                  prompt_seed=39, side_seed=40, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
+                                  context_overlap=4, controlnet=True, pose=True),
 }
 
 
@@ -251,6 +258,13 @@ def loop_case_unet_kwargs(case: dict, cfg: dict) -> dict:
     if cfg["ip_adapter_cross_attn"]:
         kw["vision_clip_emb"] = torch.randn(2, 4, cfg["cross_attention_dim"], generator=g)
         kw["ip_adapter_scale"] = 0.8
+    bt = 2 * (case["n_cond"] + case["T"])   # rows of one window forward: (CFG half, frame)
+    if case.get("controlnet"):
+        kw["down_block_additional_residuals"] = [0.1 * torch.randn(1, c, a, b_, generator=g).repeat(bt, 1, 1, 1) * (1.0 + 0.05 * torch.arange(bt).view(bt, 1, 1, 1) % 3)
+                                                 for c, a, b_ in shapes]
+        kw["mid_block_additional_residual"] = 0.1 * torch.randn(bt // 2, mid[0], mid[1], mid[2], generator=g).repeat(2, 1, 1, 1)
+    if case.get("pose"):
+        kw["pose_guider_emb"] = 0.1 * torch.randn(bt // 2, cfg["block_out_channels"][0], case["h"], case["w"], generator=g).repeat(2, 1, 1, 1)
     return kw
 
 
