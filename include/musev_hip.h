@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 9
+#define MV_ABI_VERSION 10
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -158,6 +158,33 @@ typedef struct mv_ffn_desc {
     int32_t flags;           /* bit 0: row blocks walk the hidden chunks from different starting chunks (spreads the weight reads) */
 } mv_ffn_desc;
 int mv_ffn_geglu_f16(const mv_ffn_desc* d, void* stream);
+
+/* ---- one temporal self-attention sub-block as one launch (K5 + K3 + K6c + K3) ---------------------------
+ * replaces: norm1 -> attn1 -> + hidden_states (and norm2 -> attn2 -> + hidden_states: double_self_attention) of the temporal
+ *   BasicTransformerBlock (musev/models/attention.py:293-345) on the "(b h w) t c" sequences TransformerTemporalModel forms
+ *   (musev/models/temporal_transformer.py:250-279), for the 320-channel (level 0) stream, 8 heads x 40, T <= 16 frames:
+ *     out = x + to_out( softmax_T( q k^T scale ) v ) + bias_o,   [q | k | v] = LayerNorm(x) Wqkv^T   over the T frames of a pixel
+ * Rows stay in (b, t, p) order (row = (b T + t) HW + p): a workgroup owns 8 pixels of one batch item with all their frames.
+ * wqkv: per head 128 rows of C columns: to_q rows 40 h .. + 39, to_k rows 40 h .. + 39, to_v rows 40 h .. + 39, 8 zero rows.
+ * wo: [C][heads * 64]: column 64 h + d holds to_out.0.weight[:, 40 h + d] for d < 40, zero for 40 <= d < 64.
+ * The [M, 3 C] projection and the attention output never leave the compute unit.  MV_ERR_INVALID for any other geometry (the
+ * caller keeps the three-launch form there). */
+typedef struct mv_tsa_desc {
+    const void* x;           /* fp16 [B T HW][ldx], C columns: the rows the LayerNorm reads, also the residual  */
+    const void* ln_gamma;    /* fp16 [C], 16-byte aligned                                                       */
+    const void* ln_beta;     /* fp16 [C], 16-byte aligned                                                       */
+    const void* wqkv;        /* fp16 [heads][128][C] packed (see above)                                         */
+    const void* wo;          /* fp16 [C][heads * 64] packed (see above)                                         */
+    const void* bias_o;      /* fp16 [C] or NULL                                                                */
+    void* out;               /* fp16 [B T HW][ldo]                                                              */
+    int64_t B;
+    int32_t T, HW;           /* frames (<= 16), pixels per frame (a multiple of 8)                              */
+    int32_t C, heads, d;     /* 320, 8, 40                                                                      */
+    int32_t ldx, ldo;        /* leading dimensions in elements (multiples of 8)                                 */
+    float ln_eps, scale;     /* LayerNorm epsilon; softmax scale (d^-0.5)                                       */
+    int32_t flags;           /* bit 0: workgroups walk the heads from different starting heads (spreads the weight reads) */
+} mv_tsa_desc;
+int mv_temporal_attn_block_f16(const mv_tsa_desc* d, void* stream);
 
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
  * replaces: torch.nn.GroupNorm(32, C)(+SiLU) in ResnetBlock2D.norm1/norm2, Transformer2DModel.norm

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "l
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 9
+MV_ABI_VERSION = 10
 
 
 class MuseVHipError(RuntimeError):
@@ -50,6 +50,15 @@ class FfnDesc(C.Structure):
     ]
 
 
+class TsaDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("wqkv", C.c_void_p), ("wo", C.c_void_p),
+        ("bias_o", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int64), ("T", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32),
+        ("ldx", C.c_int32), ("ldo", C.c_int32), ("ln_eps", C.c_float), ("scale", C.c_float), ("flags", C.c_int32),
+    ]
+
+
 class AttnSeg(C.Structure):
     _fields_ = [
         ("k", C.c_void_p), ("v", C.c_void_p),
@@ -77,6 +86,7 @@ SIGNATURES = {
     "mv_last_error": (C.c_char_p, []),
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "mv_ffn_geglu_f16": (_i32, [C.POINTER(FfnDesc), _vp]),
+    "mv_temporal_attn_block_f16": (_i32, [C.POINTER(TsaDesc), _vp]),
     "mv_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
     "mv_gemm_choice": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
     "mv_gemm_weight_stationary": (_i32, [C.POINTER(GemmDesc)]),

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .layers import FeedForward, HipModule, IPAttention, lin_w, ln_linear
+from .layers import FeedForward, HipModule, IPAttention, lin_b, lin_w, ln_linear, w16
 from .runtime import Ctx, Geo, SourceCache
 
 
@@ -116,6 +116,14 @@ class BasicTransformerBlock(HipModule):
     def hip_forward_temporal(self, x: torch.Tensor, geo: Geo) -> torch.Tensor:
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
         for norm, attn in ((self.norm1, self.attn1), (self.norm2, self.attn2)):
+            if ops.tsa_fused_applies(c, h, d, geo.t, geo.hw) and attn.to_q.bias is None:
+                # level 0: LayerNorm -> q / k / v -> T x T attention -> to_out + x in one launch (mv_temporal_attn_block_f16)
+                x = ops.temporal_attn_block(
+                    x, w16(norm.weight), w16(norm.bias), norm.eps,
+                    attn.packed("tsa_qkv", lambda a=attn: ops.pack_tsa_qkv(lin_w(a.to_q), lin_w(a.to_k), lin_w(a.to_v), h, d)),
+                    attn.packed("tsa_out", lambda a=attn: ops.pack_tsa_out(lin_w(a.to_out[0]), h, d)),
+                    lin_b(attn.to_out[0]), geo.b, geo.t, geo.hw, h, d, attn.scale)
+                continue
             qkv = ln_linear(attn, "qkv", x, norm, attn.build_qkv)
             att = ops.temporal_attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], geo.b, geo.t, geo.hw, h, d, attn.scale)
             x = attn.project_out(att, residual=x)

@@ -44,7 +44,7 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_CFG    -1 = measured per-shape table, then rules (default); -2 = rules only; >= 0 = that catalogue id
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 #   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
-#                      COLSTATS, CARRY, FFN_FUSED, LN_FOLD, ATTN_GROUPS, XATTN_RESIDENT, GEMM_WEIGHT_STATIONARY); applied at the
+#                      COLSTATS, CARRY, FFN_FUSED, TSA_FUSED, LN_FOLD, ATTN_GROUPS, XATTN_RESIDENT, GEMM_WEIGHT_STATIONARY); applied at the
 #                      bottom of this file
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
@@ -151,6 +151,8 @@ def _launch_gemm(d: GemmDesc, what: str, dev: torch.device, keep: tuple = (), co
 def _replay_one(lib, d, st) -> None:
     if isinstance(d, _lib.FfnDesc):
         check(lib.mv_ffn_geglu_f16(C.byref(d), st), "mv_ffn_geglu_f16(replay)")
+    elif isinstance(d, _lib.TsaDesc):
+        check(lib.mv_temporal_attn_block_f16(C.byref(d), st), "mv_temporal_attn_block_f16(replay)")
     else:
         check(lib.mv_gemm_f16(C.byref(d), st), "mv_gemm_f16(replay)")
 
@@ -159,6 +161,8 @@ def record_flops(d) -> float:
     """algorithmic FLOPs of a recorded launch (mv_gemm_f16: 2 M N K; the fused feed-forward: both projections)"""
     if isinstance(d, _lib.FfnDesc):
         return 2.0 * d.M * d.C * 2 * d.H + 2.0 * d.M * d.H * d.C
+    if isinstance(d, _lib.TsaDesc):   # the q / k / v projection and to_out (the T x T attention itself is not counted, as before)
+        return 2.0 * d.B * d.T * d.HW * d.C * 4 * d.C
     return 2.0 * d.M * d.N * d.K
 
 
@@ -326,6 +330,61 @@ def ffn_geglu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     if GEMM_RECORD is not None:  # the fused feed-forward is matrix work of the same family: recorded next to the mv_gemm_f16 launches
         nbytes = 2 * (3 * M * c + 3 * hidden * c)   # x, the residual and the output once; both weight matrices once
         GEMM_RECORD.append((_lib.FfnDesc.from_buffer_copy(d), (x, gamma, beta, w1p, b1p, w2, b2, residual, o), nbytes, _stream()))
+    return o
+
+
+# One temporal self-attention sub-block as one launch (mv_temporal_attn_block_f16; A/B: MUSEV_OPS="TSA_FUSED=0" keeps the LayerNorm-folded
+# QKV projection + mv_temporal_attention_f16 + to_out)
+TSA_FUSED: bool = True
+TSA_FUSED_HITS: int = 0
+
+
+def tsa_fused_applies(c: int, heads: int, d: int, t: int, hw: int) -> bool:
+    return TSA_FUSED and c == 320 and heads == 8 and d == 40 and 1 <= t <= 16 and hw % 8 == 0
+
+
+def pack_tsa_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, heads: int, d: int) -> torch.Tensor:
+    """[heads * d, C] x 3 -> [heads, 128, C]: per head the rows [q_h (d) | k_h (d) | v_h (d) | zero rows up to 128]"""
+    c = wq.shape[1]
+    out = torch.zeros(heads, 128, c, dtype=torch.float16, device=wq.device)
+    for i, w in enumerate((wq, wk, wv)):
+        out[:, i * d:(i + 1) * d] = w.reshape(heads, d, c).to(torch.float16)
+    return out.contiguous()
+
+
+def pack_tsa_out(wo: torch.Tensor, heads: int, d: int) -> torch.Tensor:
+    """[C, heads * d] -> [C, heads * 64]: column 64 h + j = column d h + j for j < d, zero up to 64"""
+    c = wo.shape[0]
+    out = torch.zeros(c, heads, 64, dtype=torch.float16, device=wo.device)
+    out[:, :, :d] = wo.reshape(c, heads, d).to(torch.float16)
+    return out.reshape(c, heads * 64).contiguous()
+
+
+def temporal_attn_block(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, wqkv_p: torch.Tensor, wo_p: torch.Tensor,
+                        bias_o: Optional[torch.Tensor], b: int, t: int, hw: int, heads: int, d: int, scale: float,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x + to_out(softmax_T(q k^T scale) v) with [q | k | v] = LayerNorm(x) Wqkv^T over the t frames of every pixel, in ONE launch
+    (C = 320, 8 heads x 40, t <= 16): rows of ``x`` in (b, t, p) order; ``wqkv_p`` / ``wo_p`` from :func:`pack_tsa_qkv` / :func:`pack_tsa_out`."""
+    x = _mat(x, "x")
+    M, c = x.shape
+    if M != b * t * hw or not wqkv_p.is_contiguous() or not wo_p.is_contiguous() or tuple(wqkv_p.shape) != (heads, 128, c) or \
+            tuple(wo_p.shape) != (c, heads * 64) or not _on_gpu(wqkv_p) or not _on_gpu(wo_p):
+        raise ValueError("temporal_attn_block: shape mismatch")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(bias_o, "bias_o", c)
+    o = _out(out, M, c, x)
+    ds = _lib.TsaDesc()
+    ds.x, ds.ln_gamma, ds.ln_beta, ds.wqkv, ds.wo, ds.bias_o, ds.out = (x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), wqkv_p.data_ptr(),
+                                                                       wo_p.data_ptr(), _p(bias_o), o.data_ptr())
+    ds.B, ds.T, ds.HW, ds.C, ds.heads, ds.d = b, t, hw, c, heads, d
+    ds.ldx, ds.ldo, ds.ln_eps, ds.scale, ds.flags = x.stride(0), o.stride(0), float(eps), float(scale), int(FFN_ROTATE)
+    check(_lib.load().mv_temporal_attn_block_f16(C.byref(ds), _stream()), "mv_temporal_attn_block_f16")
+    global TSA_FUSED_HITS
+    TSA_FUSED_HITS += 1
+    if GEMM_RECORD is not None:  # matrix work of the same family (the q / k / v projection + to_out): recorded next to the mv_gemm_f16 launches
+        nbytes = 2 * (3 * M * c + 4 * c * c)   # x twice (rows, residual) and the output once; the four weight matrices once
+        GEMM_RECORD.append((_lib.TsaDesc.from_buffer_copy(ds), (x, gamma, beta, wqkv_p, wo_p, bias_o, o), nbytes, _stream()))
     return o
 
 
@@ -825,7 +884,7 @@ def _apply_env_overrides() -> None:
     for item in filter(None, (x.strip() for x in spec.split(","))):
         name, _, val = item.partition("=")
         if name not in ("COLSTATS", "CARRY", "CARRY_MAX_C", "FFN_FUSED", "FFN_ROTATE", "LN_FOLD", "ATTN_GROUPS", "XATTN_RESIDENT",
-                        "GEMM_WEIGHT_STATIONARY"):
+                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED"):
             raise ValueError(f"MUSEV_OPS: unknown switch {name!r}")
         cur = globals()[name]
         globals()[name] = bool(int(val)) if isinstance(cur, bool) else int(val)

@@ -293,6 +293,39 @@ def case_ffn_fused(M=300, seed=700, offset=0.0, with_bias=True):
     return _all_ok(results)
 
 
+def case_tsa_block(b=1, t=13, hw=24, seed=720, offset=0.0, with_bias=True):
+    """one temporal self-attention sub-block as one launch (mv_temporal_attn_block_f16): x + to_out(softmax_T(q k^T scale) v) with
+    [q | k | v] = LayerNorm(x) Wqkv^T over the t frames of every pixel (C = 320, 8 heads x 40), against the torch fp32 expression of
+    the chain and, as a second check, against the three launches it replaces"""
+    from musev_amd import ops
+    c, heads, d = 320, 8, 40
+    M = b * t * hw
+    x = (_rand((M, c), seed, 1.5).float() + offset).half()
+    gamma = (_rand((c,), seed + 1, 0.2).float() + 1.0).half()
+    beta = _rand((c,), seed + 2, 0.2)
+    wq, wk, wv = (_rand((c, c), seed + 3 + i, 1.6 / math.sqrt(c)) for i in range(3))
+    wo = _rand((c, c), seed + 6, 1.0 / math.sqrt(c))
+    bo = _rand((c,), seed + 7, 0.3) if with_bias else None
+    scale = d ** -0.5
+    got = ops.temporal_attn_block(x, gamma, beta, 1e-5, ops.pack_tsa_qkv(wq, wk, wv, heads, d), ops.pack_tsa_out(wo, heads, d), bo,
+                                  b, t, hw, heads, d, scale)
+    xn = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), 1e-5)
+
+    def seq(y):  # [(b t hw), c] -> [(b hw), t, c]
+        return y.reshape(b, t, hw, c).permute(0, 2, 1, 3).reshape(b * hw, t, c)
+    att = _attn_ref(seq(xn @ wq.float().t()), seq(xn @ wk.float().t()), seq(xn @ wv.float().t()), heads, d, scale)
+    att = att.reshape(b, hw, t, c).permute(0, 2, 1, 3).reshape(M, c)
+    ref = x.float() + att @ wo.float().t() + (bo.float() if with_bias else 0.0)
+    results = [_cmp(f"tsa block b{b} t{t} hw{hw} offset{offset}", got, ref, atol=6e-3)]
+    # the three launches: LayerNorm-folded (or plain) q / k / v projection, mv_temporal_attention_f16, to_out + residual
+    xln = ops.layernorm(x, gamma, beta, 1e-5)
+    qkv = ops.gemm(xln, torch.cat([wq, wk, wv], 0).contiguous())
+    a3 = ops.temporal_attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, t, hw, heads, d, scale)
+    three = ops.gemm(a3, wo, bias=bo, residual=x)
+    results.append(_cmp(f"tsa block vs three launches b{b} t{t} hw{hw}", got, three.float(), atol=6e-3))
+    return _all_ok(results)
+
+
 def case_tail_carry(n=3, h=16, w=16, c=320, seed=800):
     """the network's tail on a carried stream: conv_norm_out reads hi + lo (statistics of hi, from the producer's column statistics or
     its own pass), normalises in fp32 and hands conv_out two fp16 halves; conv_out (320 -> 4, fp32 out) reads both.  Against the
@@ -895,6 +928,9 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_resident_rows_per_block", lambda: _all_ok([case_attention_resident(d=40, nb=4, t=2, lq=300, groups=False, seed=101, rows=r) for r in (16, 48, 512)])),
     ("attention_resident_128_keys", lambda: case_attention_resident(d=40, nb=2, t=1, lq=300, lk=128, groups=False, seed=94)),
     ("attention_resident_5_heads", lambda: case_attention_resident(d=40, nb=3, t=3, lq=17, lk=5, groups=False, seed=93, heads=5)),
+    ("tsa_block", case_tsa_block),
+    ("tsa_block_two_items_t5", lambda: case_tsa_block(b=2, t=5, hw=16, seed=730, offset=0.7)),
+    ("tsa_block_t16_no_bias", lambda: case_tsa_block(b=1, t=16, hw=8, seed=740, with_bias=False)),
     ("attention_spike", case_attention_spike),
     ("temporal_attention", case_temporal_attention),
     ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),
@@ -981,6 +1017,7 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_level0", case_attention_level0),
     ("attention_groups_l0_half", lambda: case_attention_groups(d=40, nb=13, t=13, lq=4096, seed=78)),   # level-0 cross attention, one CFG half
     ("attention_groups_l1_half", lambda: case_attention_groups(d=80, nb=13, t=13, lq=1024, seed=79)),
+    ("tsa_block_l0_half", lambda: case_tsa_block(b=1, t=13, hw=4096, seed=750)),   # one CFG half of a level-0 temporal sub-block
     ("attention_resident_l0_half", lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, seed=96)),   # level-0 cross attention, one CFG half
     ("attention_resident_l0_text_ip_half", lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, face=False, seed=100)),
     ("attention_resident_l0_text_half", lambda: case_attention_resident(d=40, nb=13, t=13, lq=4096, groups=False, seed=97)),

@@ -1,4 +1,4 @@
-"""Builds the SIMULATED C-ABI library: the five unmodified .hip sources of musev_amd/csrc compiled for x86 against the stand-in
+"""Builds the SIMULATED C-ABI library: the unmodified .hip sources of musev_amd/csrc compiled for x86 against the stand-in
 tests/cpu_sim/hip/hip_runtime.h (thread-per-lane execution, MFMA / LDS-DMA / buffer-descriptor models -- see that header), and
 lets a test route musev_amd.ops through it.  TEST INFRASTRUCTURE ONLY: the product never imports this module, and the
 routing is a pytest monkeypatch of the loaded-library handle -- there is no switch in the product that selects it."""
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = os.path.join(ROOT, "tests", "cpu_sim")
 CSRC = os.path.join(ROOT, "musev_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ("lib", "gemm", "norm", "attention", "elementwise", "ffn")
+SOURCES = ("lib", "gemm", "norm", "attention", "elementwise", "ffn", "tsa")
 
 
 def transform(text: str) -> str:
