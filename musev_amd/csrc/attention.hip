@@ -449,6 +449,10 @@ __global__ __launch_bounds__(256, (OPT >= 1 && D == 40) ? 4 : 2) void attn_kerne
 //          the hardware's lane groups (80-byte rows: 2-way on both).
 //   4  (d = 40) register budget of four waves per SIMD (128 VGPRs) instead of three
 //   8  eight waves = 256 query rows per block share every K / V tile (half the L2 -> LDS traffic and half the barriers per MFMA)
+//  32  s_setprio 1 around the two matrix clusters of a tile (S^T = K Q^T, O^T += V^T P^T), 0 around the softmax: the SIMD's other waves'
+//      exp / convert work yields issue slots to the wave that feeds the matrix pipe.  Round 5, same box (profiles/r05i_attn_variants.log):
+//      26 frames 1.630 -> 1.578 ms, 13 frames 0.868 -> 0.781 ms; in the two-stream step -0.25 ms (r05j: 55.76 / 55.89 against 56.06 /
+//      56.13 / 56.08).  A static priority for the second-dispatched half of the block instead measured 0.4 % (not kept).
 //  16  softmax GROUPS: a segment flagged new_group closes the running softmax -- O / row sum, times the group's weight, is added to
 //      a second accumulator -- and starts a fresh one: out = sum_g gscale_g * softmax_g(Q K_g^T) V_g in ONE launch (text
 //      cross-attention + IP-Adapter (+ FaceID) image-prompt attention: Q read once, the output written once, no read-modify-write)
@@ -669,6 +673,7 @@ void attn3_kernel(const AttnArgs p) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) acc_s[qt][st] = float4v{m0, m0, m0, m0};
         }
+        if constexpr ((VAR & 32) != 0) __builtin_amdgcn_s_setprio(1);   // VAR bit 32: raised priority around the matrix clusters
 #pragma unroll
         for (int c = 0; c < C::NC32; ++c) {
 #pragma unroll
@@ -688,6 +693,7 @@ void attn3_kernel(const AttnArgs p) {
                     acc_s[qt][st] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qt16[qt], acc_s[qt][st], 0, 0, 0);
             }
         }
+        if constexpr ((VAR & 32) != 0) __builtin_amdgcn_s_setprio(0);
         if (rows < C::KV) {  // wave-uniform: the partial last tile of a segment masks its missing keys
 #pragma unroll
             for (int st = 0; st < 4; ++st)
@@ -749,6 +755,7 @@ void attn3_kernel(const AttnArgs p) {
             }
         }
         // ---- O^T += V^T P^T; row sums += 1^T P^T (ONES: output row D of the same product) ----
+        if constexpr ((VAR & 32) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             if constexpr (!C::ONES) {
@@ -769,6 +776,7 @@ void attn3_kernel(const AttnArgs p) {
                     acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfrag[qt][cc], acc_o[qt][dt], 0, 0, 0);
             }
         }
+        if constexpr ((VAR & 32) != 0) __builtin_amdgcn_s_setprio(0);
         first = false;
       }
     }
@@ -1315,7 +1323,7 @@ namespace {
 
 // kernel variants the library runs (Attn3Cfg: 1 = 16-deep contraction tail, 2 = 48-half rows with the ones column at d = 40);
 // chosen from the same-box A/B of tools/gpu_attn_bench.py (profiles/r03*_attn_variants.log)
-constexpr int kAttnVar40 = 15;  // r03a / r03g, level 0: var 0 1.870 ms -> var 7 1.715 (26 frames), 0.964 -> 0.809 (13 frames); var 15 a further -5.5 % / -1.5 %
+constexpr int kAttnVar40 = 47;  // r03a / r03g, level 0: var 0 1.870 ms -> var 7 1.715 (26 frames), 0.964 -> 0.809 (13 frames); var 15 a further -5.5 % / -1.5 %
 constexpr int kAttnVar80 = 8;   // r03g: eight waves -5 % at 13 frames (the two-stream default), +4 % at 26; the 16-deep tail is 3-4 % slower at d = 80
 
 template <int D, int VAR>
@@ -1479,7 +1487,7 @@ int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) 
         int rc = MV_OK;
         if (grouped) {
             // (three waves per SIMD at d = 40: the second accumulator does not fit the 128-register budget of variant bit 4)
-            rc = d->d == 40 ? launch_attn3<40, 27>(a, grid1, s) : launch_attn3<80, 24>(a, grid1, s);
+            rc = d->d == 40 ? launch_attn3<40, 59>(a, grid1, s) : launch_attn3<80, 24>(a, grid1, s);
         } else if (d->d == 40) {
 #ifdef MV_EXPERIMENT
             if (var40 == 0) rc = launch_attn3<40, 0>(a, grid1, s);
@@ -1490,6 +1498,7 @@ int attention_launch(const mv_attn_desc* d, int var40, int var80, void* stream) 
             else if (var40 == 15) rc = launch_attn3<40, 15>(a, grid1, s);
             else if (var40 == 14) rc = launch_attn3<40, 14>(a, grid1, s);
             else if (var40 == 11) rc = launch_attn3<40, 11>(a, grid1, s);
+            else if (var40 == 47) rc = launch_attn3<40, 47>(a, grid1, s);
             else
 #endif
             rc = launch_attn3<40, kAttnVar40>(a, grid1, s);

@@ -257,7 +257,7 @@ def init_state_dict(cfg: dict, seed: int = 3, gain: float = 1.0, residual_gain: 
 
 
 def calibrate_as_denoiser(sd: "OrderedDict[str, Tensor]", cfg: dict, noise_gain: float = 0.9, random_gain: float = 0.18,
-                          carrier: float = 4.0) -> "OrderedDict[str, Tensor]":
+                          carrier: float = 4.0, carrier_mix_seed: Optional[int] = None, carrier_route: str = "skip0") -> "OrderedDict[str, Tensor]":
     """Turns a seeded random state dict (init_state_dict) into one that BEHAVES LIKE A NOISE PREDICTOR, in place, for the loop
     parity tests: eps = noise_gain * (group-normalised input latent) + random_gain * (the random network's prediction).
 
@@ -277,26 +277,55 @@ def calibrate_as_denoiser(sd: "OrderedDict[str, Tensor]", cfg: dict, noise_gain:
     deviation of standard deviation ~0.2 (mean squared error ~0.04 against the input noise -- the order of a trained
     epsilon-predictor's loss at t >= 500, and of the text-dependent difference classifier-free guidance then amplifies); with
     1.0 the function is the plain random network again.  ``noise_gain`` 0.9 x the group statistics' 1.118 makes eps ~ unit
-    variance."""
+    variance.
+
+    Fixture-sensitivity variants (round 5, tools/cpu_fixture_sweep.py -- is the loop-parity margin a property of THIS carrier?):
+    ``carrier_mix_seed``: the latent channels enter the carrier features through a random orthogonal matrix R (feature 2k / 2k+1 =
+    +- carrier * (R x)_k) and conv_out un-mixes with R^T -- the same function, but every carrier feature is a mixture of all latent
+    channels; ``carrier_route="skip1"``: the carrier is NOT taken from conv_in's output (skip 0) but from the stream one whole level-0
+    stage later (skip 1: behind the first ResnetBlock2D / temporal convolution / transformers, whose residual branches have added to
+    it), copied by the conv_shortcut of the last up block's second-to-last resnet and handed through its last resnet's conv_shortcut
+    from the hidden stream."""
     ch = cfg["block_out_channels"]
     nin = cfg["in_channels"]
     last = len(cfg["up_block_types"]) - 1
-    sc = f"up_blocks.{last}.resnets.{cfg['layers_per_block']}.conv_shortcut"
+    L = cfg["layers_per_block"]
+    sc = f"up_blocks.{last}.resnets.{L}.conv_shortcut"
     n = 2 * nin
     if n > ch[0] // cfg["norm_num_groups"]:
         raise ValueError("calibrate_as_denoiser: the carrier features must fit one normalisation group of the first level")
+    if carrier_route not in ("skip0", "skip1"):
+        raise ValueError("carrier_route")
+    R = torch.eye(nin)
+    if carrier_mix_seed is not None:
+        R = torch.linalg.qr(torch.randn(nin, nin, generator=torch.Generator().manual_seed(carrier_mix_seed)))[0]
     w = sd["conv_in.weight"]
     w[:n] = 0
     sd["conv_in.bias"][:n] = 0
-    for c in range(nin):
-        w[2 * c, c, 1, 1] = carrier
-        w[2 * c + 1, c, 1, 1] = -carrier
+    for k in range(nin):
+        for c in range(nin):
+            if R[k, c] != 0:   # (the identity writes exactly the entries the unmixed construction always wrote)
+                w[2 * k, c, 1, 1] = carrier * R[k, c]
+                w[2 * k + 1, c, 1, 1] = -carrier * R[k, c]
     ws = sd[sc + ".weight"]  # [C, C_hidden + C_skip, 1, 1]: torch.cat([hidden, skip]) -> the skip's features come second
     ws[:n] = 0
     sd[sc + ".bias"][:n] = 0
     hidden = ws.shape[1] - ch[0]
-    for k in range(n):
-        ws[k, hidden + k, 0, 0] = 1.0
+    if carrier_route == "skip0":
+        for k in range(n):
+            ws[k, hidden + k, 0, 0] = 1.0
+    else:
+        # skip 1 (the stream behind the first level-0 stage) enters through the second-to-last resnet of the last up block; the last
+        # resnet hands features 0 .. n-1 of its HIDDEN input on (its own skip, skip 0, no longer feeds them)
+        for k in range(n):
+            ws[k, k, 0, 0] = 1.0
+        sc1 = f"up_blocks.{last}.resnets.{L - 1}.conv_shortcut"
+        w1 = sd[sc1 + ".weight"]
+        w1[:n] = 0
+        sd[sc1 + ".bias"][:n] = 0
+        hidden1 = w1.shape[1] - ch[0]
+        for k in range(n):
+            w1[k, hidden1 + k, 0, 0] = 1.0
     sd["conv_norm_out.weight"][:n] = 1.0
     sd["conv_norm_out.bias"][:n] = 0.0
     wo = sd["conv_out.weight"]
@@ -304,8 +333,10 @@ def calibrate_as_denoiser(sd: "OrderedDict[str, Tensor]", cfg: dict, noise_gain:
     sd["conv_out.bias"] *= random_gain
     wo[:, :n] = 0
     for c in range(nin):
-        wo[c, 2 * c, 1, 1] = noise_gain
-        wo[c, 2 * c + 1, 1, 1] = -noise_gain
+        for k in range(nin):
+            if R[k, c] != 0:
+                wo[c, 2 * k, 1, 1] = noise_gain * R[k, c]
+                wo[c, 2 * k + 1, 1, 1] = -noise_gain * R[k, c]
     return sd
 
 

@@ -376,6 +376,51 @@ def ffn_geglu(x, gamma, beta, eps, w1p, b1p, w2, b2, residual, out=None):
     return _store(y + residual.float(), out)
 
 
+def tsa_fused_applies(c, heads, d, t, hw):
+    return c == 320 and heads == 8 and d == 40 and 1 <= t <= 16 and hw % 8 == 0
+
+
+def pack_tsa_qkv(wq, wk, wv, heads, d):
+    c = wq.shape[1]
+    out = torch.zeros(heads, 128, c, dtype=torch.float16)
+    for i, w in enumerate((wq, wk, wv)):
+        out[:, i * d:(i + 1) * d] = w.reshape(heads, d, c).to(torch.float16)
+    return out.contiguous()
+
+
+def pack_tsa_out(wo, heads, d):
+    c = wo.shape[0]
+    out = torch.zeros(c, heads, 64, dtype=torch.float16)
+    out[:, :, :d] = wo.reshape(c, heads, d).to(torch.float16)
+    return out.reshape(c, heads * 64).contiguous()
+
+
+def temporal_attn_block(x, gamma, beta, eps, wqkv_p, wo_p, bias_o, b, t, hw, heads, d, scale, out=None):
+    """the kernel's arithmetic: LayerNorm rounded to fp16, q / k / v rounded to fp16, probabilities normalised then rounded to fp16,
+    the attention output rounded to fp16, fp32 accumulation and an fp32 residual add, rounded once"""
+    _mat(x, "x")
+    M, c = x.shape
+    _req(c == 320 and heads == 8 and d == 40 and 1 <= t <= 16 and hw % 8 == 0 and M == b * t * hw, "temporal_attn_block: C = 320 = 8 x 40, T <= 16, HW % 8")
+    _req(tuple(wqkv_p.shape) == (heads, 128, c) and tuple(wo_p.shape) == (c, heads * 64) and wqkv_p.is_contiguous() and wo_p.is_contiguous(), "temporal_attn_block: packed weights")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(bias_o, "bias_o", c)
+    _check_out(out, M, c, 8)
+    xn = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), eps).to(torch.float16).float()
+    qkv = (xn @ wqkv_p.float().reshape(heads * 128, c).t()).to(torch.float16).float().reshape(M, heads, 128)
+
+    def seq(y):  # [M, heads, d] rows (b, t, p) -> [(b p), heads, t, d]
+        return y.reshape(b, t, hw, heads, d).permute(0, 2, 3, 1, 4).reshape(b * hw, heads, t, d)
+    q, k, v = seq(qkv[:, :, :d]), seq(qkv[:, :, d:2 * d]), seq(qkv[:, :, 2 * d:3 * d])
+    p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1).to(torch.float16).float()
+    o = (p @ v).to(torch.float16).float()                                             # [(b p), heads, t, d]
+    o = o.reshape(b, hw, heads, t, d).permute(0, 3, 1, 2, 4).reshape(M, heads, d)
+    y = torch.einsum("mhd,chd->mc", o, wo_p.float().reshape(c, heads, 64)[:, :, :d])
+    if bias_o is not None:
+        y = y + bias_o.float()
+    return _store(y + x.float(), out)
+
+
 def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None, _carry=False):
     cin = x.shape[1]
     _req(x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[0] == n_img * h * w_, "conv_in: x")
@@ -464,7 +509,7 @@ def pack_geglu(w, bias):
 EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
-            "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu"]
+            "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu", "tsa_fused_applies", "pack_tsa_qkv", "pack_tsa_out", "temporal_attn_block"]
 
 
 def install(monkeypatch) -> None:

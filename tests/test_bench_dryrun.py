@@ -82,3 +82,81 @@ def test_bench_main_dry_run(monkeypatch, capsys):
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["launches_per_step"] > 50 and set(rf["by_mode"]) == {"linear", "conv3x3", "tconv3"}
     assert abs(rf["avg_launch_ms"] - 0.01) < 1e-9 and rec["config"]["graphs"] is False   # (no device: eager emulation)
     assert rec["cpu_baseline"] is None   # --no-cpu-baseline
+
+
+class _MP:
+    """monkeypatch stand-in for spawned workers (their patches die with the process)"""
+    def setattr(self, o, n, v):
+        setattr(o, n, v)
+
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+
+def _bench_rank(rank, world, port, ret):
+    import io
+    import contextlib
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import bench
+    from musev_amd import ops
+    from oracle import unet3d
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    mp_ = _MP()
+    emu_ops.install(mp_)
+    arch = dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
+    sd = unet3d.init_state_dict(unet3d.flavour_config("musev", **arch), 3)
+
+    def build_unet(flavour, dev):
+        m = load_unet_by_name(flavour, sd_unet_model=sd, dtype=torch.float16, **arch)
+        m._device_check = False
+        return m
+
+    bench.build_unet = build_unet
+    ParallelDenoiser._device_check = False
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda *a: None
+    torch.cuda.get_device_properties = lambda d: SimpleNamespace(uuid=None)
+    torch.cuda.current_device = lambda: 0
+    real_device = torch.device
+    bench.torch.device = lambda *a, **k: real_device("cpu")
+    sys.argv = ["bench.py", "--gpus", str(world), "--rehearse-shared-gpu", "--workload", "weak", "--size", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                "--no-roofline"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    ret[rank] = buf.getvalue()
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_bench_two_ranks_over_gloo_emits_the_multi_gpu_block():
+    """`bench.py --gpus 2` as the driver's SCALE run launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* from the
+    environment), on the CPU over gloo with the kernels emulated: rank 0 alone prints the line, and the line carries the `multi_gpu`
+    diagnostics -- backend, rank count, distinct devices, every rank's own ms_per_step, exposed exchange time and unit count (VERDICT
+    r4 item 8).  The `weak` workload keeps the CPU run short (16 frames -> 2 windows x 2 CFG halves = 4 units, 2 per rank); the
+    driver's default for N > 1 is config 4, whose unit list is covered by tests/test_parallel_sharding.py (world 8)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_rank, args=(2, port, ret), nprocs=2, join=True)
+    out = dict(ret)
+    assert not [ln for ln in out[1].splitlines() if ln.startswith("{")], "only rank 0 prints the line"
+    rec = json.loads([ln for ln in out[0].splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["workload"].startswith("weak") and rec["rehearsal"]
+    m = rec["multi_gpu"]
+    assert m["backend"] == "gloo" and m["ranks"] == 2 and m["distinct_devices"] == 1
+    assert len(m["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in m["per_rank_ms_per_step"])
+    assert len(m["per_rank_exposed_exchange_ms_per_step"]) == 2 and m["per_rank_units"] == [2, 2]
+    assert rec["config"]["windows"] == 2 and rec["config"]["units_per_gpu_max"] == 2 and rec["config"]["ideal_speedup_vs_1gpu_same_workload"] == 2.0
+    assert rec["value"] > 0 and rec["config"]["output_finite"] is True
