@@ -141,8 +141,7 @@ def measured_traffic(workload: str):
     FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command, gfx950 read correction x2 applied by
     tools/pmc_summary.py) and committed as profiles/hbm_traffic.json -- a counter pass cannot run inside the timed
     process.  The file records the hash of the kernel sources it was measured on: a measurement of OTHER code is not
-    reported (None), so `traffic` is reproducible from profiles/ or absent -- except for a build the file itself declares as
-    differing only by code the default path does not run (`carried_over_to`; `traffic_source` then starts with CARRIED OVER)."""
+    reported (None), so `traffic` is reproducible from profiles/ or absent."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
@@ -150,22 +149,13 @@ def measured_traffic(workload: str):
         ent = rec.get(workload, {})
         fam = ent.get("gemm")
         here = kernel_source_hash()
-        carried = None
-        if fam is not None and ent.get("kernel_source_hash") != here:
-            # a build that differs from the measured one ONLY by code the default path does not run may be declared in the file
-            # (carried_over_to: its source hash + the reason); the bench line then says so in traffic_source.  Anything else: None.
-            carried = next((c for c in ent.get("carried_over_to", []) if c.get("kernel_source_hash") == here), None)
-        if fam is None or (ent.get("kernel_source_hash") != here and carried is None):
+        if fam is None or ent.get("kernel_source_hash") != here:
             return None, (f"profiles/hbm_traffic.json holds no PMC measurement of this build (kernel sources {here}, "
                           f"file: {ent.get('kernel_source_hash')})")
         per_step = ent.get("gemm_family", {}).get("hbm_bytes_per_step")
         if per_step is None:  # (a round-3 summary: split-K reduces counted as gemm dispatches over 2 profiled steps)
             per_step = fam["hbm_bytes_per_launch"] * fam["launches"] / 2.0
-        src = ent.get("source")
-        if carried is not None:
-            src = (f"CARRIED OVER from the build with kernel sources {ent.get('kernel_source_hash')} (not re-measured on {here}): "
-                   f"{carried.get('reason')} | {src}")
-        return per_step, src
+        return per_step, ent.get("source")
     except (OSError, ValueError, KeyError):
         return None, None
 
@@ -442,6 +432,10 @@ def main():
                 rows.append({"mode": 3, "M": int(d.M), "N": int(d.C), "K": int(d.H), "geglu": 1, "ln": 1, "residual": 1, "colstats": 0, "cfg": -1,
                              "nsplit": 1, "algorithmic_bytes": nb})
                 continue
+            if isinstance(d, _lib.TsaDesc):   # the fused temporal self-attention sub-block (mv_temporal_attn_block_f16): q / k / v + to_out
+                rows.append({"mode": 4, "M": int(d.B) * int(d.T) * int(d.HW), "N": int(d.C), "K": 4 * int(d.C), "geglu": 0, "ln": 1, "residual": 1,
+                             "colstats": 0, "cfg": -1, "nsplit": 1, "algorithmic_bytes": nb})
+                continue
             cfg, ns = C.c_int32(), C.c_int32()
             _lib.load().mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns))
             rows.append({"mode": int(d.mode), "M": int(d.M), "N": int(d.N), "K": int(d.K), "geglu": int(d.geglu), "ln": int(bool(d.ln_colsum)),
@@ -476,10 +470,10 @@ def main():
         rec_all, ops.GEMM_RECORD = ops.GEMM_RECORD, None
         den.use_graphs = True
         from musev_amd import _lib as _mvlib
-        names = {0: "linear", 1: "conv3x3", 2: "tconv3", 3: "ffn_fused"}
+        names = {0: "linear", 1: "conv3x3", 2: "tconv3", 3: "ffn_fused", 4: "tsa_fused"}
 
         def rmode(d):
-            return 3 if isinstance(d, _mvlib.FfnDesc) else int(d.mode)
+            return 3 if isinstance(d, _mvlib.FfnDesc) else 4 if isinstance(d, _mvlib.TsaDesc) else int(d.mode)
         reps = 3
         ops.replay_gemms(rec_all, 1)  # warm (clocks, code objects)
         fam_ms = ops.replay_gemms(rec_all, reps) / reps
@@ -532,6 +526,8 @@ def main():
                 d = r[0]
                 if rmode(d) == 3:
                     key = ("ffn_fused", int(d.M), int(d.C), int(d.H), "ln+geglu+res", 0, 0)
+                elif rmode(d) == 4:
+                    key = ("tsa_fused", int(d.B) * int(d.T) * int(d.HW), int(d.C), 4 * int(d.C), "ln+attn+res", 0, 0)
                 else:
                     key = (names[int(d.mode)], int(d.M), int(d.N), int(d.K), "geglu" if d.geglu else "ln" if d.ln_colsum else "res" if d.residual else "-",
                            int(bool(d.colstats)), int(bool(d.a2)))
@@ -566,14 +562,14 @@ def main():
         del rec_all
         ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch)",
+            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch) + tsa_kernel (the fused level-0 temporal self-attention sub-block: q / k / v projection + to_out per launch)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
             # PMC bytes of the family per step / the step's API launches: the same denominator as algorithmic_bytes_per_launch
             "traffic": (measured_traffic(workload)[0] / max(fam_n * rec_scale, 1)) if measured_traffic(workload)[0] is not None else None,
             "traffic_unit": "HBM bytes per mv_gemm_f16 launch (PMC bytes of gemm2_kernel + splitk_reduce per step / launches per step)",
             "traffic_ratio": (measured_traffic(workload)[0] / (fam_bytes * rec_scale)) if (measured_traffic(workload)[0] is not None and fam_bytes > 0) else None,
             "traffic_source": measured_traffic(workload)[1],
-            "method": f"one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 launches re-issued back to back on one stream, {reps} repetitions between "
+            "method": f"one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 / mv_temporal_attn_block_f16 launches re-issued back to back on one stream, {reps} repetitions between "
                       "one HIP event pair (device time; no per-launch host gap)",
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
             "launches_per_step": fam_n * rec_scale,

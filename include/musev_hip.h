@@ -307,7 +307,10 @@ int mv_conv3x3_direct_f16(const void* x, int32_t cin, const void* w /* [cout][3]
 int mv_timestep_embedding_f16(const float* t, int32_t n, int32_t dim, void* out, void* stream);
 int mv_silu_f16(const void* x, void* y, int64_t n, void* stream);
 /* y = a + b (fp16), used for ControlNet residual adds (unet_3d_condition.py:1146-1156,1195)               */
-int mv_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* y = a + b.  With a_lo / y_lo (may be NULL): a is a carried residual-stream tensor (mv_gemm_desc.c_lo) -- the sum (a + a_lo) + b is
+ * formed in fp32 and stored as two fp16 halves again (the ControlNet residuals added to the UNet's skips, pipeline_controlnet.py:
+ * 2045-2067 / unet_3d_condition.py:1160-1175, join the unrounded stream instead of rounding it a second time). */
+int mv_add_f16(const void* a, const void* a_lo, const void* b, void* y, void* y_lo, int64_t n, void* stream);
 /* rows of x selected by zeroing: y[g, :] = 0 for group rows flagged in mask (temb zeroing of the          */
 /* vision-condition frames, unet_3d_condition.py:898-906)                                                   */
 int mv_zero_rows_f16(void* x, int32_t ld, const int32_t* row_idx, int32_t n_idx, int32_t cols, void* stream);

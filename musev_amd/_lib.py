@@ -112,7 +112,7 @@ SIGNATURES = {
     "mv_conv3x3_cout_small_f16": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
     "mv_timestep_embedding_f16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "mv_silu_f16": (_i32, [_vp, _vp, _i64, _vp]),
-    "mv_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "mv_add_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mv_zero_rows_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     "mv_bcthw_to_bthwc_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mv_bthwc_to_bcthw_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -39,14 +39,23 @@ __global__ void silu_kernel(const half_t* x, half_t* y, long n8) {
     }
 }
 
-__global__ void add_kernel(const half_t* a, const half_t* b, half_t* y, long n8) {
+// y = a + b; with a_lo (the lo half of a carried residual-stream tensor, mv_gemm_desc.c_lo) the sum is (a + a_lo) + b in fp32 and is
+// stored as two halves again: the ControlNet residual joins the unrounded skip instead of rounding it a second time
+__global__ void add_kernel(const half_t* a, const half_t* a_lo, const half_t* b, half_t* y, half_t* y_lo, long n8) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         half8v u = reinterpret_cast<const half8v*>(a)[i];
         half8v v = reinterpret_cast<const half8v*>(b)[i];
-        half8v w;
+        half8v ul = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+        if (a_lo) ul = reinterpret_cast<const half8v*>(a_lo)[i];
+        half8v w, wl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = (half_t)((float)u[j] + (float)v[j]);
+        for (int j = 0; j < 8; ++j) {
+            const float sv = ((float)u[j] + (float)ul[j]) + (float)v[j];
+            w[j] = (half_t)sv;
+            wl[j] = (half_t)(sv - (float)w[j]);
+        }
         reinterpret_cast<half8v*>(y)[i] = w;
+        if (y_lo) reinterpret_cast<half8v*>(y_lo)[i] = wl;
     }
 }
 
@@ -526,9 +535,12 @@ extern "C" int mv_silu_f16(const void* x, void* y, int64_t n, void* stream) {
     return MV_OK;
 }
 
-extern "C" int mv_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+extern "C" int mv_add_f16(const void* a, const void* a_lo, const void* b, void* y, void* y_lo, int64_t n, void* stream) {
     MV_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "mv_add_f16: n must be a positive multiple of 8");
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, (half_t*)y, (long)(n / 8));
+    MV_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a_lo) |
+                 reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0, "mv_add_f16: 16-byte aligned pointers");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)a_lo, (const half_t*)b,
+                       (half_t*)y, (half_t*)y_lo, (long)(n / 8));
     MV_CHECK_LAUNCH("mv_add_f16");
     return MV_OK;
 }

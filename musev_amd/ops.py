@@ -668,7 +668,11 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous() or a.dtype != torch.float16 or b.dtype != torch.float16:
         raise ValueError("add: contiguous fp16 tensors of equal shape expected")
     y = torch.empty_like(a)
-    check(_lib.load().mv_add_f16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mv_add_f16")
+    a_lo = _lo_of(a) if CARRY else None   # a carried stream tensor keeps both halves through the add (see mv_add_f16)
+    y_lo = torch.empty_like(a) if a_lo is not None else None
+    check(_lib.load().mv_add_f16(a.data_ptr(), _p(a_lo), b.data_ptr(), y.data_ptr(), _p(y_lo), a.numel(), _stream()), "mv_add_f16")
+    if y_lo is not None:
+        _set_lo(y, y_lo)
     return y
 
 

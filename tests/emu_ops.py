@@ -344,6 +344,9 @@ def silu(x):
 def add(a, b):
     _req(a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == torch.float16
          and a.numel() % 8 == 0, "add: contiguous fp16 tensors of equal shape, n % 8")
+    lo = _res_lo(a)
+    if lo is not None:   # a carried stream tensor keeps both halves through the add (mv_add_f16 with a_lo / y_lo)
+        return _carry_store((a.float() + lo.float()) + b.float(), None)
     return (a.float() + b.float()).to(torch.float16)
 
 

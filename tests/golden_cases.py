@@ -216,9 +216,22 @@ LOOP_CASES_AT_SIZE = {
     # frame, `musev_referencenet_pose` inputs -- ReferenceNet features, IP-Adapter tokens, ControlNet residuals on every skip + mid
     # block and the PoseGuider embedding, constant over the window as a pipeline with pre-computed control features hands them over --
     # first 4 of 20 DDIM steps (the reference's own UNet3DConditionModel inside the oracle loop; ~1 h of CPU)
+    # fixture sensitivity AT SIZE: config 2 once more with another weight seed and twice the share of the random
+    # network in the prediction (calibrate_as_denoiser(random_gain = 0.35)), the whole 20-step schedule
+    "musev_cfg2_loop20_w12_g035": dict(flavour="musev", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=12, latent_seed=41, cond_seed=42,
+                                       prompt_seed=43, guidance_scale=3.5, num_inference_steps=20, steps=20, context_frames=12, context_overlap=4,
+                                       calib=dict(random_gain=0.35)),
     "refnet_pose_cfg5_loop": dict(flavour="musev_referencenet", arch={}, T=12, h=96, w=96, n_cond=1, weight_seed=11, latent_seed=37, cond_seed=38,
                                   prompt_seed=39, side_seed=40, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
                                   context_overlap=4, controlnet=True, pose=True),
+    # the same with the ControlNet residuals IDENTICAL in the two CFG halves (what a ControlNet fed the same control image produces
+    # up to its text input): the case above scales them per ROW over both halves (uncond rows x1.0-1.6, cond rows x1.65-2.25), which
+    # decorrelates the two halves' rounding errors -- classifier-free guidance then amplifies them (3.5 e_c - 2.5 e_u) instead of
+    # cancelling their common part, as it does in configs 2 / 3 (profiles/r05n_attribution_cfg5.log: the forward's error itself is
+    # config 2's, rms 4.9e-4)
+    "refnet_pose_cfg5_loop_sym": dict(flavour="musev_referencenet", arch={}, T=12, h=96, w=96, n_cond=1, weight_seed=11, latent_seed=37, cond_seed=38,
+                                      prompt_seed=39, side_seed=40, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
+                                      context_overlap=4, controlnet=True, pose=True, controlnet_same_in_both_halves=True),
 }
 
 
@@ -260,7 +273,10 @@ def loop_case_unet_kwargs(case: dict, cfg: dict) -> dict:
         kw["ip_adapter_scale"] = 0.8
     bt = 2 * (case["n_cond"] + case["T"])   # rows of one window forward: (CFG half, frame)
     if case.get("controlnet"):
-        kw["down_block_additional_residuals"] = [0.1 * torch.randn(1, c, a, b_, generator=g).repeat(bt, 1, 1, 1) * (1.0 + 0.05 * torch.arange(bt).view(bt, 1, 1, 1) % 3)
+        rows = torch.arange(bt).view(bt, 1, 1, 1)
+        if case.get("controlnet_same_in_both_halves"):
+            rows = rows % (bt // 2)   # row scale by FRAME: the two halves get the same residuals
+        kw["down_block_additional_residuals"] = [0.1 * torch.randn(1, c, a, b_, generator=g).repeat(bt, 1, 1, 1) * (1.0 + 0.05 * rows % 3)
                                                  for c, a, b_ in shapes]
         kw["mid_block_additional_residual"] = 0.1 * torch.randn(bt // 2, mid[0], mid[1], mid[2], generator=g).repeat(2, 1, 1, 1)
     if case.get("pose"):
@@ -272,7 +288,7 @@ def loop_case_state_dict(case: dict):
     from oracle import unet3d
     cfg = unet3d.flavour_config(case["flavour"], **case["arch"])
     sd = unet3d.init_state_dict(cfg, case["weight_seed"])
-    unet3d.calibrate_as_denoiser(sd, cfg)
+    unet3d.calibrate_as_denoiser(sd, cfg, **case.get("calib", {}))
     return cfg, sd
 
 

@@ -734,9 +734,18 @@ def case_layout_and_misc():
     refz[[3, 17]] = 0
     r4 = _cmp("zero_rows", z, refz, atol=0.0, rtol=0.0)
     r5 = _cmp("add", ops.add(a, s), a.float() + s.float(), atol=1e-3)
-    ok = all(t["ok"] for t in (r, r2, r3, r4, r5))
-    return {"name": "layout+misc", "ok": ok, "max_abs_err": max(t["max_abs_err"] for t in (r, r2, r3, r4, r5)),
-            "parts": {t["name"]: t["ok"] for t in (r, r2, r3, r4, r5)}}
+    # a carried stream tensor (hi + lo) keeps both halves through the add: hi' + lo' = (hi + lo) + b to ~22 bits
+    s32 = (_rand((64, 40), 122, 6.0).float() + 0.37 * _rand((64, 40), 123).float())
+    hi = s32.half()
+    ops._set_lo(hi, (s32 - hi.float()).half())
+    y = ops.add(hi, s)
+    ylo = ops._lo_of(y)
+    r6 = {"name": "add (carried)", "ok": False, "max_abs_err": float("nan")} if ylo is None else \
+        _cmp("add (carried)", y.float() + ylo.float(), s32 + s.float(), atol=2e-5, rtol=1e-6)
+    parts = (r, r2, r3, r4, r5, r6)
+    ok = all(t["ok"] for t in parts)
+    return {"name": "layout+misc", "ok": ok, "max_abs_err": max(t["max_abs_err"] for t in parts),
+            "parts": {t["name"]: t["ok"] for t in parts}}
 
 
 def case_window_loop():

@@ -282,14 +282,23 @@ def test_twenty_step_drift_against_fp16_torch_floor():
     assert max(d_hip) < FREE_RUNNING_BAR, f"|delta latent|max per step: {d_hip}"
 
 
-@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop", "refnet_cfg3_loop20"])
+@pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop", "refnet_cfg3_loop20", "refnet_pose_cfg5_loop",
+                                  "refnet_pose_cfg5_loop_sym", "musev_cfg2_loop20_w12_g035"])
 def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, full-width
     `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the HIP loop against those recorded by
     tests/golden/make_loop_goldens.py (oracle loop around the REFERENCE'S OWN UNet3DConditionModel, fp32 on the CPU):
     `musev_cfg2_loop20` = the WHOLE 20-step DDIM schedule, `musev_cfg2_loop` = its first 4 steps, `refnet_cfg3_loop` = the first 4
     steps of BASELINE config 3 (`musev_referencenet`: ReferenceNet features + IP-Adapter image tokens as loop-constant side
-    inputs), `refnet_cfg3_loop20` = config 3's whole 20-step schedule.  Asserted: free-running
+    inputs), `refnet_cfg3_loop20` = config 3's whole 20-step schedule, `refnet_pose_cfg5_loop` = the first 4 steps at config 5's
+    resolution and side inputs (768x768 px: 96x96 latents; ReferenceNet features, IP-Adapter tokens, ControlNet residuals on every skip
+    + mid block, PoseGuider embedding) with the residuals scaled differently in the two CFG halves -- a stress case: the halves' rounding
+    errors decorrelate, guidance amplifies them (3.5 e_c - 2.5 e_u) instead of cancelling their common part, and the FREE-RUNNING error
+    leaves 1e-2 from the third step on (measured 3.7e-3 / 7.3e-3 / 1.04e-2 / 1.34e-2, profiles/r05l_cfg5_loop.log; the forward's error
+    is config 2's: rms 4.9e-4, profiles/r05n_attribution_cfg5.log): asserted there: every step from the reference's latents < 1e-2,
+    free-running < 2e-2 --, `refnet_pose_cfg5_loop_sym` = the same with identical residuals in the two halves (what a ControlNet fed one
+    control image produces up to its text input), `musev_cfg2_loop20_w12_g035` = config 2's whole schedule on ANOTHER fixture (weight seed 12,
+    calibrate_as_denoiser(random_gain=0.35): twice the share of the random network in the prediction).  Asserted: free-running
     ABSOLUTE |delta latent|max < 1e-2 at EVERY step (the metric's output bar; the two-fp16 carry on the residual stream is what
     makes it reachable, profiles/r04b_loop_rounding_ensemble.json); every step started from the reference's latents < 1e-2; the
     graph replay is bit-identical."""
@@ -346,14 +355,16 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     os.makedirs(out_dir, exist_ok=True)
     from musev_amd import ops
     with open(os.path.join(out_dir, f"loop_at_size_{name}.json"), "w") as f:
-        json.dump({"case": name, "config": ("BASELINE config 3: musev_referencenet + IP-Adapter tokens + ReferenceNet features" if case["flavour"] != "musev"
-                                            else "BASELINE config 2: musev") + ", 512x512, 12 + 1 frames, guidance 3.5, 20-step DDIM schedule",
+        json.dump({"case": name, "config": (("BASELINE config 5 inputs: musev_referencenet_pose (ReferenceNet features, IP-Adapter tokens, ControlNet residuals, PoseGuider embedding)"
+                                             if case.get("pose") else "BASELINE config 3: musev_referencenet + IP-Adapter tokens + ReferenceNet features") if case["flavour"] != "musev"
+                                            else "BASELINE config 2: musev") + f", {8 * case['h']}x{8 * case['w']}, 12 + 1 frames, guidance 3.5, 20-step DDIM schedule"
+                                           + (f", fixture {case['calib']} weight seed {case['weight_seed']}" if case.get("calib") else ""),
                    "golden": "oracle loop around the reference's own UNet3DConditionModel, fp32 CPU (tests/golden/make_loop_goldens.py)",
                    "carry": bool(ops.CARRY), "colstats": bool(ops.COLSTATS), "ln_fold": bool(ops.LN_FOLD),
                    "free_running_abs_max": errs, "per_step_from_reference_latents": forced,
                    "latent_absmax": [float(np.abs(gold[f"latents_step{i + 1}"]).max()) for i in range(case["steps"])]}, f, indent=1)
     assert max(forced) < 1e-2, forced
-    assert max(errs) < FREE_RUNNING_BAR, errs
+    assert max(errs) < (2e-2 if name == "refnet_pose_cfg5_loop" else FREE_RUNNING_BAR), errs
 
 
 def test_odd_unit_lane_is_bit_identical_to_running_the_groups_in_turn(monkeypatch):
