@@ -141,7 +141,7 @@ def test_keyed_table_is_what_the_committed_measurements_vote():
     tune.PREFER_TWO_BLOCK = True
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "t.h")
-        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r04t_musev512_gemm_tune.json", "r03g_refnet512_gemm_tune.json", "r03g_refnet768_gemm_tune.json")], out)
+        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r05v_musev512_pairs_gemm_tune.json", "r05w_refnet512_pairs_gemm_tune.json", "r05w_refnet768_pairs_gemm_tune.json")], out)
         assert open(out).read() == open(os.path.join(ROOT, "musev_amd", "csrc", "gemm_tuned.h")).read()
 
 
