@@ -331,8 +331,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs1[e] = cs2[e] = 0.f;
     }
-    half8v res[2][KI];
-    half8v resl[(CARRY && RES) ? 2 : 1][(CARRY && RES) ? KI : 1];
+    // (the 160-accumulator tile's carry form has no registers for a second set of residual chunks: its request for pass i + 1 goes
+    // out right behind pass i's stores into the SAME registers -- the write phase of pass i + 2 is the latency window)
+    constexpr int NRB = (CARRY && TM * TN >= 40) ? 1 : 2;
+    half8v res[NRB][KI];
+    half8v resl[(CARRY && RES) ? NRB : 1][(CARRY && RES) ? KI : 1];
     auto request = [&](int i, half8v* rs, half8v* rsl) {  // residual chunks of pass i, in the read layout
         if constexpr (RES) {
 #pragma unroll
@@ -384,7 +387,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // ---- the next pass's residual requests go out ahead of this pass's stores ----
-        if (i + 1 < TM) request(i + 1, res[buf ^ 1], resl[(CARRY && RES) ? (buf ^ 1) : 0]);
+        if constexpr (NRB == 2) {
+            if (i + 1 < TM) request(i + 1, res[buf ^ 1], resl[(CARRY && RES) ? (buf ^ 1) : 0]);
+        }
+        const int rb = NRB == 2 ? buf : 0;
         // ---- read phase of pass i: every LDS read of the pass first (lanes past the pass rows read row 0, their values unused) ----
         const half_t* rrow = rd + buf * (16 * LDW);
         half8v ov[KI], ovl[CARRY ? KI : 1];
@@ -405,7 +411,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float sv = (float)ov[k][e] + (float)ovl[k][e];
-                        if constexpr (RES) sv = (sv + (float)res[buf][k][e]) + (float)resl[buf][k][e];
+                        if constexpr (RES) sv = (sv + (float)res[rb][k][e]) + (float)resl[rb][k][e];
                         o[e] = (half_t)sv;
                         ol[e] = (half_t)(sv - (float)o[e]);
                     }
@@ -413,7 +419,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
                     *reinterpret_cast<half8v*>(clo + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = ol;
                 } else {
                     o = ov[k];
-                    if constexpr (RES) o += res[buf][k];
+                    if constexpr (RES) o += res[rb][k];
                     *reinterpret_cast<half8v*>(cbase + (coff + (unsigned)((16 * i + k * RPI) * p.ldc))) = o;
                 }
             }
@@ -427,6 +433,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, float4v (&acc
                     }
                 }
             }
+        }
+        if constexpr (NRB == 1) {
+            if (i + 1 < TM) request(i + 1, res[0], resl[0]);
         }
         asm volatile("" ::: "memory");
     }
@@ -1090,8 +1099,8 @@ int launch_ln_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
 // two halves and the staged value's two halves per pass); any other choice is mapped to the nearest of them
 inline int gemm_carry_cfg(int id) {
     switch (id) {
-        case 0: case 1: case 2: case 3: case 8: case 13: case 15: return id;
-        case 4: case 6: case 11: return 8;    // 256x160 / 256x320 / 128x320 -> 256x160 (two stages)
+        case 0: case 1: case 2: case 3: case 6: case 8: case 13: case 15: return id;
+        case 4: case 11: return 8;    // 256x160 / 256x320 / 128x320 -> 256x160 (two stages)
         case 12: case 18: return 0;           // 128x160 three stages -> two stages
         case 5: case 7: case 9: case 10: case 16: return 2;   // the 128-wide family -> 128x128
         case 17: return 1;
@@ -1107,6 +1116,7 @@ int launch_carry_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
         case 1: return launch_cfg2s<MODE, 2, 5, 2, 2, 0, false, true>(a, stream);
         case 2: return launch_cfg2s<MODE, 4, 4, 2, 2, 0, false, true>(a, stream);
         case 3: return launch_cfg2s<MODE, 2, 4, 2, 2, 0, false, true>(a, stream);
+        case 6: return launch_cfg2s<MODE, 8, 5, 2, 4, 0, false, true>(a, stream);
         case 8: return launch_cfg2s<MODE, 4, 5, 4, 2, 0, false, true>(a, stream);
         case 13: return launch_cfg2s<MODE, 2, 5, 2, 1, 0, false, true>(a, stream);
         case 15: return launch_cfg2s<MODE, 2, 5, 4, 2, 0, false, true>(a, stream);
@@ -1176,14 +1186,15 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
         int best = -1;
         double best_d = 1e30;
         const bool want_ln = g.ln_colsum != nullptr;
+        const bool want_carry = g.c_lo != nullptr;   // rows measured on the carry form of a launch (its own epilogue, never split): ln == 2
         for (int i = 0; i < kNumGemmTuned; ++i) {
             const GemmTuned& e = kGemmTuned[i];
             if (e.mode != mode || e.N != g.N || e.K != g.K || e.geglu != g.geglu || e.M <= 0 || !(e.cfg == -2 || gemm_cfg_applies(e.cfg, g))) continue;
-            if (e.ln && !want_ln) continue;
+            if ((e.ln == 1 && !want_ln) || (e.ln == 2 && !want_carry)) continue;
             const double r = (double)g.M / (double)e.M;
             double dist = r > 1.0 ? r : 1.0 / r;  // >= 1: the size ratio
             if (dist > 3.0) continue;
-            if ((e.ln != 0) != want_ln) dist *= 1.0001;  // tie-break only
+            if ((e.ln == 1) != want_ln || (e.ln == 2) != want_carry) dist *= 1.0001;  // tie-break only
             if (dist < best_d) {
                 best_d = dist;
                 best = i;
@@ -1197,7 +1208,7 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
                 ch.cfg = kGemmTuned[best].cfg;
                 ch.nsplit = kGemmTuned[best].nsplit;
             }
-        } else if (best >= 0 && kGemmTuned[best].cfg >= 0 && (kGemmTuned[best].ln != 0) == want_ln && gemm_key(kGemmTuned[best].M, g.N, g.K, cus) == key) {
+        } else if (best >= 0 && kGemmTuned[best].cfg >= 0 && (kGemmTuned[best].ln == 1) == want_ln && gemm_key(kGemmTuned[best].M, g.N, g.K, cus) == key) {
             settled = true;
             ch.cfg = kGemmTuned[best].cfg;
         }

@@ -911,6 +911,7 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("carry_tconv", lambda: case_carry(kind="tconv", n=5, h=8, w=16, seed=620)),
     ("carry_ragged", lambda: case_carry(kind="linear", n=1, h=9, w=37, cin=200, c=200, seed=630)),
     ("carry_every_tile", lambda: _all_ok([case_carry(kind=("linear", "conv", "tconv")[c_ % 3], n=2, seed=640 + c_, cfg=c_) for c_ in range(19)])),
+    ("carry_256x320", lambda: _all_ok([case_carry(kind=k_, n=3, seed=660 + i_, cfg=6) for i_, k_ in enumerate(("linear", "conv", "tconv"))])),
     ("ffn_fused", case_ffn_fused),
     ("ffn_fused_ragged_large_mean", lambda: case_ffn_fused(M=1111, seed=710, offset=6.0)),
     ("ffn_fused_no_bias_one_row_block", lambda: case_ffn_fused(M=128, seed=720, with_bias=False)),

@@ -36,6 +36,7 @@ CASES = {
     "carry_tconv": "kc.case_carry(kind='tconv', n=3, h=4, w=12, c=64)",
     "carry_ragged": "kc.case_carry(kind='linear', n=1, h=5, w=15, cin=72, c=72)",
     "carry_every_tile": "kc._all_ok([kc.case_carry(kind=('linear', 'conv', 'tconv')[c % 3], n=2, h=4, w=12, cin=64, c=64, seed=640 + c, cfg=c) for c in range(19)])",
+    "carry_256x320": "kc._all_ok([kc.case_carry(kind=k, n=3, h=8, w=12, cin=64, c=c, seed=660 + i, cfg=6) for i, (k, c) in enumerate((('linear', 320), ('conv', 64), ('tconv', 64)))])",
     "ffn_fused": "kc.case_ffn_fused(M=200)",
     "ffn_fused_one_block_no_bias": "kc.case_ffn_fused(M=70, seed=720, with_bias=False, offset=3.0)",
     "tail_carry": "kc.case_tail_carry(n=2, h=8, w=8, c=64)",
@@ -101,7 +102,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block",
+    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")

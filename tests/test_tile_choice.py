@@ -55,13 +55,13 @@ def _mirror(rows, keyed, configs, mode, M, N, K, geglu, ln):
     best, best_d = None, 1e30
     for (m, eM, eN, eK, eg, eln, cfg, ns) in rows:
         e = dict(mode=study_mode(m), M=eM, N=eN, K=eK, geglu=eg, ln=eln)
-        if m != mode or eN != N or eK != K or eg != geglu or not (cfg == -2 or study.applies(p, cfg, configs)) or (eln and not ln):
+        if m != mode or eN != N or eK != K or eg != geglu or not (cfg == -2 or study.applies(p, cfg, configs)) or (eln == 1 and not ln) or eln == 2:   # (ln == 2: rows of carry launches, not probed here)
             continue
         r = M / eM
         d = r if r > 1 else 1 / r
         if d > 3.0:
             continue
-        if bool(eln) != bool(ln):
+        if (eln == 1) != bool(ln):
             d *= 1.0001
         if d < best_d:
             best, best_d = (e, cfg, ns), d
@@ -105,6 +105,8 @@ def test_unseen_sizes_follow_the_studied_lookup_order():
     checked = steps = 0
     seen = {"table": 0, "bucket": 0, "keyed": 0}
     for (mode, M, N, K, geglu, ln, cfg, ns) in rows:
+        if ln == 2:
+            continue
         for hw_scale, frames in ((1.0, 13), (0.625, 13), (1.0, 9), (2.25, 13), (0.25, 13), (1.0, 26)):
             # the layer at another resolution (512 x 320: x 0.625 pixels; 768^2 from 512^2: x 2.25) or window length (8 + 1 frames)
             base_frames = 26 if M % 26 == 0 and (M // 26) >= 25 and mode != 2 else 13
@@ -141,7 +143,7 @@ def test_keyed_table_is_what_the_committed_measurements_vote():
     tune.PREFER_TWO_BLOCK = True
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "t.h")
-        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r05v_musev512_pairs_gemm_tune.json", "r05w_refnet512_pairs_gemm_tune.json", "r05w_refnet768_pairs_gemm_tune.json")], out)
+        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r05y_musev512_pairs_gemm_tune.json", "r05y_refnet512_pairs_gemm_tune.json", "r05y_refnet768_pairs_gemm_tune.json")], out)
         assert open(out).read() == open(os.path.join(ROOT, "musev_amd", "csrc", "gemm_tuned.h")).read()
 
 
