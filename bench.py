@@ -571,6 +571,10 @@ def main():
             "traffic_source": measured_traffic(workload)[1],
             "method": f"one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 / mv_temporal_attn_block_f16 launches re-issued back to back on one stream, {reps} repetitions between "
                       "one HIP event pair (device time; no per-launch host gap)",
+            # (round 5) the tile table is measured on concurrent PAIRS of launches -- how the timed step runs the CFG halves -- so an
+            # ISOLATED launch is not the fastest the library could make it: `achieved` is the isolated figure (what rocprofv3's
+            # serialised kernel durations reproduce), `two_streams` the same launches as the step runs them
+            "note": "achieved = isolated launches on one stream; the tile table is tuned for the step's two concurrent streams (see two_streams)",
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
             "launches_per_step": fam_n * rec_scale,
             "recorded_windows": (f"1 of {n_windows} (every window issues the same launches; per-step figures = the recorded window x {n_windows})"
