@@ -160,3 +160,13 @@ def test_bench_two_ranks_over_gloo_emits_the_multi_gpu_block():
     assert len(m["per_rank_exposed_exchange_ms_per_step"]) == 2 and m["per_rank_units"] == [2, 2]
     assert rec["config"]["windows"] == 2 and rec["config"]["units_per_gpu_max"] == 2 and rec["config"]["ideal_speedup_vs_1gpu_same_workload"] == 2.0
     assert rec["value"] > 0 and rec["config"]["output_finite"] is True
+
+
+def test_committed_pmc_traffic_is_a_measurement_of_the_shipping_kernel_sources():
+    """roofline.traffic comes from profiles/hbm_traffic.json, which is bound to the hash of the kernel sources it was measured on
+    (bench.measured_traffic): a tree whose kernels changed after the last PMC pass -- or a file bench.py cannot read -- would report
+    `traffic: null` on the driver's box.  Re-run tools/gpu_final_profile.sh and commit the summary when this fails."""
+    import bench
+    per_step, source = bench.measured_traffic("config2")
+    assert per_step is not None, source
+    assert 40e9 < per_step < 150e9 and "pmc_summary.json" in source
