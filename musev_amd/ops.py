@@ -410,14 +410,19 @@ def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], rep
 
 # LayerNorm folding (A/B: MUSEV_OPS="LN_FOLD=0" keeps mv_layernorm_f16 + the plain projection everywhere)
 LN_FOLD: bool = True
+# ... and only for projections with K <= LN_FOLD_MAX_K: beside the pair-timed tile table (round 5) the 1 280-wide levels run faster as
+# mv_layernorm_f16 + a plain projection on a 256 x 256 / 256 x 320 tile than folded (the folded tiles stop at 256 x 256 and carry the
+# in-loop row statistics): same-box alternating legs 49.65 -> 49.27 ms per config-2 step at 640, 49.35 with no folding at all
+# (profiles/r05zf_ab_lnfold{,2}.log; per launch of a pair 32 against 39 us at 3 328 x 3 840 x 1 280)
+LN_FOLD_MAX_K: int = 640
 _ln_fold_cache: dict = {}
 
 
 def ln_fold_applies(M: int, N: int, K: int, geglu: bool) -> bool:
     """whether ``gemm(..., ln=)`` is the better form of LayerNorm + projection for this problem: it is wherever the plain
     projection runs as ONE K slice (the folded kernel needs the whole row in one block's K loop); the small-M / long-K problems
-    the library splits over K keep mv_layernorm_f16 + the split GEMM."""
-    if not LN_FOLD or K % 64 != 0 or geglu:
+    the library splits over K keep mv_layernorm_f16 + the split GEMM, and so do the levels wider than LN_FOLD_MAX_K (above)."""
+    if not LN_FOLD or K % 64 != 0 or geglu or K > LN_FOLD_MAX_K:
         # (GEGLU: the gate's epilogue already bounds that launch -- folded it measured 4-11 % SLOWER than LayerNorm + GEMM at every
         # level, profiles/r03e_ln_fold_variants.log; the q / k / v projections gain 5-44 %.  Row statistics emitted by the PRODUCER's
         # epilogue instead of the in-loop ones -- which would also let the GEGLU launch fold -- measured +0.6 ms per step:
@@ -888,7 +893,7 @@ def _apply_env_overrides() -> None:
     for item in filter(None, (x.strip() for x in spec.split(","))):
         name, _, val = item.partition("=")
         if name not in ("COLSTATS", "CARRY", "CARRY_MAX_C", "FFN_FUSED", "FFN_ROTATE", "LN_FOLD", "ATTN_GROUPS", "XATTN_RESIDENT",
-                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED"):
+                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K"):
             raise ValueError(f"MUSEV_OPS: unknown switch {name!r}")
         cur = globals()[name]
         globals()[name] = bool(int(val)) if isinstance(cur, bool) else int(val)

@@ -143,7 +143,7 @@ def test_keyed_table_is_what_the_committed_measurements_vote():
     tune.PREFER_TWO_BLOCK = True
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "t.h")
-        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r05y_musev512_pairs_gemm_tune.json", "r05y_refnet512_pairs_gemm_tune.json", "r05y_refnet768_pairs_gemm_tune.json")], out)
+        tune.merge([os.path.join(ROOT, "profiles", f) for f in ("r05y_musev512_pairs_gemm_tune.json", "r05zf_musev512_lnfold0_pairs_gemm_tune.json", "r05y_refnet512_pairs_gemm_tune.json", "r05y_refnet768_pairs_gemm_tune.json")], out)
         assert open(out).read() == open(os.path.join(ROOT, "musev_amd", "csrc", "gemm_tuned.h")).read()
 
 

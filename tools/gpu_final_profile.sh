@@ -6,7 +6,7 @@
 #   3. bench lines WITH the roofline block for configs 3 and 5
 #   4. tools/gpu_sq_counters.sh: SQ counter passes (MFMA busy / VALU / LDS / waits per kernel)
 set -u
-TAG=${1:-r05zz}
+TAG=${1:-r05final}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
