@@ -44,7 +44,7 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_CFG    -1 = measured per-shape table, then rules (default); -2 = rules only; >= 0 = that catalogue id
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 #   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
-#                      COLSTATS, CARRY, FFN_FUSED, TSA_FUSED, LN_FOLD, ATTN_GROUPS, XATTN_RESIDENT, GEMM_WEIGHT_STATIONARY); applied at the
+#                      COLSTATS, CARRY, FFN_FUSED, TSA_FUSED, LN_FOLD, LN_FOLD_MAX_K, ATTN_GROUPS, XATTN_RESIDENT, GEMM_WEIGHT_STATIONARY); applied at the
 #                      bottom of this file
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
