@@ -1096,11 +1096,12 @@ int launch_ln_by_id(const GemmArgs2& a, hipStream_t stream, int id) {
 }
 
 // Carry launches (GemmArgs::c_lo): the two-stage tiles of up to 80 accumulators per lane (the carry's epilogue holds the residual's
-// two halves and the staged value's two halves per pass); any other choice is mapped to the nearest of them
+// two halves and the staged value's two halves per pass) and, since round 5, the 160-accumulator 256x320 tile with ONE set of residual
+// registers (epilogue_staged: NRB); any other choice is mapped to the nearest of them
 inline int gemm_carry_cfg(int id) {
     switch (id) {
         case 0: case 1: case 2: case 3: case 6: case 8: case 13: case 15: return id;
-        case 4: case 11: return 8;    // 256x160 / 256x320 / 128x320 -> 256x160 (two stages)
+        case 4: case 11: return 8;    // 256x160 three stages / 128x320 -> 256x160 (two stages)
         case 12: case 18: return 0;           // 128x160 three stages -> two stages
         case 5: case 7: case 9: case 10: case 16: return 2;   // the 128-wide family -> 128x128
         case 17: return 1;
