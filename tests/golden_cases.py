@@ -221,6 +221,10 @@ LOOP_CASES_AT_SIZE = {
     "musev_cfg2_loop20_w12_g035": dict(flavour="musev", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=12, latent_seed=41, cond_seed=42,
                                        prompt_seed=43, guidance_scale=3.5, num_inference_steps=20, steps=20, context_frames=12, context_overlap=4,
                                        calib=dict(random_gain=0.35)),
+    # ... and config 3 (ReferenceNet features + IP-Adapter tokens) on another fixture as well: weight seed 13, random share 0.35, 20 steps
+    "refnet_cfg3_loop20_w13_g035": dict(flavour="musev_referencenet", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=13, latent_seed=44,
+                                        cond_seed=45, prompt_seed=46, side_seed=47, guidance_scale=3.5, num_inference_steps=20, steps=20,
+                                        context_frames=12, context_overlap=4, calib=dict(random_gain=0.35)),
     "refnet_pose_cfg5_loop": dict(flavour="musev_referencenet", arch={}, T=12, h=96, w=96, n_cond=1, weight_seed=11, latent_seed=37, cond_seed=38,
                                   prompt_seed=39, side_seed=40, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
                                   context_overlap=4, controlnet=True, pose=True),

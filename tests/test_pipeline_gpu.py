@@ -283,7 +283,7 @@ def test_twenty_step_drift_against_fp16_torch_floor():
 
 
 @pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop", "refnet_cfg3_loop20", "refnet_pose_cfg5_loop",
-                                  "refnet_pose_cfg5_loop_sym", "musev_cfg2_loop20_w12_g035"])
+                                  "refnet_pose_cfg5_loop_sym", "musev_cfg2_loop20_w12_g035", "refnet_cfg3_loop20_w13_g035"])
 def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, full-width
     `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the HIP loop against those recorded by
@@ -298,7 +298,8 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     is config 2's: rms 4.9e-4, profiles/r05n_attribution_cfg5.log): asserted there: every step from the reference's latents < 1e-2,
     free-running < 2e-2 --, `refnet_pose_cfg5_loop_sym` = the same with identical residuals in the two halves (what a ControlNet fed one
     control image produces up to its text input), `musev_cfg2_loop20_w12_g035` = config 2's whole schedule on ANOTHER fixture (weight seed 12,
-    calibrate_as_denoiser(random_gain=0.35): twice the share of the random network in the prediction).  Asserted: free-running
+    calibrate_as_denoiser(random_gain=0.35): twice the share of the random network in the prediction), `refnet_cfg3_loop20_w13_g035` = the
+    same for config 3 (weight seed 13).  Asserted: free-running
     ABSOLUTE |delta latent|max < 1e-2 at EVERY step (the metric's output bar; the two-fp16 carry on the residual stream is what
     makes it reachable, profiles/r04b_loop_rounding_ensemble.json); every step started from the reference's latents < 1e-2; the
     graph replay is bit-identical."""
