@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 10
+#define MV_ABI_VERSION 11
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -328,9 +328,16 @@ int mv_bthwc_to_bcthw_f16(const void* x, int32_t x_is_f32, void* y, int32_t y_is
  * latents: fp32 [C][T_total][HW] (batch 1), cond: fp32 [C][n_cond][HW].
  * hi_lo = 1: rows of 2 C columns [fp16(v) | fp16(v - fp16(v))]: the fp32 latents as two fp16 halves -- conv_in with its weight
  *   duplicated over the two channel groups then convolves the unrounded input (conv is linear).
+ * cond_slot (ABI 11; int32 [n_cond] on the device, or NULL = condition frame k in slot k): the window slot of every condition frame
+ *   = the reference's `vision_condition_latent_index` (prepare_condition_latents_and_index, pipeline_controlnet.py:966-1040; -1 ->
+ *   the last of the n_cond + video_length frames, :995-1003).  As in batch_concat_two_tensor_with_index (data_util.py:242-268, call
+ *   site :1939-1946) the condition frames are written into a zero tensor first and the window's frames at n_cond.. afterwards: a
+ *   slot < n_cond no condition frame names stays ZERO, a condition frame whose slot is >= n_cond is overwritten by the window's
+ *   frame there.  The caller checks 0 <= cond_slot[k] < n_cond + win (torch raises IndexError otherwise).
  */
-int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
-                     int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, int32_t hi_lo, void* out, void* stream);
+int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, const int32_t* cond_slot, int32_t win,
+                     int32_t n_cond, int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, int32_t hi_lo, void* out,
+                     void* stream);
 /* mv_window_scatter_add: eps_acc[half][C][T_total][HW] += eps_win (channels-last fp16|fp32 [halves][n_cond+win][HW][C],
  *   cond frames dropped); counter[T_total] += 1.
  * replaces: pipeline_controlnet.py:2068-2078. */

@@ -266,9 +266,12 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const half_t* x
 }
 
 // ---- sliding-window loop glue ----
-// out: channels-last fp16 [copies][n_cond + win][hw][c]; frame f < n_cond from cond[c][n_cond][hw], else latents[:, idx[f-n_cond]]
-__global__ void window_gather_kernel(const float* latents, const float* cond, const int* idx, int win, int n_cond, int c,
-                                     int t_total, int hw, int copies, int hi_lo, half_t* out) {
+// out: channels-last fp16 [copies][n_cond + win][hw][c]; frame f < n_cond from cond[c][n_cond][hw], else latents[:, idx[f-n_cond]].
+// cond_slot (optional, [n_cond]): the window slot of every condition frame (the reference's vision_condition_latent_index, written
+// FIRST into a zero tensor and then overwritten by the window's frames at n_cond.., pipeline_controlnet.py:1939-1946): slot f <
+// n_cond holds cond frame k where cond_slot[k] == f, zeros where no k does; slots >= n_cond always hold the window's frames.
+__global__ void window_gather_kernel(const float* latents, const float* cond, const int* idx, const int* cond_slot, int win, int n_cond,
+                                     int c, int t_total, int hw, int copies, int hi_lo, half_t* out) {
     const int tw = n_cond + win;
     const long per = (long)tw * hw * c;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
@@ -277,8 +280,17 @@ __global__ void window_gather_kernel(const float* latents, const float* cond, co
         const int p = (int)(r % hw);
         const int f = (int)(r / hw);
         float v;
-        if (f < n_cond) v = cond[((long)ci * n_cond + f) * hw + p];
-        else v = latents[((long)ci * t_total + idx[f - n_cond]) * hw + p];
+        if (f < n_cond) {
+            int k = f;
+            if (cond_slot) {
+                k = -1;
+                for (int q = 0; q < n_cond; ++q)
+                    if (cond_slot[q] == f) k = q;
+            }
+            v = k < 0 ? 0.f : cond[((long)ci * n_cond + k) * hw + p];
+        } else {
+            v = latents[((long)ci * t_total + idx[f - n_cond]) * hw + p];
+        }
         const half_t hv = (half_t)v;
         if (hi_lo) {  // rows of 2 c columns: [hi | lo]
             const half_t lv = (half_t)(v - (float)hv);
@@ -642,12 +654,13 @@ extern "C" int mv_conv3x3_cout_small_f16(const void* x, const void* x_lo, int32_
     return MV_OK;
 }
 
-extern "C" int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, int32_t win, int32_t n_cond,
-                                int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, int32_t hi_lo, void* out, void* stream) {
+extern "C" int mv_window_gather(const float* latents, const float* cond, const int32_t* idx, const int32_t* cond_slot, int32_t win,
+                                int32_t n_cond, int32_t c, int32_t t_total, int32_t hw, int32_t cfg_copies, int32_t hi_lo, void* out,
+                                void* stream) {
     MV_REQUIRE(latents && idx && out && win > 0 && n_cond >= 0 && (n_cond == 0 || cond) && c > 0 && t_total > 0 && hw > 0 && cfg_copies > 0,
                "mv_window_gather: bad args");
     hipLaunchKernelGGL(window_gather_kernel, dim3(grid_for((long)(n_cond + win) * hw * c)), dim3(kBlock), 0, (hipStream_t)stream,
-                       latents, cond, idx, win, n_cond, c, t_total, hw, cfg_copies, hi_lo, (half_t*)out);
+                       latents, cond, idx, cond_slot, win, n_cond, c, t_total, hw, cfg_copies, hi_lo, (half_t*)out);
     MV_CHECK_LAUNCH("mv_window_gather");
     return MV_OK;
 }

@@ -793,15 +793,20 @@ def bthwc_to_bcthw(x: torch.Tensor, b: int, t: int, h: int, w: int, dtype=torch.
 
 
 def window_gather(latents: torch.Tensor, cond: Optional[torch.Tensor], idx: torch.Tensor, n_cond: int, copies: int,
-                  hi_lo: bool = False) -> torch.Tensor:
+                  hi_lo: bool = False, cond_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """latents fp32 [C, T_total, HW]; cond fp32 [C, n_cond, HW]; idx int32 [win] -> fp16 [copies*(n_cond+win)*HW, C].
+    ``cond_slot`` int32 [n_cond] (device): the window slot of every condition frame (the reference's vision_condition_latent_index;
+    None = in front).  Slots < n_cond that no condition frame names are zero, the window's frames always fill n_cond.. (see
+    include/musev_hip.h).
     ``hi_lo``: rows of 2 C columns [fp16(v) | fp16(v - fp16(v))] -- the fp32 latents as two fp16 halves (the UNet's conv_in takes
     them with its weight duplicated over the two channel groups: the input is not rounded to fp16, see CARRY)."""
     c, t_total, hw = latents.shape
     win = idx.numel()
     out = torch.empty((copies * (n_cond + win) * hw, 2 * c if hi_lo else c), dtype=torch.float16, device=latents.device)
-    check(_lib.load().mv_window_gather(latents.data_ptr(), _p(cond), idx.data_ptr(), win, n_cond, c, t_total, hw, copies, int(hi_lo),
-                                       out.data_ptr(), _stream()), "mv_window_gather")
+    if cond_slot is not None and (cond_slot.dtype != torch.int32 or cond_slot.numel() != n_cond or not cond_slot.is_contiguous()):
+        raise ValueError("window_gather: cond_slot must be contiguous int32 [n_cond]")
+    check(_lib.load().mv_window_gather(latents.data_ptr(), _p(cond), idx.data_ptr(), _p(cond_slot), win, n_cond, c, t_total, hw, copies,
+                                       int(hi_lo), out.data_ptr(), _stream()), "mv_window_gather")
     return out
 
 

@@ -113,7 +113,8 @@ class ParallelDenoiser:
                  guidance_scale_method: str = "linear", generator=None, noise_type: str = "random",
                  w_ind_noise: float = 0.5, controlnet=None, control_image: Optional[torch.Tensor] = None,
                  controlnet_conditioning_scale: float = 1.0, control_guidance_start: float = 0.0,
-                 control_guidance_end: float = 1.0, guess_mode: bool = False, start_step: int = 0) -> torch.Tensor:
+                 control_guidance_end: float = 1.0, guess_mode: bool = False, start_step: int = 0,
+                 vision_condition_latent_index: Optional[Sequence[int]] = None) -> torch.Tensor:
         """latents [1, c, T, h, w] (frames to generate, any float dtype, on the GPU); prompt_embeds [2, L, D] =
         [negative, positive] (or [1, L, D] when guidance_scale <= 1); condition_latents [1, c, n_cond, h, w] or None.
         ``group``: torch.distributed process group to shard the units over (None = this process alone).
@@ -129,7 +130,15 @@ class ParallelDenoiser:
         ``max_steps``: run only the first max_steps steps of the num_inference_steps-long schedule (smoke / bench helper).
         ``start_step``: enter the schedule at this step with ``latents`` being the latents of that step (what the reference's
         ``get_timesteps(strength)`` does for img2img starts, :1613-1622; the parity tests use it to start a step from recorded latents).
-        Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted in front, reference :2149-2156)."""
+        ``vision_condition_latent_index``: where the condition frames sit among the n_cond + T output frames, -1 = the last one
+        (prepare_condition_latents_and_index, :966-1040; the CLI's ``condition_images_index``); None = in front.  The reference's
+        literal behaviour is reproduced (tests/golden/reference_condition_index.json): the final re-insert (:2149-2156) uses these
+        positions, but every WINDOW's input is built by writing the condition latents at the same GLOBAL positions into a zero tensor
+        of n_cond + win frames and the window's frames at n_cond.. afterwards (:1914-1946) -- a position outside a window's
+        n_cond + win slots raises IndexError as torch's index_copy_ does (any run with more than one window and a -1), a tail
+        condition frame is overwritten by the window's last frame and the slot it would have had in front stays zero, while the
+        UNet is told that the given positions hold the condition frames (temb zeroing, reference-only attention).
+        Returns fp32 latents [1, c, n_cond + T, h, w] (condition frames re-inserted at their positions, in front by default)."""
         if latents.ndim != 5 or latents.shape[0] != 1:
             raise ValueError("latents must be [1, c, T, h, w]")
         if self._device_check and not latents.is_cuda:
@@ -204,7 +213,24 @@ class ParallelDenoiser:
                         tab[hf, f, q, 0], tab[hf, f, q, 1] = slot_, j
             cover = tab.to(dev)
 
-        vis_idx = list(range(n_cond)) if n_cond else None  # host ints (vision_condition_latent_index, :1914-1920)
+        # vision_condition_latent_index / latent_index as prepare_condition_latents_and_index builds them (:995-1029)
+        vis_idx, latent_index, cond_slot = None, None, None
+        if n_cond:
+            total_frames = n_cond + T
+            vis_idx = (list(range(n_cond)) if vision_condition_latent_index is None
+                       else [int(i) if int(i) != -1 else total_frames - 1 for i in vision_condition_latent_index])
+            if len(vis_idx) != n_cond:
+                raise IndexError(f"vision_condition_latent_index names {len(vis_idx)} positions for {n_cond} condition frames")
+            if len(set(vis_idx)) != n_cond:
+                raise ValueError("vision_condition_latent_index visits a position twice (index_copy_ is undefined there)")
+            for wd in wins:
+                if min(vis_idx) < 0 or max(vis_idx) >= n_cond + len(wd):
+                    # index_copy_ into the window's n_cond + win slots (data_util.py:457): the reference fails here as well
+                    raise IndexError(f"vision-condition position {max(vis_idx)} is outside a window's {n_cond + len(wd)} input frames "
+                                     "(the reference scatters GLOBAL positions into every window's input, pipeline_controlnet.py:1939-1946)")
+            latent_index = sorted(set(range(total_frames)) - set(vis_idx))
+            if vis_idx != list(range(n_cond)):
+                cond_slot = torch.tensor(vis_idx, dtype=torch.int32, device=dev)
         # sub_latent_index_c = arange(len(window)) + n_cond (:1914-1920), one tensor per distinct window length
         sub_idx_by_len = {n: ((torch.arange(n, dtype=torch.long, device=dev) + n_cond) if n_cond else None)
                           for n in sorted({len(wd) for wd in wins})}
@@ -228,7 +254,7 @@ class ParallelDenoiser:
             frames_all = control_image[0].to(dev).permute(1, 0, 2, 3)  # [n_cond + T, c, H, W]
             ctrl_frames = []
             for wd in wins:  # controlnet_context = condition indices + (window indices + n_cond)   (:1953-1961)
-                sel = torch.tensor(list(range(n_cond)) + [i + n_cond for i in wd], dtype=torch.long, device=dev)
+                sel = torch.tensor((vis_idx or []) + [i + n_cond for i in wd], dtype=torch.long, device=dev)
                 ctrl_frames.append(frames_all.index_select(0, sel).to(torch.float16).contiguous())
             # static buffers (one per window length): the captured graphs read the window's frames from here
             ctrl_bufs = {n: torch.empty_like(next(f for f, wd in zip(ctrl_frames, wins) if len(wd) == n)) for n in sub_idx_by_len}
@@ -259,7 +285,8 @@ class ParallelDenoiser:
                 wl = len(wins[wi])
                 tw = n_cond + wl
                 # (hi_lo: the fp32 latents as two fp16 halves -- conv_in sees them unrounded, ops.CARRY)
-                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs), hi_lo=ops.CARRY and controlnet is None and 18 * c <= 128)
+                x = ops.window_gather(lat_in, cond, idx_dev[wi], n_cond, len(hs), hi_lo=ops.CARRY and controlnet is None and 18 * c <= 128,
+                                      **({} if cond_slot is None else {"cond_slot": cond_slot}))
                 cn_ = None
                 if controlnet is not None and cn_on:
                     ctrl_bufs[wl].copy_(ctrl_frames[wi])
@@ -330,7 +357,13 @@ class ParallelDenoiser:
 
         out = lat.view(1, c, T, h, w)
         if cond is not None and reinsert_condition:
-            out = torch.cat([cond.view(1, c, n_cond, h, w), out], dim=2)
+            if cond_slot is None:
+                out = torch.cat([cond.view(1, c, n_cond, h, w), out], dim=2)
+            else:  # batch_concat_two_tensor_with_index(condition_latents, vision_condition_latent_index, latents, latent_index) (:2149-2156)
+                full = torch.zeros((1, c, n_cond + T, h, w), dtype=out.dtype, device=dev)
+                full.index_copy_(2, torch.tensor(vis_idx, dtype=torch.long, device=dev), cond.view(1, c, n_cond, h, w))
+                full.index_copy_(2, torch.tensor(latent_index, dtype=torch.long, device=dev), out)
+                out = full
         return out
 
     def _unet_rows(self, x, hs: tuple, halves: int, tw: int, h: int, w: int, t_dev, embeds, sub_idx, vis_idx, motion_speed,

@@ -164,10 +164,15 @@ class MusevControlNetPipeline:
                 raise ValueError("`condition_images` needs vae_encode=callable(images) -> latents; or pass `condition_latents`")
             condition_latents = self.vae_encode(condition_images)
         n_cond = 0 if condition_latents is None else int(condition_latents.shape[2])
-        if vision_condition_latent_index is not None and list(map(int, vision_condition_latent_index)) != list(range(n_cond)):
-            raise NotImplementedError("vision-condition frames anywhere but in front of the generated frames")
-        if latent_index is not None and list(map(int, latent_index)) != list(range(n_cond, n_cond + int(video_length))):
-            raise NotImplementedError("latent_index other than the frames behind the vision-condition frames")
+        # vision_condition_latent_index (-1 = the last of the n_cond + video_length frames, :995-1003) goes to the loop as it is;
+        # latent_index is what the reference derives from it (:1017-1029) -- anything else it would only use for a shape (:1903-1907)
+        vis_given = None if vision_condition_latent_index is None else [int(i) for i in (
+            vision_condition_latent_index.tolist() if torch.is_tensor(vision_condition_latent_index) else vision_condition_latent_index)]
+        if latent_index is not None and n_cond:
+            total_frames = n_cond + int(video_length)
+            vis_res = list(range(n_cond)) if vis_given is None else [i if i != -1 else total_frames - 1 for i in vis_given]
+            if sorted(map(int, latent_index)) != sorted(set(range(total_frames)) - set(vis_res)):
+                raise NotImplementedError("latent_index other than the positions the vision-condition frames leave free")
 
         # ---- scheduler, initial latents (:1613-1676) ----
         den = self._denoiser(context_schedule, context_frames, context_stride, context_overlap, context_batch_size)
@@ -290,7 +295,8 @@ class MusevControlNetPipeline:
                       callback=cb, guidance_scale_end=guidance_scale_end, guidance_scale_method=guidance_scale_method,
                       generator=generator, noise_type=noise_type, w_ind_noise=w_ind_noise, controlnet=controlnet, control_image=ctrl,
                       controlnet_conditioning_scale=float(controlnet_conditioning_scale), control_guidance_start=float(control_guidance_start),
-                      control_guidance_end=float(control_guidance_end), guess_mode=bool(guess_mode), start_step=start_step)
+                      control_guidance_end=float(control_guidance_end), guess_mode=bool(guess_mode), start_step=start_step,
+                      vision_condition_latent_index=vis_given)
         finally:
             if skip_temporal_layer:
                 self.unet.set_skip_temporal_layers(False)                                               # :2175-2176

@@ -208,6 +208,30 @@ def fusion_noise(shape, generator, w_ind_noise: float = 0.5, initial_common_nois
 
 
 # ---- the loop --------------------------------------------------------------------------------------------
+def condition_indices(n_cond: int, video_length: int, vision_condition_latent_index: Optional[Sequence[int]] = None):
+    """prepare_condition_latents_and_index (pipeline_controlnet.py:966-1040), the index part: -1 -> n_cond + video_length - 1
+    (:995-1003), default arange(n_cond) (:1010-1016); latent_index = the remaining positions in ascending order (:1017-1029).
+    Pinned by tests/golden/reference_condition_index.json (the reference's own function executed)."""
+    if not n_cond:
+        return None, None
+    total = n_cond + video_length
+    if vision_condition_latent_index is None:
+        vis = list(range(n_cond))
+    else:
+        vis = [int(i) if int(i) != -1 else total - 1 for i in vision_condition_latent_index]
+    lat = sorted(set(range(total)) - set(vis))
+    return torch.tensor(vis, dtype=torch.long), torch.tensor(lat, dtype=torch.long)
+
+
+def concat_with_index(data1: Tensor, data1_index: Tensor, data2: Tensor, data2_index: Tensor) -> Tensor:
+    """data_util.py:242-268 (batch_concat_two_tensor_with_index, dim = 2): a zero tensor of len1 + len2 frames, data1 copied to its
+    positions, then data2 to its own (a later copy wins; a position out of range raises IndexError)."""
+    full = torch.zeros((data1.shape[0], data1.shape[1], data1.shape[2] + data2.shape[2], *data1.shape[3:]), dtype=data1.dtype)
+    full.index_copy_(2, data1_index, data1)
+    full.index_copy_(2, data2_index, data2)
+    return full
+
+
 def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds: Tensor, *, num_inference_steps: int,
                  guidance_scale: float, condition_latents: Optional[Tensor] = None, context_frames: int = 12,
                  context_overlap: int = 4, context_stride: int = 1, context_schedule: str = "uniform",
@@ -217,8 +241,14 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                  guidance_scale_method: str = "linear", controlnet_fn: Optional[Callable[..., tuple]] = None,
                  control_image: Optional[Tensor] = None, controlnet_conditioning_scale: float = 1.0,
                  control_guidance_start: float = 0.0, control_guidance_end: float = 1.0, guess_mode: bool = False,
-                 record_latents: Optional[list] = None, start_step: int = 0) -> Tensor:
-    """pipeline_controlnet.py:1832-2156.  ``start_step`` (test helper: resume of an interrupted golden run; DDIM at eta 0 carries no
+                 record_latents: Optional[list] = None, start_step: int = 0,
+                 vision_condition_latent_index: Optional[Sequence[int]] = None) -> Tensor:
+    """pipeline_controlnet.py:1832-2156.  ``vision_condition_latent_index`` (prepare_condition_latents_and_index, :966-1040): where
+    the condition frames sit among the n_cond + T output frames, -1 = the last one (:995-1003); None = in front.  The loop scatters
+    the condition latents into every WINDOW's input at these GLOBAL positions and then the window's frames at n_cond.. (:1914-1946,
+    a later index_copy_ wins; a position outside the window's n_cond + win slots raises IndexError as torch does): with [0, -1] and
+    one window the tail condition frame is overwritten by the last generated frame and slot 1 stays zero, while the UNet is still
+    told that slots 0 and n_cond + T - 1 are the condition frames -- the reference's literal behaviour, restated as it is.  ``start_step`` (test helper: resume of an interrupted golden run; DDIM at eta 0 carries no
     state between steps): ``latents`` are the latents AFTER step ``start_step``, the first ``start_step`` schedule entries are skipped.  ``record`` / ``record_latents`` (test helpers): per-step guided noise prediction / latents.  ``max_steps`` (test helper, not in the reference): stop after the first
     max_steps entries of the num_inference_steps-long schedule.  latents [1, c, T, h, w] (generated frames only); condition_latents
     [1, c, n_cond, h, w] or None; prompt_embeds [2, 77, d] = [uncond, cond].  unet_fn(sample, t, ehs, sample_index=,
@@ -230,9 +260,8 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
     sched = EulerOracle(**(scheduler_kwargs or {})) if euler else DDIMOracle()
     sched.set_timesteps(num_inference_steps)
     n_cond = 0 if condition_latents is None else condition_latents.shape[2]
-    vis_idx = torch.arange(n_cond, dtype=torch.long) if n_cond else None      # vision_condition_latent_index
     T = latents.shape[2]
-    latent_index = torch.arange(n_cond, n_cond + T, dtype=torch.long) if n_cond else None
+    vis_idx, latent_index = condition_indices(n_cond, T, vision_condition_latent_index)
     gscales = guidance_schedule(guidance_scale, num_inference_steps, guidance_scale_end, guidance_scale_method)  # :1718-1723
     global_context = prepare_global_context(context_schedule, num_inference_steps, T, context_frames, context_stride,
                                             context_overlap, context_batch_size)
@@ -258,14 +287,11 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
                 sub_idx = torch.arange(win, dtype=torch.long) + n_cond                       # :1914-1920
             if condition_latents is not None:
                 cond = torch.cat([condition_latents] * 2) if do_cfg else latents             # :1922-1926
-                full = torch.zeros((x.shape[0], x.shape[1], n_cond + x.shape[2], *x.shape[3:]), dtype=x.dtype)
-                full.index_copy_(2, vis_idx, cond)                                            # data_util.py:242-268
-                full.index_copy_(2, sub_idx, x)
-                x = full
+                x = concat_with_index(cond, vis_idx, x, sub_idx)                                # :1939-1946
             extra = {}
             if controlnet_fn is not None:
                 cond_scale = controlnet_conditioning_scale * keep[i]                          # :1235
-                cctx = [list(range(n_cond)) + [ci + n_cond for ci in c] for c in context]     # :1953-1961
+                cctx = [vis_idx.tolist() + [ci + n_cond for ci in c] for c in context]        # :1953-1961
                 ctrl = torch.cat([control_image[:, :, c] for c in cctx])                      # :1977-1979
                 if guess_mode and do_cfg:                                                     # :1218-1226: conditional half only
                     cin, ctext = x[x.shape[0] // 2:], prompt_embeds.chunk(2)[1]
@@ -297,10 +323,7 @@ def denoise_loop(unet_fn: Callable[..., Tensor], latents: Tensor, prompt_embeds:
         if record_latents is not None:
             record_latents.append(latents.clone())
     if condition_latents is not None:
-        out = torch.zeros((latents.shape[0], latents.shape[1], n_cond + T, *latents.shape[3:]), dtype=latents.dtype)
-        out.index_copy_(2, vis_idx, condition_latents)
-        out.index_copy_(2, latent_index, latents)
-        latents = out
+        latents = concat_with_index(condition_latents, vis_idx, latents, latent_index)        # :2149-2156
     return latents
 
 

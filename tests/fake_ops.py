@@ -8,10 +8,15 @@ import math
 import torch
 
 
-def window_gather(latents, cond, idx, n_cond, copies, hi_lo=False):
+def window_gather(latents, cond, idx, n_cond, copies, hi_lo=False, cond_slot=None):
     frames = latents[:, idx.long()]
-    if n_cond:
+    if n_cond and cond_slot is None:
         frames = torch.cat([cond, frames], dim=1)
+    elif n_cond:  # condition frames at their slots first, the window's frames at n_cond.. afterwards (data_util.py:242-268)
+        full = torch.zeros((latents.shape[0], n_cond + idx.numel(), latents.shape[2]), dtype=latents.dtype)
+        full.index_copy_(1, cond_slot.long(), cond)
+        full[:, n_cond:] = frames
+        frames = full
     rows = frames.permute(1, 2, 0).reshape(-1, latents.shape[0])
     rows = torch.cat([rows] * copies, dim=0)
     hi = rows.to(torch.float16)
@@ -55,8 +60,9 @@ def cfg_affine_step(latents, eps_acc, counter, guidance, cx, ce):
 
 
 class FakeUNet:
-    """eps = tanh(0.5 x) * (1 + 0.1 * mean(text)) + 0.01 * (timestep / 1000) + 0.05 * frame_position -- depends on the
-    input frames, the CFG half's prompt, the timestep and the window-local frame position, like the real network."""
+    """eps = tanh(0.5 x) * (1 + 0.1 * mean(text)) + 0.01 * (timestep / 1000) + 0.05 * frame_position + 0.02 * [the frame is one the
+    caller names a vision-condition frame] -- depends on the input frames, the CFG half's prompt, the timestep, the window-local
+    frame position and the condition-frame index list, like the real network."""
 
     in_channels = 4
 
@@ -68,11 +74,16 @@ class FakeUNet:
         s = 1.0 + 0.1 * ehs.float().mean(dim=(1, 2)).reshape(b, 1, 1, 1)
         pos = torch.arange(t, dtype=torch.float32).reshape(1, t, 1, 1)
         out = torch.tanh(0.5 * v) * s + 0.01 * float(timestep.reshape(-1)[0]) / 1000.0 + 0.05 * pos
+        vis = kw.get("vision_conditon_frames_sample_index")
+        if vis is not None:
+            mark = torch.zeros(t)
+            mark[[int(i) for i in (vis.tolist() if torch.is_tensor(vis) else vis)]] = 1.0
+            out = out + 0.02 * mark.reshape(1, t, 1, 1)
         return out.reshape(b * t * h * w, c)  # fp32 rows, like UNet3DConditionModel.forward_rows
 
     def nchw(self, x, t, ehs, **kw):
         """the same function on the reference layout [b, c, t, h, w] (for the oracle loop)"""
         b, c, tt, h, w = x.shape
         rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).to(torch.float16)
-        y = self.forward_rows(rows, b, tt, h, w, torch.as_tensor(float(t)), ehs)
+        y = self.forward_rows(rows, b, tt, h, w, torch.as_tensor(float(t)), ehs, **kw)
         return y.float().reshape(b, tt, h, w, c).permute(0, 4, 1, 2, 3)

@@ -84,7 +84,8 @@ def main():
         with torch.no_grad():
             opipe.denoise_loop(unet_fn, latents, prompt, num_inference_steps=case["num_inference_steps"], max_steps=case["steps"],
                                guidance_scale=case["guidance_scale"], condition_latents=cond, context_frames=case["context_frames"],
-                               context_overlap=case["context_overlap"], motion_speed=8.0, record_latents=rec, unet_kwargs=side, start_step=start)
+                               context_overlap=case["context_overlap"], motion_speed=8.0, record_latents=rec, unet_kwargs=side, start_step=start,
+                               vision_condition_latent_index=case.get("vision_condition_latent_index"))
             out = {f"latents_step{i + 1}": r.numpy().astype(np.float32) for i, r in enumerate(rec)}
         np.savez_compressed(path, **out)
         os.remove(path + ".part.npz")

@@ -340,6 +340,73 @@ def gen_multi_shot():
     print("multi shot:", {k: v.shape for k, v in out.items() if k.endswith("_video")})
 
 
+CONDITION_INDEX_CASES = {
+    # name: (n_cond, video_length, vision_condition_latent_index)
+    "front_1": (1, 12, None), "front_2": (2, 6, None), "head_tail": (2, 12, [0, -1]), "tail_only": (1, 5, [-1]),
+    "head_tail_short": (2, 6, [0, -1]), "explicit": (2, 5, [0, 3]),
+}
+
+
+def gen_condition_index():
+    """musev/pipelines/pipeline_controlnet.py:966-1040 -- ``MusevControlNetPipeline.prepare_condition_latents_and_index``: the method's
+    OWN SOURCE (cut out with ast: the module imports the un-vendored diffusers pipeline base) executed with a stub ``self``; recorded:
+    the two index vectors it returns, and -- built with the reference's own data_util functions exactly as the loop calls them
+    (:1914-1946 one window over all frames, :2068-2071, :2149-2156) -- the window input, the selected prediction rows and the final
+    re-insert for a ramp of frame numbers."""
+    import ast
+    import json
+    import textwrap
+    import typing
+    from einops import rearrange
+    from musev.data import data_util as du
+    path = "/root/reference/musev/pipelines/pipeline_controlnet.py"
+    src = open(path).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "MusevControlNetPipeline")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "prepare_condition_latents_and_index")
+    code = textwrap.dedent(ast.get_source_segment(src, fn))
+
+    class _Log:
+        def debug(self, *a, **k):
+            pass
+
+    class _Self:
+        print_idx = 1
+    ns = dict(np=np, torch=torch, logger=_Log(), rearrange=rearrange, **{k: getattr(typing, k) for k in ("Union", "List", "Optional", "Callable", "Dict", "Any", "Tuple")})
+    exec(compile(code, path, "exec"), ns)
+    prep = ns["prepare_condition_latents_and_index"]
+    out = {}
+    for name, (n_cond, T, vis) in CONDITION_INDEX_CASES.items():
+        cond = 100.0 + torch.arange(n_cond, dtype=torch.float32).view(1, 1, n_cond, 1, 1).expand(1, 2, n_cond, 1, 3).contiguous()
+        lat = 1.0 + torch.arange(T, dtype=torch.float32).view(1, 1, T, 1, 1).expand(1, 2, T, 1, 3).contiguous()
+        c_lat, lat_idx, vis_idx = prep(_Self(), condition_images=None, condition_latents=cond.clone(), video_length=T, batch_size=1,
+                                       dtype=torch.float32, device="cpu", latent_index=None, vision_condition_latent_index=vis)
+        rec = dict(n_cond=n_cond, video_length=T, given=vis, vision_condition_latent_index=vis_idx.tolist(), latent_index=lat_idx.tolist())
+        # the loop's window input for ONE window over all T frames (context = [range(T)]), CFG on (:1902-1946)
+        x = torch.cat([lat] * 2)
+        sub = torch.LongTensor(torch.arange(T) + n_cond)                      # sub_latent_index_c (:1914-1920)
+        try:
+            full = du.batch_concat_two_tensor_with_index(data1=torch.cat([c_lat] * 2), data1_index=vis_idx, data2=x, data2_index=sub, dim=2)
+            rec["window_input_frames"] = full[0, 0, :, 0, 0].tolist()          # which frame sits in every slot (0 = never written)
+            rec["selected"] = du.batch_index_select(full, dim=2, index=sub)[0, 0, :, 0, 0].tolist()      # :2068-2071
+        except (IndexError, RuntimeError) as ex:
+            rec["window_input_error"] = type(ex).__name__
+        final = du.batch_concat_two_tensor_with_index(data1=c_lat, data1_index=vis_idx, data2=lat, data2_index=lat_idx, dim=2)  # :2149-2156
+        rec["final_frames"] = final[0, 0, :, 0, 0].tolist()
+        # ... and for a window of 4 frames out of T (several windows): global positions past n_cond + win do not exist in its input
+        win = min(4, T)
+        try:
+            du.batch_concat_two_tensor_with_index(data1=torch.cat([c_lat] * 2), data1_index=vis_idx, data2=x[:, :, :win],
+                                                  data2_index=torch.LongTensor(torch.arange(win) + n_cond), dim=2)
+            rec["short_window"] = "ok"
+        except (IndexError, RuntimeError) as ex:
+            rec["short_window"] = type(ex).__name__
+        out[name] = rec
+    with open(os.path.join(HERE, "reference_condition_index.json"), "w") as f:
+        f.write("{\n" + ",\n".join(f' "{k}": {json.dumps(v)}' for k, v in out.items()) + "\n}\n")
+    print("condition index:", {k: (v["vision_condition_latent_index"], v.get("window_input_frames"), v["short_window"]) for k, v in out.items()})
+
+
 def gen_pipeline_signature():
     """the keyword list (names, order, literal defaults) of MusevControlNetPipeline.__call__ and of the predictor's shot loop call
     site, read from the reference's SOURCE with ast (the module itself imports the un-vendored diffusers pipeline base)"""
@@ -378,6 +445,9 @@ if __name__ == "__main__":
     if "--ddim" in sys.argv:
         gen_ddim()
         sys.exit(0)
+    if "--condition-index" in sys.argv:
+        gen_condition_index()
+        sys.exit(0)
     if "--at-size" in sys.argv:  # the BASELINE-size UNet cases only (minutes of CPU, ~25 GB)
         gen_unet(UNET_CASES_AT_SIZE)
         sys.exit(0)
@@ -386,6 +456,7 @@ if __name__ == "__main__":
         gen_unet(UNET_CASES_AT_SIZE_CFG5)
         sys.exit(0)
     gen_pipeline_signature()
+    gen_condition_index()
     gen_multi_shot()
     gen_poseguider()
     gen_loop_utils()

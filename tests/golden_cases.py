@@ -231,6 +231,18 @@ LOOP_CASES_AT_SIZE = {
     "refnet_cfg3_loop20_w13_g035": dict(flavour="musev_referencenet", arch={}, T=12, h=64, w=64, n_cond=1, weight_seed=13, latent_seed=44,
                                         cond_seed=45, prompt_seed=46, side_seed=47, guidance_scale=3.5, num_inference_steps=20, steps=20,
                                         context_frames=12, context_overlap=4, calib=dict(random_gain=0.35)),
+    # BASELINE config 4's schedule AT SIZE with MORE THAN ONE WINDOW: T = 24, window 12, overlap 4 -> the windows
+    # [0..11] [8..19] [16..23, 0..3] (context.py:21-48: the last one wraps around), every frame of 8..11 / 16..19 / 0..3 covered twice
+    # and averaged (pipeline_controlnet.py:2076-2079); 512x512, full widths, first 4 of the 20 DDIM steps = 12 forwards of the reference's UNet
+    "musev_cfg4_w3": dict(flavour="musev", arch={}, T=24, h=64, w=64, n_cond=1, weight_seed=8, latent_seed=51, cond_seed=52,
+                          prompt_seed=53, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12, context_overlap=4),
+    # condition frames at HEAD AND TAIL (the CLI's condition_images_index = [0, -1]): config 2's size, two condition
+    # latents, vision_condition_latent_index = [0, -1] -> [0, 13].  The reference's literal window input (tests/golden/
+    # reference_condition_index.json): slot 0 = condition frame 0, slot 1 = ZEROS, slots 2..13 = the 12 generated frames (the tail
+    # condition frame is overwritten), the UNet told that slots 0 and 13 are condition frames; final re-insert at 0 and 13.  First 2 steps
+    "musev_cfg2_headtail": dict(flavour="musev", arch={}, T=12, h=64, w=64, n_cond=2, weight_seed=8, latent_seed=54, cond_seed=55,
+                                prompt_seed=56, guidance_scale=3.5, num_inference_steps=20, steps=2, context_frames=12, context_overlap=4,
+                                vision_condition_latent_index=[0, -1]),
     "refnet_pose_cfg5_loop": dict(flavour="musev_referencenet", arch={}, T=12, h=96, w=96, n_cond=1, weight_seed=11, latent_seed=37, cond_seed=38,
                                   prompt_seed=39, side_seed=40, guidance_scale=3.5, num_inference_steps=20, steps=4, context_frames=12,
                                   context_overlap=4, controlnet=True, pose=True),

@@ -766,6 +766,18 @@ def case_window_loop():
     r1b = _all_ok([_cmp("window_gather hi_lo: hi", both[:, :c], ref_in.half().float(), atol=0.0, rtol=0.0),
                    _cmp("window_gather hi_lo: hi + lo", both[:, :c].float() + both[:, c:].float(), ref_in.float(), atol=1e-6, rtol=4e-6)])
     r1["ok"] = r1["ok"] and r1b["ok"]
+    # condition frames at given slots (the reference's vision_condition_latent_index, data_util.py:242-268 as called at
+    # pipeline_controlnet.py:1939-1946): two condition frames named at slots [0, n_cond + win - 1] -> slot 0 = cond 0, slot 1 zeros,
+    # the tail slot overwritten by the window's last frame; and [1, 0] -> swapped in front
+    cond2 = torch.randn((c, 2, hw), generator=g).to(DEV)
+    for slots in ([0, 2 + win - 1], [1, 0], [0, 1]):
+        got = ops.window_gather(lat, cond2, idx, 2, 2, cond_slot=torch.tensor(slots, dtype=torch.int32, device=DEV))
+        full = torch.zeros((c, 2 + win, hw), device=DEV)
+        full.index_copy_(1, torch.tensor(slots, device=DEV), cond2)
+        full[:, 2:] = lat[:, idx.long()]
+        ref_s = full.permute(1, 2, 0).reshape(-1, c)
+        rs = _cmp(f"window_gather cond_slot={slots}", got, torch.cat([ref_s, ref_s], dim=0).half().float(), atol=0.0, rtol=0.0)
+        r1["ok"] = r1["ok"] and rs["ok"]
     eps_win = _rand((2 * (n_cond + win) * hw, c), 131)
     acc = torch.zeros((2, c, t_total, hw), device=DEV)
     cnt = torch.zeros((t_total,), device=DEV)

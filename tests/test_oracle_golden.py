@@ -141,6 +141,41 @@ def test_datautil_semantics():
     assert np.array_equal(unet3d.align_repeat(torch.arange(6.0).reshape(2, 3), 8, dim=0).numpy(), g["rep"])
 
 
+def test_condition_index_matches_reference():
+    """where the vision-condition frames sit: oracle.pipeline.condition_indices / concat_with_index against
+    tests/golden/reference_condition_index.json -- ``prepare_condition_latents_and_index`` (pipeline_controlnet.py:966-1040, its own
+    source executed) and the window input / selection / final re-insert built with the reference's data_util functions as the loop
+    calls them (:1914-1946, :2068-2071, :2149-2156).  Incl. the reference's literal head + tail behaviour: with [0, -1] and one
+    window the tail condition frame is overwritten by the last generated frame and slot 1 stays zero; a window shorter than the
+    video raises IndexError."""
+    import json
+    from oracle import pipeline as opipe
+    gold = json.load(open(os.path.join(GOLD, "reference_condition_index.json")))
+    assert {"front_1", "head_tail", "tail_only"} <= set(gold)
+    for name, g in gold.items():
+        n_cond, T = g["n_cond"], g["video_length"]
+        vis, lat_idx = opipe.condition_indices(n_cond, T, g["given"])
+        assert vis.tolist() == g["vision_condition_latent_index"], name
+        assert lat_idx.tolist() == g["latent_index"], name
+        cond = 100.0 + torch.arange(n_cond, dtype=torch.float32).view(1, 1, n_cond, 1, 1).expand(1, 2, n_cond, 1, 3).contiguous()
+        lat = 1.0 + torch.arange(T, dtype=torch.float32).view(1, 1, T, 1, 1).expand(1, 2, T, 1, 3).contiguous()
+        sub = torch.arange(T) + n_cond
+        if "window_input_error" in g:
+            with pytest.raises((IndexError, RuntimeError)):
+                opipe.concat_with_index(torch.cat([cond] * 2), vis, torch.cat([lat] * 2), sub)
+        else:
+            full = opipe.concat_with_index(torch.cat([cond] * 2), vis, torch.cat([lat] * 2), sub)
+            assert full[0, 0, :, 0, 0].tolist() == g["window_input_frames"], name
+            assert full.index_select(2, sub)[0, 0, :, 0, 0].tolist() == g["selected"], name
+        assert opipe.concat_with_index(cond, vis, lat, lat_idx)[0, 0, :, 0, 0].tolist() == g["final_frames"], name
+        win = min(4, T)
+        if g["short_window"] == "ok":
+            opipe.concat_with_index(torch.cat([cond] * 2), vis, torch.cat([lat] * 2)[:, :, :win], torch.arange(win) + n_cond)
+        else:
+            with pytest.raises((IndexError, RuntimeError)):
+                opipe.concat_with_index(torch.cat([cond] * 2), vis, torch.cat([lat] * 2)[:, :, :win], torch.arange(win) + n_cond)
+
+
 def test_euler_matches_reference():
     """oracle.pipeline.EulerOracle and the host tables of musev_amd.schedulers.EulerDiscreteScheduler against the reference's
     own EulerDiscreteScheduler (step override musev/schedulers/scheduling_euler_discrete.py:47-167 executed on the refshim

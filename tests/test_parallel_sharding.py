@@ -36,7 +36,7 @@ def _patch(monkeypatch_like):
         monkeypatch_like(ops, name, getattr(fake_ops, name))
 
 
-def _run_loop(group=None, scheduler=None, frames=20, schedule="uniform", window=8, overlap=2, **loop_kw):
+def _run_loop(group=None, scheduler=None, frames=20, schedule="uniform", window=8, overlap=2, n_cond=1, **loop_kw):
     from musev_amd import ops
     from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
     saved = {n: getattr(ops, n) for n in ("window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step")}
@@ -45,7 +45,7 @@ def _run_loop(group=None, scheduler=None, frames=20, schedule="uniform", window=
         ParallelDenoiser._device_check = False
         g = torch.Generator().manual_seed(0)
         lat = torch.randn(1, 4, frames, 4, 4, generator=g)
-        cond = torch.randn(1, 4, 1, 4, 4, generator=g)
+        cond = torch.randn(1, 4, n_cond, 4, 4, generator=g)
         prompt = torch.randn(2, 7, 16, generator=g)
         den = ParallelDenoiser(fake_ops.FakeUNet(), scheduler=scheduler, context_frames=window, context_overlap=overlap,
                                context_schedule=schedule)
@@ -104,6 +104,30 @@ def test_multi_rank_gloo_matches_single_process_and_oracle(world):
     want = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
                               context_frames=8, context_overlap=2, motion_speed=8.0)
     assert (single - want).abs().max().item() < 5e-3  # fp16 window inputs / predictions vs the fp32 oracle loop
+
+
+def test_condition_frames_at_head_and_tail_follow_the_reference():
+    """vision_condition_latent_index = [0, -1] (the CLI's condition_images_index): the loop against the oracle
+    loop, whose index logic is pinned to the reference's own functions (tests/golden/reference_condition_index.json).  One window:
+    slot 0 = condition frame 0, slot 1 = zeros, the tail condition frame overwritten by the last generated frame, the UNet told that
+    slots 0 and n_cond + T - 1 are condition frames, the final re-insert at positions 0 and n_cond + T - 1.  More than one window:
+    IndexError, as the reference's index_copy_ raises."""
+    from oracle import pipeline as opipe
+    for vis, n_cond in (([0, -1], 2), ([-1], 1), ([0, 3], 2), (None, 2)):
+        got, (lat, cond, prompt) = _run_loop(None, frames=8, n_cond=n_cond, vision_condition_latent_index=vis)
+        fake = fake_ops.FakeUNet()
+        want = opipe.denoise_loop(fake.nchw, lat, prompt, num_inference_steps=5, guidance_scale=3.5, condition_latents=cond,
+                                  context_frames=8, context_overlap=2, motion_speed=8.0, vision_condition_latent_index=vis)
+        assert got.shape == want.shape == (1, 4, n_cond + 8, 4, 4)
+        assert (got - want).abs().max().item() < 5e-3, vis
+        v_res, l_res = opipe.condition_indices(n_cond, 8, vis)
+        assert torch.equal(got[:, :, v_res], cond), "the condition frames come back at their positions, untouched"
+    with pytest.raises(IndexError):
+        _run_loop(None, frames=20, n_cond=2, vision_condition_latent_index=[0, -1])
+    with pytest.raises(IndexError):  # the oracle (= torch's index_copy_ as in the reference) refuses the same call
+        lat = torch.randn(1, 4, 20, 4, 4)
+        opipe.denoise_loop(fake_ops.FakeUNet().nchw, lat, torch.randn(2, 7, 16), num_inference_steps=5, guidance_scale=3.5,
+                           condition_latents=torch.randn(1, 4, 2, 4, 4), context_frames=8, context_overlap=2, vision_condition_latent_index=[0, -1])
 
 
 def test_euler_loop_matches_oracle_loop():

@@ -51,7 +51,7 @@ def _unplain(v):
     return v
 
 
-def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim"):
+def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim", n_cond=1, vis=None):
     from oracle import pipeline as opipe
     from oracle import unet3d
     from musev_amd.models.unet_loader import load_unet_by_name
@@ -67,9 +67,11 @@ def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim"):
         sched = EulerDiscreteScheduler()
         sched.set_timesteps(20)
         latents = latents * sched.init_noise_sigma  # prepare_latents scales the initial noise (pipeline_controlnet.py)
-    cond = 0.18215 * torch.randn(1, 4, 1, h, w, generator=g) if with_cond else None
+    cond = 0.18215 * torch.randn(1, 4, n_cond, h, w, generator=g) if with_cond else None
     prompt = torch.randn(2, 77, 768, generator=g)
     kw = dict(num_inference_steps=20, max_steps=steps, guidance_scale=3.5, condition_latents=cond)
+    if vis is not None:
+        kw["vision_condition_latent_index"] = vis
 
     def oracle_unet(x, t, ehs, **k):
         return unet3d.unet3d_forward(sd, cfg, x, t, ehs, **k)
@@ -96,6 +98,25 @@ def test_loop_parity_first_steps(T, win, ov, steps):
     assert err < 1e-2, f"|delta latent|max = {err}"
     # the vision-condition frame is re-inserted untouched in front (pipeline_controlnet.py:2149-2156)
     assert torch.equal(got[:, :, 0], want[:, :, 0])
+
+
+@pytest.mark.parametrize("flavour,n_cond,vis", [("musev", 2, [0, -1]), ("musev_referencenet", 2, [0, -1]), ("musev", 1, [-1]), ("musev", 2, [1, 0])])
+def test_loop_parity_condition_frames_head_and_tail(flavour, n_cond, vis):
+    """vision_condition_latent_index (round 6): the HIP loop against the oracle loop, whose index logic is pinned to
+    the reference's own prepare_condition_latents_and_index / data_util functions (tests/golden/reference_condition_index.json) -- the
+    reference's literal behaviour incl. the zero slot and the overwritten tail frame; `musev_referencenet` zeroes the time embedding
+    of the frames the index names (keep_vision_condtion).  More than one window with a -1 raises IndexError like torch's index_copy_."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    want, got, got2 = _run(flavour, 6, 6, 2, 2, n_cond=n_cond, vis=vis)
+    assert got.shape == want.shape == (1, 4, n_cond + 6, 8, 8)
+    assert torch.equal(got, got2), "the loop must be deterministic"
+    err = (got - want).abs().max().item()
+    assert err < 1e-2, f"|delta latent|max = {err}"
+    pos = [i if i != -1 else n_cond + 6 - 1 for i in vis]
+    assert torch.equal(got[:, :, pos], want[:, :, pos]), "the condition frames are re-inserted untouched at their positions"
+    if -1 in vis:
+        with pytest.raises(IndexError):
+            _run(flavour, 12, 6, 2, 1, n_cond=n_cond, vis=vis)
 
 
 def test_full_size_window_average_property():
@@ -287,7 +308,7 @@ def test_twenty_step_drift_against_fp16_torch_floor():
 
 @pytest.mark.parametrize("name", ["musev_cfg2_loop20", "musev_cfg2_loop", "refnet_cfg3_loop", "refnet_cfg3_loop20", "refnet_pose_cfg5_loop",
                                   "refnet_pose_cfg5_loop_sym", "musev_cfg2_loop20_w12_g035", "refnet_cfg3_loop20_w13_g035",
-                                  "musev_cfg2_loop20_w14_skip1"])
+                                  "musev_cfg2_loop20_w14_skip1", "musev_cfg4_w3", "musev_cfg2_headtail"])
 def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     """BASELINE config 2 AT SIZE: 512x512 px (64x64 latents), 12 generated + 1 vision-condition frame, guidance 3.5, full-width
     `musev` (1.42 B parameters, noise-predictor weights) -- per-step latents of the HIP loop against those recorded by
@@ -304,7 +325,11 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     control image produces up to its text input), `musev_cfg2_loop20_w12_g035` = config 2's whole schedule on ANOTHER fixture (weight seed 12,
     calibrate_as_denoiser(random_gain=0.35): twice the share of the random network in the prediction), `refnet_cfg3_loop20_w13_g035` = the
     same for config 3 (weight seed 13), `musev_cfg2_loop20_w14_skip1` = config 2 on the sweep's adverse carrier layout (a stress case like
-    the decorrelated config-5 one).  Asserted: free-running
+    the decorrelated config-5 one), `musev_cfg4_w3` = BASELINE config 4's schedule with MORE THAN ONE WINDOW at size (round 6: 24 frames,
+    window 12, overlap 4 -> [0..11] [8..19] [16..23, 0..3] incl. the wrap-around window, 12 frames covered twice and averaged; first 4
+    steps = 12 forwards of the reference's UNet), `musev_cfg2_headtail` = two condition frames with vision_condition_latent_index = [0, -1]
+    (the reference's literal window input: slot 0 condition frame, slot 1 zeros, the tail condition frame overwritten, the UNet told that
+    slots 0 and 13 are condition frames; 2 steps).  Asserted: free-running
     ABSOLUTE |delta latent|max < 1e-2 at EVERY step (the metric's output bar; the two-fp16 carry on the residual stream is what
     makes it reachable, profiles/r04b_loop_rounding_ensemble.json); every step started from the reference's latents < 1e-2; the
     graph replay is bit-identical."""
@@ -335,12 +360,13 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     del sd
     den = ParallelDenoiser(unet, context_frames=case["context_frames"], context_overlap=case["context_overlap"])
     shape = (1, 4, case["T"], case["h"], case["w"])
+    vis = dict(vision_condition_latent_index=case["vision_condition_latent_index"]) if "vision_condition_latent_index" in case else {}
     runs = []
     for _ in range(2):
         rec = []
         den(latents.to(dev), prompt.to(dev), num_inference_steps=case["num_inference_steps"], max_steps=case["steps"],
             guidance_scale=case["guidance_scale"], condition_latents=cond.to(dev), motion_speed=8.0, unet_kwargs=side,
-            callback=lambda i, t, lat: rec.append(lat.clone().view(shape).cpu()))
+            callback=lambda i, t, lat: rec.append(lat.clone().view(shape).cpu()), **vis)
         torch.cuda.synchronize()
         runs.append(rec)
     assert len(runs[0]) == case["steps"]
@@ -352,7 +378,7 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     prev = latents
     for i in range(case["steps"]):
         out = den(prev.to(dev), prompt.to(dev), num_inference_steps=case["num_inference_steps"], guidance_scale=case["guidance_scale"],
-                  condition_latents=cond.to(dev), motion_speed=8.0, start_step=i, max_steps=i + 1, reinsert_condition=False, unet_kwargs=side)
+                  condition_latents=cond.to(dev), motion_speed=8.0, start_step=i, max_steps=i + 1, reinsert_condition=False, unet_kwargs=side, **vis)
         want = torch.from_numpy(gold[f"latents_step{i + 1}"])
         forced.append((out.float().cpu() - want).abs().max().item())
         prev = want
@@ -363,7 +389,9 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
     with open(os.path.join(out_dir, f"loop_at_size_{name}.json"), "w") as f:
         json.dump({"case": name, "config": (("BASELINE config 5 inputs: musev_referencenet_pose (ReferenceNet features, IP-Adapter tokens, ControlNet residuals, PoseGuider embedding)"
                                              if case.get("pose") else "BASELINE config 3: musev_referencenet + IP-Adapter tokens + ReferenceNet features") if case["flavour"] != "musev"
-                                            else "BASELINE config 2: musev") + f", {8 * case['h']}x{8 * case['w']}, 12 + 1 frames, guidance 3.5, 20-step DDIM schedule"
+                                            else "BASELINE config 2: musev") + f", {8 * case['h']}x{8 * case['w']}, {case['T']} + {case['n_cond']} frames, window "
+                                           f"{case['context_frames']} overlap {case['context_overlap']}, guidance 3.5, 20-step DDIM schedule"
+                                           + (f", vision_condition_latent_index {case['vision_condition_latent_index']}" if vis else "")
                                            + (f", fixture {case['calib']} weight seed {case['weight_seed']}" if case.get("calib") else ""),
                    "golden": "oracle loop around the reference's own UNet3DConditionModel, fp32 CPU (tests/golden/make_loop_goldens.py)",
                    "carry": bool(ops.CARRY), "colstats": bool(ops.COLSTATS), "ln_fold": bool(ops.LN_FOLD),
@@ -516,6 +544,81 @@ def test_ranks_sharing_the_gpu_match_the_single_process_loop(world, T, win, ov, 
     err = (ret[0][0] - single).abs().max().item()
     # same fp32 predictions, summed per frame in a different (but fixed) order than the local scatter-add: fp32 rounding only
     assert err < 2e-5 * scale, f"sharded vs single-process |delta|max = {err}"
+
+
+def _shared_gpu_at_size_worker(rank, world, port, ret, name):
+    import os
+    import torch.distributed as dist
+    from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // world)))
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        case = LOOP_CASES_AT_SIZE[name]
+        cfg, sd = loop_case_state_dict(case)
+        latents, cond, prompt = loop_case_inputs(case)
+        unet = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16).to(dev)
+        del sd
+        den = ParallelDenoiser(unet, context_frames=case["context_frames"], context_overlap=case["context_overlap"])
+        kw = dict(num_inference_steps=case["num_inference_steps"], max_steps=2, guidance_scale=case["guidance_scale"], motion_speed=8.0,
+                  condition_latents=cond.to(dev), reinsert_condition=False)
+        outs = [den(latents.to(dev), prompt.to(dev), group=dist.group.WORLD, **kw) for _ in range(2)]  # second call replays the graphs
+        torch.cuda.synchronize()
+        ret[rank] = _plain([o.float().cpu() for o in outs])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_the_gpu_at_size_config4_windows(world):
+    """sharded == single process on the REAL network at size: `musev_cfg4_w3` -- full-width `musev` (1.42 B
+    parameters), 512x512, 24 frames, window 12 overlap 4 -> 3 windows incl. the wrap-around one x 2 CFG halves = 6 units -- over 2
+    gloo ranks (3 + 3 units: each rank owns a two-half window and a LONE half -- the odd-unit lane) and over 3 (2 + 2 + 2) sharing the
+    box's GPU, first 2 steps.  Asserted: replicas bit-identical, graph replay bit-identical, sharded = single process to the fp32
+    rounding of the different (fixed) summation order, and the sharded run within 1e-2 of the reference-UNet loop golden."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import os
+    import socket
+
+    import numpy as np
+    import torch.multiprocessing as mp
+    from golden_cases import LOOP_CASES_AT_SIZE, loop_case_inputs, loop_case_state_dict
+    from musev_amd.models.unet_loader import load_unet_by_name
+    from musev_amd.pipelines.parallel_denoise import ParallelDenoiser
+    name = "musev_cfg4_w3"
+    path = os.path.join(os.path.dirname(__file__), "golden", f"reference_loop_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated (tests/golden/make_loop_goldens.py --case {name})")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_shared_gpu_at_size_worker, args=(world, port, ret, name), nprocs=world, join=True)
+    ret = {k: _unplain(v) for k, v in dict(ret).items()}
+    for r in range(world):
+        assert torch.equal(ret[r][0], ret[r][1]), "graph replay changed the result"
+        assert torch.equal(ret[0][0], ret[r][0]), "replicated latents diverged between ranks"
+    case = LOOP_CASES_AT_SIZE[name]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg, sd = loop_case_state_dict(case)
+    latents, cond, prompt = loop_case_inputs(case)
+    dev = torch.device("cuda", 0)
+    unet = load_unet_by_name(case["flavour"], sd_unet_model=sd, dtype=torch.float16).to(dev)
+    del sd
+    den = ParallelDenoiser(unet, context_frames=case["context_frames"], context_overlap=case["context_overlap"])
+    single = den(latents.to(dev), prompt.to(dev), num_inference_steps=case["num_inference_steps"], max_steps=2,
+                 guidance_scale=case["guidance_scale"], motion_speed=8.0, condition_latents=cond.to(dev), reinsert_condition=False).float().cpu()
+    err = (ret[0][0] - single).abs().max().item()
+    gold = torch.from_numpy(np.load(path)["latents_step2"])
+    gerr = (ret[0][0] - gold).abs().max().item()
+    print(f"{name} world {world}: sharded vs single-process |delta|max {err:.2e}; sharded vs reference-UNet loop golden after 2 steps {gerr:.2e}")
+    assert err < 2e-5, f"sharded vs single-process |delta|max = {err}"
+    assert gerr < FREE_RUNNING_BAR, gerr
 
 
 def _rccl_one_rank_worker(rank, port, ret):
