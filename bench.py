@@ -238,6 +238,52 @@ def build_unet(flavour: str, dev):
     return unet
 
 
+def device_state(local_rank: int) -> dict:
+    """clocks / power cap / temperature of the GPU under this rank (`rocm-smi --json`), so that a slow box explains itself in the
+    line the driver keeps; best effort -- any failure is recorded, never raised"""
+    import subprocess
+    try:
+        p = subprocess.run(["rocm-smi", "-d", str(local_rank), "--showclocks", "--showpower", "--showmaxpower", "--showtemp", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(p.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "temperature (sensor junction)", "temperature (sensor memory)", "performance level")):
+                keep[k] = v
+        return keep
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)[:200]}
+
+
+FAMILY_ENTRIES = ("mv_gemm_f16", "mv_ffn_geglu_f16", "mv_temporal_attn_block_f16")
+
+
+class issue_family_twice:
+    """context manager: every launch of the matrix family (FAMILY_ENTRIES of the C ABI) is issued TWICE with the same arguments (the
+    entries are idempotent: same inputs, same outputs) -- the step's extra time is what the family's launches cost WHERE THEY RUN
+    (two HIP streams, hipGraph replay), the quantity tools/gpu_insitu_cost.py tabulates for every entry"""
+
+    def __enter__(self):
+        from musev_amd import _lib
+        self.lib = _lib.load()
+        self.saved = {}
+        for name in FAMILY_ENTRIES:
+            orig = getattr(self.lib, name)
+            self.saved[name] = orig
+
+            def twice(*a, _orig=orig):
+                rc = _orig(*a)
+                return _orig(*a) if rc == 0 else rc
+            setattr(self.lib, name, twice)   # an instance attribute of the CDLL: musev_amd.ops resolves the entry through it
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self.saved.items():
+            setattr(self.lib, name, orig)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +426,7 @@ def main():
                  "per_rank_units": [int(v[3].item()) for v in allr],
                  "exchange_payload": "fp32 predictions, one async all_gather_into_tensor per unit slot (<= 786 KB per unit and rank)"}
     den.time_exchange = False
+    dev_state = device_state(local_rank) if rank == 0 else None   # right after the timed region: the clocks it ran at
     ms_per_step = elapsed * 1e3 / args.steps
     value = T / (DENOISE_STEPS * ms_per_step / 1e3)
     finite = bool(torch.isfinite(out).all())
@@ -400,6 +447,28 @@ def main():
         ms4 = (time.perf_counter() - marks4["t0"]) * 1e3 / k4
         config4_n1 = {"workload": "config4: musev, 512x512, 96 frames, window 12 overlap 4 -> 12 windows x 2 CFG halves on 1 GPU",
                       "value": 96 / (DENOISE_STEPS * ms4 / 1e3), "unit": "frames/s", "ms_per_step": ms4, "steps": k4, "warmup": w4}
+
+    # ---- the matrix family's cost IN THE STEP (roofline.achieved): the same timed loop once more with every launch of the family issued
+    # twice, on fresh captures; extra ms per step = the family's marginal cost under the step's two streams + graph replay ----
+    in_step = None
+    if world == 1 and not args.no_roofline:
+        den2 = ParallelDenoiser(unet, context_frames=win, context_overlap=4, context_stride=1, context_schedule="uniform")
+        k2, w2 = args.steps, max(args.warmup, 2)
+        marks2 = {}
+
+        def cb2(step, t, lat):
+            if step + 1 == w2:
+                sync_all()
+                marks2["t0"] = time.perf_counter()
+        with issue_family_twice():
+            den2(latents, prompt, num_inference_steps=w2 + k2, guidance_scale=3.5, condition_latents=cond, motion_speed=8.0,
+                 unet_kwargs=unet_kwargs, callback=cb2)
+            sync_all()
+        ms_twice = (time.perf_counter() - marks2["t0"]) * 1e3 / k2
+        if den2.use_graphs and dev.type == "cuda" and den2.graph_replays() == 0:
+            raise SystemExit("bench.py: the doubled-family steps did not replay a hipGraph")
+        in_step = {"ms_per_step_family_issued_twice": ms_twice, "family_marginal_ms_per_step": ms_twice - ms_per_step, "steps": k2, "warmup": w2}
+        del den2
 
     # ---- whole-step algorithmic FLOPs (what each rank executes per step, summed over ranks) ----
     halves = 2
@@ -560,7 +629,13 @@ def main():
             with open(args.gemm_by_problem, "w") as f:
                 json.dump(rows, f, indent=0)
         del rec_all
-        ach = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        iso = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        step_fam_flops = fam_flops * rec_scale
+        if in_step is not None and in_step["family_marginal_ms_per_step"] > 0:
+            fam_step_ms = in_step["family_marginal_ms_per_step"]
+            ach = step_fam_flops / (fam_step_ms * 1e-3) / 1e12
+        else:   # (N > 1 / --workload runs without the doubled leg: the isolated figure)
+            fam_step_ms, ach = fam_ms * rec_scale, iso
         roofline = {
             "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch) + tsa_kernel (the fused level-0 temporal self-attention sub-block: q / k / v projection + to_out per launch)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
@@ -569,19 +644,27 @@ def main():
             "traffic_unit": "HBM bytes per mv_gemm_f16 launch (PMC bytes of gemm2_kernel + splitk_reduce per step / launches per step)",
             "traffic_ratio": (measured_traffic(workload)[0] / (fam_bytes * rec_scale)) if (measured_traffic(workload)[0] is not None and fam_bytes > 0) else None,
             "traffic_source": measured_traffic(workload)[1],
-            "method": f"one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 / mv_temporal_attn_block_f16 launches re-issued back to back on one stream, {reps} repetitions between "
-                      "one HIP event pair (device time; no per-launch host gap)",
-            # (round 5) the tile table is measured on concurrent PAIRS of launches -- how the timed step runs the CFG halves -- so an
-            # ISOLATED launch is not the fastest the library could make it: `achieved` is the isolated figure (what rocprofv3's
-            # serialised kernel durations reproduce), `two_streams` the same launches as the step runs them
-            "note": "achieved = isolated launches on one stream; the tile table is tuned for the step's two concurrent streams (see two_streams)",
+            # (round 6) `achieved` describes the TIMED REGION: the family's algorithmic FLOPs per step / the family's
+            # marginal time in the step (the same graph-replayed two-stream loop with every launch of the family issued twice, minus
+            # the timed step) -- by construction below the step time.  rocprofv3 serialises the two HIP streams under kernel tracing
+            # (profiles/r06b_trace_overlap.json: 3 % of the busy time overlapped, 63.9 ms per traced step against ~49 untraced), so
+            # a trace cannot give the in-step figure; tools/gpu_insitu_cost.py's table (profiles/r06*_insitu_cost.json) reproduces it:
+            # frac = family TFLOP per step / (sum of the marginal ms of mv_gemm_f16:* + mv_ffn_geglu_f16 + mv_temporal_attn_block_f16) / 2500.
+            # `isolated` = the same launches alone on one stream (what rocprofv3's per-kernel durations reproduce; round 1-5's `achieved`).
+            "method": (f"in-step: {in_step['steps']} graph-replayed steps with every launch of the family issued twice ({in_step['ms_per_step_family_issued_twice']:.3f} ms) "
+                       f"minus the timed step ({ms_per_step:.3f} ms) = the family's marginal time per step; " if in_step is not None and ach != iso else "") +
+                      f"isolated: one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 / mv_temporal_attn_block_f16 launches re-issued back to back on one stream, "
+                      f"{reps} repetitions between one HIP event pair (device time; no per-launch host gap)",
+            "in_step": in_step,
+            "isolated": {"achieved": iso, "frac": iso / PEAK_MFMA_TFLOPS, "family_ms_per_step": fam_ms * rec_scale, "avg_launch_ms": fam_ms / max(fam_n, 1)},
             "algorithmic_bytes_per_launch": fam_bytes / max(fam_n, 1),
             "launches_per_step": fam_n * rec_scale,
             "recorded_windows": (f"1 of {n_windows} (every window issues the same launches; per-step figures = the recorded window x {n_windows})"
                                  if one_window else f"all of this rank's units of the {n_windows}-window step"),
-            "avg_launch_ms": fam_ms / max(fam_n, 1),
+            "avg_launch_ms": fam_step_ms / max(fam_n * rec_scale, 1),
             "algorithmic_flops_per_launch": fam_flops / max(fam_n, 1),
-            "family_ms_per_step": fam_ms * rec_scale,
+            "family_tflop_per_step": step_fam_flops / 1e12,
+            "family_ms_per_step": fam_step_ms,
             "by_mode": by_mode,
             "two_streams": two_stream,
             "batch2_one_stream": batch2,
@@ -627,7 +710,7 @@ def main():
                        # strong-scaling workloads: the speed-up this rank count can reach at best = total units / the largest shard
                        "ideal_speedup_vs_1gpu_same_workload": (n_windows * 2) / max(len(s_) for s_ in shards),
                        "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
-                       "output_finite": finite, "graphs": bool(graphs)},
+                       "output_finite": finite, "graphs": bool(graphs), "device_state": dev_state},
             "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1, "multi_gpu": multi,
         }
         if args.rehearse_shared_gpu:

@@ -1382,6 +1382,9 @@ int xattn_key_tiles(const mv_attn_desc* d) {
 
 int xattn_launch(const mv_attn_desc* d, void* stream) {
     MV_REQUIRE(d->nb > 0 && d->lq > 0 && d->nb <= 65535, "mv_attention_f16: empty problem");
+    // scale * log2(e) goes on the fp32 scores inside the exponential's fma while the row maximum is taken over the RAW scores:
+    // only a positive scale keeps "max of the raw scores" the maximum of the scaled ones
+    MV_REQUIRE(d->scale > 0.f, "mv_attention_f16: resident_kv needs scale > 0 (got %g)", (double)d->scale);
     const int kt = xattn_key_tiles(d);
     MV_REQUIRE(kt > 0, "mv_attention_f16: resident_kv needs d in {40, 80}, heads <= 8, <= 128 keys in tiles of 16 per segment, <= 3 groups, no accumulate, "
                        "and an LDS image of V under 160 KB (ask mv_attention_resident_ok)");

@@ -44,8 +44,10 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_CFG    -1 = measured per-shape table, then rules (default); -2 = rules only; >= 0 = that catalogue id
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 #   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
-#                      COLSTATS, CARRY, FFN_FUSED, TSA_FUSED, LN_FOLD, LN_FOLD_MAX_K, ATTN_GROUPS, XATTN_RESIDENT, GEMM_WEIGHT_STATIONARY); applied at the
-#                      bottom of this file
+#                      COLSTATS, CARRY, CARRY_MAX_C, FFN_FUSED, FFN_ROTATE, TSA_FUSED, LN_FOLD, LN_FOLD_MAX_K, ATTN_GROUPS, XATTN_RESIDENT,
+#                      GEMM_WEIGHT_STATIONARY); applied at the bottom of this file.  The per-feature variables of earlier rounds
+#                      (MUSEV_CARRY, MUSEV_SHARE_PREFIX, MUSEV_XATTN_RESIDENT, MUSEV_GEMM_WEIGHT_STATIONARY, ...) are gone: setting one
+#                      raises at import, so that an A/B leg written from an old example cannot silently measure the baseline twice.
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
 GEMM_SPLITK: int = int(os.environ.get("MUSEV_GEMM_SPLITK", "0"))
 # mv_gemm_desc.tile_order = 1: the library MAY take the weight-stationary workgroup order -- an XCD's workgroups cover a few n-tiles x
@@ -388,12 +390,15 @@ def temporal_attn_block(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor
     return o
 
 
-def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], reps: int = 1) -> float:
+def replay_gemms_two_streams(rec_a: Sequence[tuple], rec_b: Sequence[tuple], reps: int = 1, side=None) -> float:
     """the two lists re-issued CONCURRENTLY, one per HIP stream (how the loop runs the two CFG halves); returns the elapsed device
-    milliseconds from the common start to the later of the two ends, over all reps"""
+    milliseconds from the common start to the later of the two ends, over all reps.  ``side``: the second stream (the loop's own side
+    stream; a fresh stream per call would walk through HIP's few hardware queues and sooner or later share the main stream's)"""
     lib = _lib.load()
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=main.device)
+    if side is None:
+        from .pipelines.parallel_denoise import ParallelDenoiser
+        side = ParallelDenoiser._shared_stream("side", main.device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(main)
     side.wait_stream(main)
@@ -892,8 +897,17 @@ def probe_tr16(image: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# every MUSEV_* variable the package, bench.py and tools/ read; anything else with the prefix is a typo or a knob of an earlier round
+KNOWN_ENV = ("MUSEV_OPS", "MUSEV_GEMM_CFG", "MUSEV_GEMM_SPLITK", "MUSEV_NO_GRAPH", "MUSEV_HALF_STREAMS", "MUSEV_HIP_LIBRARY",
+             "MUSEV_GOLDEN_AT_SIZE", "MUSEV_QUICK_AT_SIZE", "MUSEV_SIM_FULL", "MUSEV_SIM_MODEL")
+
+
 def _apply_env_overrides() -> None:
     """MUSEV_OPS="NAME=VALUE,...": the one environment hook for A/B runs of this module's switches (ints; booleans as 0 / 1)"""
+    unknown = sorted(k for k in os.environ if k.startswith("MUSEV_") and k not in KNOWN_ENV)
+    if unknown:
+        raise ValueError(f"unknown MUSEV_* environment variable(s) {unknown}: module switches are set through MUSEV_OPS=\"NAME=VALUE,...\" "
+                         f"(known variables: {', '.join(KNOWN_ENV)})")
     spec = os.environ.get("MUSEV_OPS", "")
     for item in filter(None, (x.strip() for x in spec.split(","))):
         name, _, val = item.partition("=")

@@ -86,8 +86,6 @@ class ParallelDenoiser:
         # executed step of a call on (every signature captured by then), with graphs, without a ControlNet (whose per-length static
         # control-frame buffer is shared by the groups).  odd_unit_lane=False keeps the groups one after the other.
         self.odd_unit_lane = odd_unit_lane
-        self._side = {}
-        self._lane = {}
         self._t_bufs: Dict[str, torch.Tensor] = {}
         self._warm: Dict[tuple, bool] = {}  # signatures whose lazily built caches (packed weights, K/V projections) are filled
         self.scheduler = scheduler or DDIMScheduler()
@@ -473,17 +471,25 @@ class ParallelDenoiser:
         """hipGraph replays issued so far by this object's captured forwards (bench.py asserts the timed steps were replays)"""
         return sum(g.replays for g in self._graphs.values())
 
+    # The side / lane streams are PROCESS-WIDE, one of each per device: HIP maps streams onto a handful of hardware queues
+    # round-robin (4 by default), so a process that creates a fresh stream per denoiser object ends up with a "side" stream that
+    # shares its queue with the main stream -- the CFG halves then run one after the other, silently (measured, round 6: a
+    # two-stream replay on the 4th stream created in the process took the serial 49.4 ms instead of 38.8).
+    _shared_streams: Dict[tuple, "torch.cuda.Stream"] = {}
+
+    @classmethod
+    def _shared_stream(cls, kind: str, dev):
+        key = (kind, str(dev))
+        st = cls._shared_streams.get(key)
+        if st is None:
+            st = cls._shared_streams[key] = torch.cuda.Stream(device=dev)
+        return st
+
     def _lane_stream(self, dev):
-        key = str(dev)
-        if key not in self._lane:
-            self._lane[key] = torch.cuda.Stream(device=dev)
-        return self._lane[key]
+        return self._shared_stream("lane", dev)
 
     def _side_stream(self, dev):
-        key = str(dev)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
-        return self._side[key]
+        return self._shared_stream("side", dev)
 
     @staticmethod
     def _slice_half(v, hs: List[int], halves: int):

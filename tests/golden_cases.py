@@ -298,7 +298,7 @@ def loop_case_unet_kwargs(case: dict, cfg: dict) -> dict:
         rows = torch.arange(bt).view(bt, 1, 1, 1)
         if case.get("controlnet_same_in_both_halves"):
             rows = rows % (bt // 2)   # row scale by FRAME: the two halves get the same residuals
-        kw["down_block_additional_residuals"] = [0.1 * torch.randn(1, c, a, b_, generator=g).repeat(bt, 1, 1, 1) * (1.0 + 0.05 * rows % 3)
+        kw["down_block_additional_residuals"] = [0.1 * torch.randn(1, c, a, b_, generator=g).repeat(bt, 1, 1, 1) * (1.0 + 0.05 * rows)
                                                  for c, a, b_ in shapes]
         kw["mid_block_additional_residual"] = 0.1 * torch.randn(bt // 2, mid[0], mid[1], mid[2], generator=g).repeat(2, 1, 1, 1)
     if case.get("pose"):

@@ -25,7 +25,9 @@ pytestmark = pytest.mark.gpu
 FREE_RUNNING_BAR = 1e-2   # north_star: |delta latent|max < 1e-2 on the loop's OUTPUT (free-running, every step)
 # stated limits, asserted per step < 1e-2 and free-running < 2e-2: the CFG halves decorrelated by the fixture, and the
 # fixture's adverse carrier layout
-STRESS_LOOP_CASES = ("refnet_pose_cfg5_loop", "musev_cfg2_loop20_w14_skip1")
+# ... each with its OWN ceiling just above what the MI355X measured (1.39e-2 / 1.45e-2, profiles/r05zc_*, r05zl_*): a drift beyond that
+# fails the suite, and the case stays visible as an exceedance of FREE_RUNNING_BAR in the printed table and in DESIGN 4
+STRESS_LOOP_CASES = {"refnet_pose_cfg5_loop": 1.5e-2, "musev_cfg2_loop20_w14_skip1": 1.6e-2}
 
 ARCH = dict(block_out_channels=(320, 640), layers_per_block=1,
             down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"), up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
@@ -398,7 +400,7 @@ def test_config2_loop_at_size_matches_reference_unet_loop_golden(name):
                    "free_running_abs_max": errs, "per_step_from_reference_latents": forced,
                    "latent_absmax": [float(np.abs(gold[f"latents_step{i + 1}"]).max()) for i in range(case["steps"])]}, f, indent=1)
     assert max(forced) < 1e-2, forced
-    assert max(errs) < (2e-2 if name in STRESS_LOOP_CASES else FREE_RUNNING_BAR), errs
+    assert max(errs) < STRESS_LOOP_CASES.get(name, FREE_RUNNING_BAR), errs
 
 
 def test_odd_unit_lane_is_bit_identical_to_running_the_groups_in_turn(monkeypatch):

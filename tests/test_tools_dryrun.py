@@ -135,3 +135,38 @@ def test_gemm_tuner_dry_run(monkeypatch, tmp_path):
     r = subprocess.run([sim_lib.CLANG, "-O0", "-std=c++17", "-pthread", "-w", "-fsyntax-only", "-I", sim_lib.SIM, "-I", str(tmp_path), str(tmp_path / "gemm_main.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_trace_overlap_on_a_synthetic_two_stream_trace(tmp_path):
+    """tools/trace_overlap.py (round 6: the in-step roofline from a rocprofv3 kernel trace with timestamps): two streams, known
+    overlaps -- the families' attributed times add up to the busy time, a family's time never exceeds the step, the overlap share and
+    the per-step cut at cfg_ddim_step are exact."""
+    import json
+    import subprocess
+    rows = ["\"Kind\",\"Agent_Id\",\"Queue_Id\",\"Stream_Id\",\"Kernel_Name\",\"Start_Timestamp\",\"End_Timestamp\""]
+    t = 1000
+
+    def k(q, name, s, e):
+        rows.append(f"\"KERNEL_DISPATCH\",1,{q},{q},\"{name}\",{s},{e}")
+    for step in range(3):   # 3 steps of 10 000 ns: the first is warm-up
+        b = t + step * 10000
+        k(1, "void gemm2_kernel<0, 2, 5>(GemmArgs2)", b + 0, b + 4000)        # alone 0-2000, beside the other stream's gemm 2000-4000
+        k(2, "void gemm2_kernel<1, 8, 5>(GemmArgs2)", b + 2000, b + 6000)     # beside attention 4000-6000
+        k(1, "void attn3_kernel<40, 47>(AttnArgs)", b + 4000, b + 7000)       # alone 6000-7000
+        k(2, "void gn_apply_kernel<false>(GnArgs)", b + 7000, b + 8000)       # alone
+        k(1, "void cfg_ddim_step_kernel(float*)", b + 9000, b + 10000)        # closes the step (idle 8000-9000)
+    p = tmp_path / "x_kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_overlap.py"), str(p), "--steps", "2", "--family-tflop", "0.01"],
+                         check=True, capture_output=True, text=True).stdout
+    d = json.loads(out)
+    assert d["steps"] == 2 and abs(d["wall_ms_per_step"] - 0.010) < 1e-9
+    assert abs(d["busy_ms_per_step"] - 0.009) < 1e-9                   # 0-8000 + 9000-10000
+    assert abs(d["overlap_frac_of_busy"] - 4000 / 9000) < 1e-9         # 2000-6000
+    fam = d["families"]
+    assert abs(fam["matrix"]["serial_ms"] - 0.008) < 1e-9 and abs(fam["matrix"]["union_ms"] - 0.006) < 1e-9
+    assert abs(fam["matrix"]["attributed_ms"] - (2000 + 2000 + 1000) / 1e6) < 1e-9   # alone, two gemms, half of gemm + attention
+    assert abs(fam["attention"]["attributed_ms"] - (1000 + 1000) / 1e6) < 1e-9
+    assert abs(sum(f["attributed_ms"] for f in fam.values()) - d["busy_ms_per_step"]) < 1e-9
+    assert all(f["attributed_ms"] <= d["wall_ms_per_step"] for f in fam.values())
+    assert abs(d["matrix_roofline"]["in_step"]["tflops"] - 0.01 / 5e-6) < 1e-3

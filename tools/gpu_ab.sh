@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Same-box back-to-back A/B of environment switches in the whole denoise step (fresh boxes differ by several per cent on one binary:
 # only legs of ONE call compare).   bash tools/gpu_ab.sh <log> "<extra bench.py args>" <name[:ENV=V ENV2=V ...]> ...
-#   e.g.  bash tools/gpu_ab.sh gpurun_out/r05f_ab.log "" base "ws:MUSEV_GEMM_WEIGHT_STATIONARY=1" base2
+#   e.g.  bash tools/gpu_ab.sh gpurun_out/r05f_ab.log "" base "ws0:MUSEV_OPS=GEMM_WEIGHT_STATIONARY=0" base2
 # every leg: python bench.py --steps 20 --warmup 5 (the driver's step count), no CPU baseline / roofline / config-4 legs
 LOG=$1; ARGS=$2; shift 2
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-config4"
