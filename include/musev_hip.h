@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 11
+#define MV_ABI_VERSION 12
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -83,7 +83,12 @@ typedef struct mv_gemm_desc {
     const float* ln_colsum;  /* fp32 [N]: sum_k w[n][k] of the fp16 values in `w`; NULL = no folding                      */
     const float* ln_colbias; /* fp32 [N]: sum_k beta_k W[n][k] + bias_n (bias / rowbias must be NULL)                      */
     float ln_eps;            /* LayerNorm epsilon                                                                          */
-    int32_t reserved0;
+    /* One weight matrix per GROUP of rows (ABI 12; LINEAR mode, no LayerNorm folding / carry): rows [g * w_group_rows,            */
+    /* (g + 1) * w_group_rows) multiply the [N][K] matrix at w + g * N * K.  A GroupNorm without activation folded into the        */
+    /* projection behind it (transformer_2d.py:260-271, temporal_transformer.py:239-247) has one scaled copy of the weights per    */
+    /* normalised item: mv_groupnorm_cs_fold_linear_f16 writes them.  M must be a whole number of groups; the launcher picks a     */
+    /* tile whose rows divide w_group_rows (a multiple of 32).  0 = one matrix.                                                     */
+    int32_t w_group_rows;
     /* Statistics of the OUTPUT, formed by the epilogue from the fp16 values it stores, for the normalisation that reads the    */
     /* tensor next (16-byte epilogue, one K slice, no GEGLU; mv_gemm_stats_layout says whether a launch can and how big):      */
     /*   colstats[m / rows_per_tile][n] = {sum, sum of squares} over that row tile -> mv_groupnorm_cs_f16 (replaces the        */
@@ -103,6 +108,9 @@ typedef struct mv_gemm_desc {
     /*    blocks per XCD) says the XCDs fetch at least 5 % less that way (mv_gemm_weight_stationary reports it): the small-M       */
     /*    levels.  Results are identical (every tile is still reduced over K in the same order by one block).                      */
     int32_t tile_order;
+    /* second fp16 half of the row bias (ABI 12): out gets rowbias[g][n] + rowbias_lo[g][n] (same layout and leading dimension) --  */
+    /* a bias formed in fp32 keeps ~22 bits as two fp16 rows (the folded GroupNorm's mean term); NULL = none                       */
+    const void* rowbias_lo;
 } mv_gemm_desc;
 
 /* The library holds no tuning state: everything that selects a kernel travels in the descriptor.  A call with a split-K
@@ -212,6 +220,21 @@ int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, int32_t c2, 
                         const void* gamma, const void* beta, int32_t silu, void* y, int32_t ldy,
                         const float* cs1, int32_t rpt1, const float* cs2, int32_t rpt2, int32_t nsplit, float* stat,
                         const void* x1_lo, void* y_lo, void* stream);
+/* GroupNorm WITHOUT activation folded into the Linear / 1x1 convolution that reads it (ABI 12; replaces the apply pass -- an HBM
+ * round trip of the activation -- of Transformer2DModel.norm -> proj_in, musev/models/transformer_2d.py:260-271,365-368, and of
+ * TransformerTemporalModel.norm -> proj_in, temporal_transformer.py:239-247):
+ *     proj(GN(x))[m][n] = sum_c (W[n][c] gamma_c rstd_{i,g(c)}) x[m][c]  +  b_n + sum_c W[n][c] beta_c - sum_c W'[n][c] mean_{i,g(c)}
+ * for row m of item i.  From the producer's column statistics of x (cs / rpt as in mv_groupnorm_cs_f16, single source) this call
+ * folds the group statistics (stat: fp32 scratch [n_items][num_groups][2]) and writes, per item, the scaled weights
+ * w_out[i][n][c] = fp16(W gamma rstd) and the bias as two fp16 halves rb_hi / rb_lo[i * rb_per_item + j][n] (fp32 sum, the mean term
+ * formed from the ROUNDED w_out so that it cancels what the product accumulates; rb_in[i * rb_per_item + j][n], ld ldrb_in, is added
+ * when given: the frame-embedding projection of the temporal transformer, rb_per_item = frames per item; else rb_per_item = 1).
+ * The projection is then mv_gemm_f16 on the RAW x with w = w_out, w_group_rows = rows, rowbias = rb_hi, rowbias_lo = rb_lo,
+ * rows_per_group = rows / rb_per_item, bias = NULL.  Two launches (fold of the statistics, weights); c <= 2048, c % 8 == 0. */
+int mv_groupnorm_cs_fold_linear_f16(const float* cs, int32_t rpt, int32_t c, int64_t n_items, int64_t rows, int32_t num_groups, float eps,
+                                    const void* gamma, const void* beta, const void* w, const void* bias, int32_t n_out,
+                                    const void* rb_in, int32_t ldrb_in, int32_t rb_per_item,
+                                    void* w_out, void* rb_hi, void* rb_lo, float* stat, void* stream);
 /* scratch size (in floats) of `partial` for the call above */
 int64_t mv_groupnorm_partial_floats(int64_t n_items, int32_t num_groups, int32_t nsplit);
 int32_t mv_groupnorm_default_nsplit(int64_t n_items, int64_t rows, int32_t c);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "l
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 11
+MV_ABI_VERSION = 12
 
 
 class MuseVHipError(RuntimeError):
@@ -34,10 +34,11 @@ class GemmDesc(C.Structure):
         ("t", C.c_int32), ("hw", C.c_int32),
         ("rows_per_group", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
         ("cfg", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("ln_colsum", C.c_void_p), ("ln_colbias", C.c_void_p), ("ln_eps", C.c_float), ("reserved0", C.c_int32),
+        ("ln_colsum", C.c_void_p), ("ln_colbias", C.c_void_p), ("ln_eps", C.c_float), ("w_group_rows", C.c_int32),
         ("colstats", C.c_void_p), ("colstats_floats", C.c_int64),
         ("residual_lo", C.c_void_p), ("c_lo", C.c_void_p),
         ("tile_order", C.c_int32),
+        ("rowbias_lo", C.c_void_p),
     ]
 
 
@@ -98,6 +99,8 @@ SIGNATURES = {
                                 _vp, _i32, _vp, _vp, _vp, _vp]),
     "mv_groupnorm_cs_f16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _i32,
                             _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mv_groupnorm_cs_fold_linear_f16": (_i32, [_vp, _i32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32,
+                                        _vp, _vp, _vp, _vp, _vp]),
     "mv_groupnorm_partial_floats": (_i64, [_i64, _i32, _i32]),
     "mv_groupnorm_default_nsplit": (_i32, [_i64, _i64, _i32]),
     "mv_layernorm_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp]),

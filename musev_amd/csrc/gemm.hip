@@ -62,6 +62,11 @@ struct GemmArgs {
     // s = value + residual + residual_lo is formed in fp32 and stored as c = fp16(s), c_lo = fp16(s - c); layers read c only
     const half_t* residual_lo;  // [M][ldr] or nullptr
     half_t* c_lo;               // [M][ldc] or nullptr (no carry)
+    // one weight matrix per GROUP of rows (LINEAR mode): rows [g * w_group_rows, (g + 1) * w_group_rows) multiply w + g * N * K -- a
+    // GroupNorm folded into the projection behind it has one scaled copy of the weights per normalised item (mv_groupnorm_cs_fold_linear_f16).
+    // A block tile never straddles two groups (the launcher picks a tile whose rows divide w_group_rows).  0 = one matrix.
+    int w_group_rows;
+    const half_t* rowbias_lo;   // second fp16 half of the row bias (same layout; the sum keeps ~22 bits), or nullptr
 };
 
 template <int TM, int TN>
@@ -228,6 +233,10 @@ __device__ __forceinline__ void epilogue_narrow(const GemmArgs& p, float4v (&acc
             if (p.rowbias) {
                 half4v b = *reinterpret_cast<const half4v*>(p.rowbias + grp * p.ldrb + n);
                 v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                if (p.rowbias_lo) {
+                    b = *reinterpret_cast<const half4v*>(p.rowbias_lo + grp * p.ldrb + n);
+                    v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                }
             }
             v *= alpha;
             if (p.act == MV_ACT_SILU) {
@@ -534,7 +543,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, q.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? q.a2_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, q.w_bytes, 0x00020000);
+    const half_t* const wmat = p.w_group_rows > 0 ? p.w + (long)(m0 / p.w_group_rows) * p.N * p.K : p.w;   // (block-uniform)
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wmat, 0, q.w_bytes, 0x00020000);
 
     // LDS-DMA lane geometry (the LDS image of a piece is lane-linear, so the swizzle lives on the SOURCE address):
     //   lane -> row lane/8, slot lane%8, fetches logical 16-byte chunk slot ^ row
@@ -606,12 +616,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm2_kernel(const GemmArgs
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = m0 + wm * 16 * TM + 16 * i + l15;
-                const half_t* rbp = p.rowbias + (long)((m < Mi ? m : Mi - 1) / p.rows_per_group) * p.ldrb + nw0 + 4 * g;
+                const long rbo = (long)((m < Mi ? m : Mi - 1) / p.rows_per_group) * p.ldrb + nw0 + 4 * g;
+                const half_t* rbp = p.rowbias + rbo;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (nw0 + 16 * j + 4 * g < p.N) {
                         const half4v b = *reinterpret_cast<const half4v*>(rbp + 16 * j);
                         acc[i][j] += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        if (p.rowbias_lo) {   // (block-uniform)
+                            const half4v bl = *reinterpret_cast<const half4v*>(p.rowbias_lo + rbo + 16 * j);
+                            acc[i][j] += float4v{(float)bl[0], (float)bl[1], (float)bl[2], (float)bl[3]};
+                        }
                     }
                 }
             }
@@ -930,8 +945,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
     }
     if (p.rowbias) {
-        const half4v b = *reinterpret_cast<const half4v*>(p.rowbias + (m / p.rows_per_group) * p.ldrb + n);
+        half4v b = *reinterpret_cast<const half4v*>(p.rowbias + (m / p.rows_per_group) * p.ldrb + n);
         v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+        if (p.rowbias_lo) {
+            b = *reinterpret_cast<const half4v*>(p.rowbias_lo + (m / p.rows_per_group) * p.ldrb + n);
+            v += float4v{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+        }
     }
     v *= p.alpha ? fabsf(*p.alpha) : 1.0f;
     if (p.act == MV_ACT_SILU) {
@@ -1261,6 +1280,17 @@ inline GemmChoice choose_config(int mode, const GemmArgs& g, int want_cfg, int w
         ch.cfg = gemm_carry_cfg(ch.cfg);
         ch.nsplit = 1;
     }
+    if (g.w_group_rows > 0 && g.w_group_rows % (16 * kGemmCfgs[ch.cfg].tm * kGemmCfgs[ch.cfg].wgm) != 0) {
+        // per-group weights: a block tile must not straddle two groups -- the largest 160-wide (GEGLU: 128-wide) tile whose rows divide the group
+        const int cand160[] = {8, 0, 1, 14}, cand128[] = {9, 2, 3, 3};   // 256 / 128 / 64 / 32 rows (64 for the 128-wide family)
+        for (int i = 0; i < 4; ++i) {
+            const int c = g.geglu ? cand128[i] : cand160[i];
+            if (g.w_group_rows % (16 * kGemmCfgs[c].tm * kGemmCfgs[c].wgm) == 0) {
+                ch.cfg = c;
+                break;
+            }
+        }
+    }
     return ch;
 }
 
@@ -1342,6 +1372,15 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     a.colstats = nullptr;  // (set by mv_gemm_f16 once the choice is known to support it)
     a.residual_lo = (const half_t*)d->residual_lo; a.c_lo = (half_t*)d->c_lo;
     MV_REQUIRE(!d->residual_lo || (d->residual && d->c_lo), "%s: residual_lo needs residual and c_lo", who);
+    a.w_group_rows = d->w_group_rows; a.rowbias_lo = (const half_t*)d->rowbias_lo;
+    MV_REQUIRE(d->w_group_rows >= 0, "%s: w_group_rows < 0", who);
+    if (d->w_group_rows > 0) {
+        MV_REQUIRE(d->mode == MV_GEMM_LINEAR && !d->ln_colsum && !d->c_lo, "%s: per-group weights (w_group_rows): LINEAR mode, no LayerNorm folding, no carry", who);
+        MV_REQUIRE(d->M % d->w_group_rows == 0 && d->w_group_rows % 32 == 0, "%s: M = %ld is not a whole number of w_group_rows = %d (a multiple of 32) row groups",
+                   who, (long)d->M, d->w_group_rows);
+        MV_REQUIRE((d->M / d->w_group_rows) * (long)d->N * d->K * 2 < 0x7fffffffL, "%s: the per-group weight matrices span 2 GiB or more", who);
+    }
+    MV_REQUIRE(!d->rowbias_lo || d->rowbias, "%s: rowbias_lo needs rowbias", who);
     if (d->c_lo)
         MV_REQUIRE(!d->geglu && !d->ln_colsum && d->splitk <= 1, "%s: the carry (c_lo) excludes GEGLU, LayerNorm folding and a forced K split", who);
     if (d->ln_colsum || d->ln_colbias) {
@@ -1370,7 +1409,7 @@ int gemm_prepare(const mv_gemm_desc* d, GemmArgs2& b, const char* who) {
     b.a_bytes = (unsigned)a_bytes; b.a2_bytes = (unsigned)a2_bytes; b.w_bytes = (unsigned)w_bytes;
     auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     b.wide = (d->N % 8 == 0) && (d->ldc % 8 == 0) && al16(d->c) && (!d->bias || al16(d->bias)) &&
-             (!d->rowbias || (d->ldrb % 8 == 0 && al16(d->rowbias))) &&
+             (!d->rowbias || (d->ldrb % 8 == 0 && al16(d->rowbias) && (!d->rowbias_lo || al16(d->rowbias_lo)))) &&
              (!d->residual || (d->ldr % 8 == 0 && al16(d->residual)));
     if (d->ln_colsum) MV_REQUIRE(b.wide, "%s: LayerNorm folding needs the 16-byte epilogue (N, ldc, ldr %% 8, aligned pointers)", who);
     if (d->c_lo)

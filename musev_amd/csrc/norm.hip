@@ -218,6 +218,82 @@ __global__ void gn_finalize_cs_kernel(const GnArgs a) {
     }
 }
 
+// GroupNorm folded into the projection behind it (mv_groupnorm_cs_fold_linear_f16): one block per (item, 4 output rows).  Thread t owns
+// the channel octet 8 t .. 8 t + 7 of each of its rows: w' = fp16(w gamma rstd) is stored, and the row's bias term
+//   sum_c w beta_c  -  sum_c w' mean_{g(c)}        (the ROUNDED w': it cancels what the product of the raw rows accumulates)
+// is folded in fp32 -- a fixed xor tree per wave, the waves in order: bit-reproducible -- and handed on as two fp16 halves.
+struct GnFoldArgs {
+    const float* stat;      // [items][groups][2] = mean, rstd
+    const half_t* gamma;
+    const half_t* beta;
+    const half_t* w;        // [n_out][c]
+    const half_t* bias;     // [n_out] or nullptr
+    const half_t* rb_in;    // [items * rb_per_item][ldrb_in] or nullptr
+    half_t* w_out;          // [items][n_out][c]
+    half_t* rb_hi;          // [items * rb_per_item][n_out]
+    half_t* rb_lo;
+    int c, n_out, groups, ldrb_in, rb_per_item;
+};
+
+__global__ __launch_bounds__(256) void gn_fold_weights_kernel(const GnFoldArgs a) {
+    __shared__ float red[4][4];   // [row of the block][wave]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long item = blockIdx.y;
+    const int n0 = blockIdx.x * 4;
+    const int oc = a.c >> 3, cpg = a.c / a.groups;
+    const float* st = a.stat + item * a.groups * 2;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = tid; o < oc; o += 256) {
+        const half8v gm = *reinterpret_cast<const half8v*>(a.gamma + 8 * o);
+        const half8v bt = *reinterpret_cast<const half8v*>(a.beta + 8 * o);
+        float sc[8], mu[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gI = (8 * o + j) / cpg;
+            mu[j] = st[2 * gI];
+            sc[j] = st[2 * gI + 1] * (float)gm[j];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + r;
+            if (n >= a.n_out) break;
+            const half8v wv = *reinterpret_cast<const half8v*>(a.w + (long)n * a.c + 8 * o);
+            half8v wo;
+            float acc = part[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float wf = (float)wv[j];
+                wo[j] = (half_t)(wf * sc[j]);
+                acc = fmaf(wf, (float)bt[j], acc);
+                acc = fmaf(-(float)wo[j], mu[j], acc);
+            }
+            part[r] = acc;
+            *reinterpret_cast<half8v*>(a.w_out + ((long)item * a.n_out + n) * a.c + 8 * o) = wo;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = part[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[r][wave] = v;
+    }
+    __syncthreads();
+    // thread (r, j): row r of the block, bias row j of the item
+    for (int idx = tid; idx < 4 * a.rb_per_item; idx += 256) {
+        const int r = idx & 3, j = idx >> 2;
+        const int n = n0 + r;
+        if (n >= a.n_out) continue;
+        float v = ((red[r][0] + red[r][1]) + red[r][2]) + red[r][3];
+        if (a.bias) v += (float)a.bias[n];
+        const long row = item * a.rb_per_item + j;
+        if (a.rb_in) v += (float)a.rb_in[row * a.ldrb_in + n];
+        const half_t hi = (half_t)v;
+        a.rb_hi[row * a.n_out + n] = hi;
+        a.rb_lo[row * a.n_out + n] = (half_t)(v - (float)hi);
+    }
+}
+
 __global__ void gn_apply_kernel(const GnArgs a) {
     const int C = a.oc * 8;
     const int o = threadIdx.x % a.oc, rl = threadIdx.x / a.oc;
@@ -611,6 +687,37 @@ extern "C" int mv_groupnorm_cs_f16(const void* x1, const void* x2, int32_t c1, i
     MV_REQUIRE(cs1, "mv_groupnorm_cs_f16: null column statistics");
     return gn_launch("mv_groupnorm_cs_f16", x1, x2, c1, c2, ld1, ld2, n_items, rows, num_groups, eps, gamma, beta, silu, y, ldy, nullptr,
                      nsplit, stat, cs1, rpt1, cs2, rpt2, x1_lo, y_lo, stream);
+}
+
+extern "C" int mv_groupnorm_cs_fold_linear_f16(const float* cs, int32_t rpt, int32_t c, int64_t n_items, int64_t rows, int32_t num_groups, float eps,
+                                               const void* gamma, const void* beta, const void* w, const void* bias, int32_t n_out,
+                                               const void* rb_in, int32_t ldrb_in, int32_t rb_per_item,
+                                               void* w_out, void* rb_hi, void* rb_lo, float* stat, void* stream) {
+    const char* who = "mv_groupnorm_cs_fold_linear_f16";
+    MV_REQUIRE(cs && gamma && beta && w && w_out && rb_hi && rb_lo && stat, "%s: null pointer", who);
+    MV_REQUIRE(c > 0 && c % 8 == 0 && c <= 2048 && num_groups > 0 && c % num_groups == 0, "%s: need C %% 8 == 0, C <= 2048, C %% groups == 0 (C=%d groups=%d)", who, c, num_groups);
+    MV_REQUIRE(n_items > 0 && n_items <= 65535 && rows > 0 && n_out > 0 && rb_per_item >= 1 && rows % rb_per_item == 0, "%s: bad sizes", who);
+    MV_REQUIRE(rpt > 0 && rows % rpt == 0 && (reinterpret_cast<uintptr_t>(cs) & 7) == 0, "%s: rows=%ld is not a whole number of the producer's %d-row statistic tiles", who, (long)rows, rpt);
+    MV_REQUIRE(n_items * num_groups <= 0x7fffffffL && n_items * (long)n_out * c * 2 < 0x7fffffffL, "%s: problem too large", who);
+    auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    MV_REQUIRE(al16(gamma) && al16(beta) && al16(w) && al16(w_out), "%s: gamma / beta / w / w_out must be 16-byte aligned", who);
+    MV_REQUIRE(!rb_in || ldrb_in >= n_out, "%s: ldrb_in < n_out", who);
+    hipStream_t s = (hipStream_t)stream;
+    GnArgs a{};
+    a.c1 = c; a.c2 = 0; a.rows = rows; a.oc = c / 8; a.stat = stat; a.n_items = n_items; a.groups = num_groups; a.eps = eps;
+    a.cs1 = cs; a.cs2 = nullptr; a.rpt1 = rpt; a.rpt2 = 0;
+    const long pairs = (long)num_groups * n_items;
+    const long per_block = (rows / rpt) * (long)(c / num_groups);
+    const int threads = per_block <= 512 ? 64 : per_block <= 2048 ? 256 : 1024;
+    hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3((unsigned)pairs), dim3(threads), 0, s, a);
+    MV_CHECK_LAUNCH("mv_groupnorm_cs_fold_linear_f16(fold)");
+    GnFoldArgs f;
+    f.stat = stat; f.gamma = (const half_t*)gamma; f.beta = (const half_t*)beta; f.w = (const half_t*)w; f.bias = (const half_t*)bias;
+    f.rb_in = (const half_t*)rb_in; f.w_out = (half_t*)w_out; f.rb_hi = (half_t*)rb_hi; f.rb_lo = (half_t*)rb_lo;
+    f.c = c; f.n_out = n_out; f.groups = num_groups; f.ldrb_in = ldrb_in; f.rb_per_item = rb_per_item;
+    hipLaunchKernelGGL(gn_fold_weights_kernel, dim3((unsigned)((n_out + 3) / 4), (unsigned)n_items), dim3(256), 0, s, f);
+    MV_CHECK_LAUNCH("mv_groupnorm_cs_fold_linear_f16(weights)");
+    return MV_OK;
 }
 
 extern "C" int mv_layernorm_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t c,

@@ -47,12 +47,18 @@ class TransformerTemporalModel(HipModule):
     def hip_forward(self, x: torch.Tensor, ctx: Ctx, geo: Geo) -> torch.Tensor:
         if self.skip_temporal_layers or ctx.skip_temporal:
             return x
-        h = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.b, geo.t * geo.hw, eps=self.norm.eps,
-                          silu=False, groups=self.norm.num_groups)
         fproj = ctx.proj_for(self)  # [B*T, C] column slice of the batched embedding projection
         if fproj is None:
             fproj = ops.gemm(ctx.femb_act, lin_w(self.frame_emb_proj), bias=lin_b(self.frame_emb_proj))
-        h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowbias=fproj, rows_per_group=geo.hw)
+        # norm -> proj_in + frame embedding (temporal_transformer.py:239-251): the statistics span (C / 32, T, H, W) of a batch item, so the
+        # folded form needs ONE scaled copy of proj_in's weights per item; the frame embedding rides in the folded row bias
+        h = ops.groupnorm_fold_linear(x, w16(self.norm.weight), w16(self.norm.bias), geo.b, geo.t * geo.hw, eps=self.norm.eps,
+                                      groups=self.norm.num_groups, w=lin_w(self.proj_in), bias=lin_b(self.proj_in),
+                                      rowbias=fproj, rb_per_item=geo.t)
+        if h is None:
+            h = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.b, geo.t * geo.hw, eps=self.norm.eps,
+                              silu=False, groups=self.norm.num_groups)
+            h = ops.gemm(h, lin_w(self.proj_in), bias=lin_b(self.proj_in), rowbias=fproj, rows_per_group=geo.hw)
         for blk in self.transformer_blocks:
             h = blk.hip_forward_temporal(h, geo)
         return ops.gemm(h, lin_w(self.proj_out), bias=lin_b(self.proj_out), residual=x, alpha=self.alpha(), colstats=True, carry=True)

@@ -40,6 +40,12 @@ class Transformer2DModel(HipModule):
 
     def hip_forward(self, x: torch.Tensor, ctx: Ctx, geo: Geo) -> torch.Tensor:
         def stem():
+            # norm -> proj_in (transformer_2d.py:260-271, 365-368): where the per-frame weight copies are small next to the tensor the
+            # GroupNorm is folded into them and its apply pass never runs (ops.groupnorm_fold_linear)
+            h0 = ops.groupnorm_fold_linear(x, w16(self.norm.weight), w16(self.norm.bias), geo.n, geo.hw, eps=self.norm.eps,
+                                           groups=self.norm.num_groups, w=lin_w(self.proj_in), bias=lin_b(self.proj_in))
+            if h0 is not None:
+                return h0
             g = ops.groupnorm(x, w16(self.norm.weight), w16(self.norm.bias), geo.n, geo.hw, eps=self.norm.eps, silu=False,
                               groups=self.norm.num_groups)
             return ops.gemm(g, lin_w(self.proj_in), bias=lin_b(self.proj_in))

@@ -21,7 +21,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
                    check)
 
 __all__ = [
-    "gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
+    "gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "groupnorm_fold_linear", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
     "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
     "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
@@ -45,7 +45,7 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 #   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
 #                      COLSTATS, CARRY, CARRY_MAX_C, FFN_FUSED, FFN_ROTATE, TSA_FUSED, LN_FOLD, LN_FOLD_MAX_K, ATTN_GROUPS, XATTN_RESIDENT,
-#                      GEMM_WEIGHT_STATIONARY); applied at the bottom of this file.  The per-feature variables of earlier rounds
+#                      GEMM_WEIGHT_STATIONARY, GN_FOLD, GN_FOLD_MAX_RATIO); applied at the bottom of this file.  The per-feature variables of earlier rounds
 #                      (MUSEV_CARRY, MUSEV_SHARE_PREFIX, MUSEV_XATTN_RESIDENT, MUSEV_GEMM_WEIGHT_STATIONARY, ...) are gone: setting one
 #                      raises at import, so that an A/B leg written from an old example cannot silently measure the baseline twice.
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
@@ -246,7 +246,7 @@ def _out(out: Optional[torch.Tensor], M: int, cols: int, like: torch.Tensor) -> 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_group: int = 0, residual=None, alpha=None, act: int = MV_ACT_NONE, geglu: bool = False,
          out: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None,
-         colstats: bool = False, carry: bool = False) -> torch.Tensor:
+         colstats: bool = False, carry: bool = False, w_groups: int = 1, rowbias_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(|alpha| * ([a | a2] @ w.T + bias + rowbias[row // rows_per_group])) + residual   (fp16, fp32 accumulate).
     ``colstats``: the output feeds a GroupNorm next -- emit its column statistics from the epilogue (see COLSTATS).
     ``carry``: the output is the residual stream -- keep the fp32 sum as two fp16 tensors (see CARRY).
@@ -256,6 +256,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     ``ln = (colsum, colbias, eps)`` (see :func:`fold_layernorm`): ``a`` holds RAW rows and ``w`` gamma-scaled weights; the kernel
     forms each row's LayerNorm statistics from the fragments it multiplies and applies them in the epilogue -- the result is
     LayerNorm(a) @ W.T + bias without the normalised tensor ever existing (no bias / rowbias / second source then).
+    ``w_groups`` > 1: ``w`` holds that many [N, K] matrices stacked ([w_groups * N, K]); rows [g * M / w_groups, (g + 1) * M / w_groups)
+    of ``a`` multiply matrix g (:func:`groupnorm_fold_linear`).  ``rowbias_lo``: second fp16 half of ``rowbias`` (same shape).
     """
     a = _mat(a, "a")
     w = _mat(w, "w")
@@ -264,6 +266,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     M, c1 = a.shape
     N, K = w.shape
     d = GemmDesc()
+    if w_groups > 1:
+        if N % w_groups or M % w_groups:
+            raise ValueError("gemm: w_groups must divide the rows of w and of a")
+        N //= w_groups
+        d.w_group_rows = M // w_groups
     d.a, d.lda, d.c1 = a.data_ptr(), a.stride(0), c1
     if a2 is not None:
         a2 = _mat(a2, "a2")
@@ -278,6 +285,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     d.M, d.N, d.K = M, N, K
     d.mode, d.geglu = MV_GEMM_LINEAR, int(geglu)
     _fill_epilogue(d, N, M, bias, rowbias, rows_per_group, residual, alpha, act, cols)
+    if rowbias_lo is not None:
+        rl = _mat(rowbias_lo, "rowbias_lo")
+        if rowbias is None or rl.shape != rowbias.shape or rl.stride(0) != rowbias.stride(0):
+            raise ValueError("rowbias_lo: needs rowbias of the same shape and row stride")
+        d.rowbias_lo = rl.data_ptr()
     if ln is not None:
         cs, cb, eps = ln
         for v, nm in ((cs, "ln colsum"), (cb, "ln colbias")):
@@ -286,7 +298,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if bias is not None or rowbias is not None or a2 is not None:
             raise ValueError("gemm(ln=...): the bias is part of colbias; no rowbias / second source")
         d.ln_colsum, d.ln_colbias, d.ln_eps = cs.data_ptr(), cb.data_ptr(), float(eps)
-    keep = (a, a2, w, o, bias, rowbias, residual, alpha, ln)
+    keep = (a, a2, w, o, bias, rowbias, rowbias_lo, residual, alpha, ln)
     if carry and not geglu and ln is None:
         keep = _carry_setup(d, o, residual, carry, keep)
     _launch_gemm(d, "mv_gemm_f16", a.device, keep, o if colstats and not geglu else None)
@@ -568,6 +580,54 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items:
                                n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(), int(silu),
                                o.data_ptr(), o.stride(0), partial_ptr, nsplit, stat_ptr, _p(x_lo), _p(y_lo), _stream()), "mv_groupnorm_f16")
     return o
+
+
+
+# GroupNorm without activation folded into the projection behind it (Transformer2DModel.norm -> proj_in, TransformerTemporalModel.norm ->
+# proj_in): the apply pass -- an HBM round trip of the activation -- is replaced by one scaled copy of the projection's weights per
+# normalised item (mv_groupnorm_cs_fold_linear_f16) and a per-item row bias.  Taken where the copies are small next to the tensor:
+# items * N * C <= GN_FOLD_MAX_RATIO * rows_total * C.  A/B: MUSEV_OPS="GN_FOLD=0" keeps groupnorm() + the plain projection.
+GN_FOLD: bool = True
+GN_FOLD_MAX_RATIO: float = 0.35
+GN_FOLD_HITS: int = 0
+
+
+def groupnorm_fold_linear(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_items: int, rows: int, *, eps: float, groups: int,
+                          w: torch.Tensor, bias: Optional[torch.Tensor], rowbias: Optional[torch.Tensor] = None, rb_per_item: int = 1,
+                          out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Linear(GroupNorm(x)) (+ rowbias[row // (rows / rb_per_item)]) with the normalisation folded into per-item weights; ``None`` when
+    the fold does not apply (no producer statistics on ``x``, or the weight copies would not be small next to the tensor) -- the caller
+    then takes :func:`groupnorm` + :func:`gemm`."""
+    if not GN_FOLD:
+        return None
+    x = _mat(x, "x")
+    w = _mat(w, "w")
+    M, c = x.shape
+    N = w.shape[0]
+    cs = getattr(x, "_mv_colstats", None) if COLSTATS else None
+    if cs is None or (len(cs) > 2 and cs[2] != x._version) or rows % cs[1] or M != n_items * rows or w.shape[1] != c or not w.is_contiguous():
+        return None
+    if n_items * N > GN_FOLD_MAX_RATIO * M or rows % 32 or rows % rb_per_item or c % 8 or c > 2048 or c % groups:
+        return None
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(bias, "bias", N)
+    rb_in = None
+    if rowbias is not None:
+        rb_in = _mat(rowbias, "rowbias")
+        if rb_in.shape[0] != n_items * rb_per_item or rb_in.shape[1] != N:
+            raise ValueError("groupnorm_fold_linear: rowbias must be [n_items * rb_per_item, N]")
+    dev = x.device
+    w_f = torch.empty((n_items * N, c), dtype=torch.float16, device=dev)
+    rb = torch.empty((2, n_items * rb_per_item, N), dtype=torch.float16, device=dev)
+    stat = torch.empty(n_items * 2 * groups, dtype=torch.float32, device=dev)
+    check(_lib.load().mv_groupnorm_cs_fold_linear_f16(cs[0].data_ptr(), cs[1], c, n_items, rows, groups, float(eps), gamma.data_ptr(), beta.data_ptr(),
+                                                      w.data_ptr(), _p(bias), N, _p(rb_in), rb_in.stride(0) if rb_in is not None else 0, rb_per_item,
+                                                      w_f.data_ptr(), rb[0].data_ptr(), rb[1].data_ptr(), stat.data_ptr(), _stream()),
+          "mv_groupnorm_cs_fold_linear_f16")
+    global GN_FOLD_HITS
+    GN_FOLD_HITS += 1
+    return gemm(x, w_f, rowbias=rb[0], rowbias_lo=rb[1], rows_per_group=rows // rb_per_item, w_groups=n_items, out=out)
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
@@ -912,10 +972,10 @@ def _apply_env_overrides() -> None:
     for item in filter(None, (x.strip() for x in spec.split(","))):
         name, _, val = item.partition("=")
         if name not in ("COLSTATS", "CARRY", "CARRY_MAX_C", "FFN_FUSED", "FFN_ROTATE", "LN_FOLD", "ATTN_GROUPS", "XATTN_RESIDENT",
-                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K"):
+                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K", "GN_FOLD", "GN_FOLD_MAX_RATIO"):
             raise ValueError(f"MUSEV_OPS: unknown switch {name!r}")
         cur = globals()[name]
-        globals()[name] = bool(int(val)) if isinstance(cur, bool) else int(val)
+        globals()[name] = bool(int(val)) if isinstance(cur, bool) else float(val) if isinstance(cur, float) else int(val)
 
 
 _apply_env_overrides()

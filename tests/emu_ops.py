@@ -502,6 +502,44 @@ def bthwc_to_bcthw(x, b, t, h, w, dtype=torch.float16):
     return x.reshape(b, t, h, w, -1).permute(0, 4, 1, 2, 3).to(dtype).contiguous()
 
 
+
+GN_FOLD_MAX_RATIO = 0.35   # musev_amd.ops.GN_FOLD_MAX_RATIO
+
+
+def groupnorm_fold_linear(x, gamma, beta, n_items, rows, *, eps, groups, w, bias, rowbias=None, rb_per_item=1, out=None):
+    """the contract of ops.groupnorm_fold_linear (mv_groupnorm_cs_fold_linear_f16 + the per-group-weight projection): per item the fp16
+    weights W gamma rstd, the bias term in fp32 from the ROUNDED weights; the emulation has no producer statistics, so the fold is taken
+    wherever the size rule allows it"""
+    _mat(x, "x")
+    _mat(w, "w")
+    M, c = x.shape
+    N = w.shape[0]
+    _req(M == n_items * rows and w.shape[1] == c, "groupnorm_fold_linear: shapes")
+    if n_items * N > GN_FOLD_MAX_RATIO * M or rows % 32 or rows % rb_per_item or c % 8 or c > 2048 or c % groups:
+        return None
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    if rowbias is not None:
+        _req(tuple(rowbias.shape) == (n_items * rb_per_item, N), "groupnorm_fold_linear: rowbias must be [n_items * rb_per_item, N]")
+    xf = x.float().reshape(n_items, rows, groups, c // groups)
+    mean = xf.mean(dim=(1, 3))                                   # [items, groups]
+    rstd = torch.rsqrt(xf.var(dim=(1, 3), unbiased=False) + eps)
+    cpg = c // groups
+    mean_c, rstd_c = mean.repeat_interleave(cpg, dim=1), rstd.repeat_interleave(cpg, dim=1)   # [items, c]
+    wf = (w.float()[None] * (gamma.float()[None] * rstd_c)[:, None, :]).half()                # [items, N, c]
+    b = (w.float() @ beta.float())[None] - torch.einsum("inc,ic->in", wf.float(), mean_c)      # [items, N]
+    if bias is not None:
+        b = b + bias.float()[None]
+    b = b.repeat_interleave(rb_per_item, dim=0)
+    if rowbias is not None:
+        b = b + rowbias.float()
+    hi = b.half()
+    lo = (b - hi.float()).half()
+    y = torch.einsum("irc,inc->irn", x.float().reshape(n_items, rows, c), wf.float()).reshape(M, N)
+    y = y + (hi.float() + lo.float())[torch.arange(M) // (rows // rb_per_item)]
+    return _store(y, out)
+
+
 def pack_geglu(w, bias):
     half = w.shape[0] // 2
     idx = torch.arange(half).view(-1, 16)
@@ -509,7 +547,7 @@ def pack_geglu(w, bias):
     return w.index_select(0, perm).contiguous(), (bias.index_select(0, perm).contiguous() if bias is not None else None)
 
 
-EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
+EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "groupnorm_fold_linear", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
             "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu", "tsa_fused_applies", "pack_tsa_qkv", "pack_tsa_out", "temporal_attn_block"]

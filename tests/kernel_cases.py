@@ -432,6 +432,47 @@ def case_colstats_groupnorm(kind="conv", n=3, h=16, w=16, cin=64, c=320, c2=0, c
     return _all_ok(results)
 
 
+def case_gn_fold_linear(kind="spatial", n=4, h=16, w=16, cin=64, c=320, n_out=320, cfg=None, seed=900, offset=0.0):
+    """GroupNorm (no activation) folded into the projection behind it (ops.groupnorm_fold_linear: mv_groupnorm_cs_fold_linear_f16 + the
+    per-group-weight GEMM with a two-half row bias).  spatial: one item per frame (Transformer2DModel.norm -> proj_in); temporal: ONE
+    item over all frames + a per-frame row bias (TransformerTemporalModel.norm -> proj_in + frame embedding).  Checked against torch
+    fp32 Linear(group_norm(x)) of the STORED producer output, and against the unfolded HIP path (groupnorm + gemm)."""
+    from musev_amd import ops
+    hw = h * w
+    x_in = _rand((n * hw, cin), seed)
+    wt = _rand((c, cin), seed + 1, 1.0 / math.sqrt(cin))
+    x = ops.gemm(x_in, wt, bias=_rand((c,), seed + 2) + offset, residual=_rand((n * hw, c), seed + 3), colstats=True)   # producer with column statistics
+    gamma = _rand((c,), seed + 4) * 0.2 + 1.0
+    beta = _rand((c,), seed + 5, 0.2)
+    wp = _rand((n_out, c), seed + 6, 1.0 / math.sqrt(c))
+    bp = _rand((n_out,), seed + 7, 0.3)
+    if kind == "spatial":
+        n_items, rows, rb, rbpi = n, hw, None, 1
+    else:
+        n_items, rows, rbpi = 1, n * hw, n
+        rb = _rand((n, n_out + 8), seed + 8, 0.5)[:, :n_out]   # a column slice of a wider tensor, as the batched embedding projection hands it over
+    old, old_ratio = ops.GEMM_CFG, ops.GN_FOLD_MAX_RATIO
+    ops.GN_FOLD_MAX_RATIO = 1e9   # (the size rule is the caller's business: here the fold itself is under test)
+    if cfg is not None:
+        ops.GEMM_CFG = cfg
+    try:
+        hits = ops.GN_FOLD_HITS
+        got = ops.groupnorm_fold_linear(x, gamma, beta, n_items, rows, eps=1e-6, groups=32, w=wp, bias=bp, rowbias=rb, rb_per_item=rbpi)
+    finally:
+        ops.GEMM_CFG, ops.GN_FOLD_MAX_RATIO = old, old_ratio
+    if got is None or ops.GN_FOLD_HITS != hits + 1:
+        return {"name": f"gn_fold_linear {kind}", "ok": False, "max_abs_err": float("nan"), "detail": "the fold was not taken"}
+    g = F.group_norm(x.float().reshape(n_items, rows, c).permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-6).permute(0, 2, 1).reshape(n_items * rows, c)
+    ref = g @ wp.float().t() + bp.float()
+    if rb is not None:
+        ref = ref + rb.float()[torch.arange(n * hw, device=ref.device) // hw]
+    res = [_cmp(f"gn_fold_linear {kind} cfg{cfg} vs torch fp32", got, ref, atol=6e-3)]
+    gh = ops.groupnorm(x.clone(), gamma, beta, n_items, rows, eps=1e-6, silu=False)
+    plain = ops.gemm(gh, wp, bias=bp, rowbias=rb, rows_per_group=hw if rb is not None else 0)
+    res.append(_cmp(f"gn_fold_linear {kind} cfg{cfg} vs groupnorm + gemm", got, plain.float(), atol=8e-3))
+    return _all_ok(res)
+
+
 def case_layernorm(rows=999, c=640, seed=50):
     from musev_amd import ops
     x = _rand((rows, c), seed) * 2.0 + 0.5
@@ -918,6 +959,11 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("colstats_tconv_groupnorm", lambda: case_colstats_groupnorm(kind="tconv", n=5, h=8, w=16, c=320, seed=320)),
     ("colstats_linear_ragged_n", lambda: case_colstats_groupnorm(kind="linear", n=2, cin=320, c=640, seed=330)),
     ("colstats_every_tile", lambda: _all_ok([case_colstats_groupnorm(n=2, c=320, seed=340 + c, cfg=c) for c in range(19)])),
+    ("gn_fold_linear_spatial", case_gn_fold_linear),
+    ("gn_fold_linear_temporal", lambda: case_gn_fold_linear(kind="temporal", n=5, h=8, w=16, seed=910)),
+    ("gn_fold_linear_large_mean_c640", lambda: case_gn_fold_linear(n=3, h=16, w=16, c=640, n_out=640, seed=920, offset=3.0)),
+    ("gn_fold_linear_64_row_items", lambda: case_gn_fold_linear(n=6, h=8, w=8, c=1280, n_out=1280, cin=128, seed=930)),   # a 256-row tile would straddle two items
+    ("gn_fold_linear_every_tile", lambda: _all_ok([case_gn_fold_linear(n=2, h=16, w=16, seed=940 + c_, cfg=c_) for c_ in range(19)])),
     ("carry_linear", case_carry),
     ("carry_conv", lambda: case_carry(kind="conv", seed=610)),
     ("carry_tconv", lambda: case_carry(kind="tconv", n=5, h=8, w=16, seed=620)),

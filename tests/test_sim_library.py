@@ -31,6 +31,9 @@ CASES = {
     "colstats_linear_ragged": "kc.case_colstats_groupnorm(kind='linear', n=3, h=8, w=8, cin=64, c=96, rows_mul=1)",
     "colstats_linear_fold_of_256": "kc.case_colstats_groupnorm(kind='linear', n=1, h=96, w=96, cin=64, c=64, cfg=1)",  # 576 pairs per group: the 256-thread fold played by one wave
     "colstats_every_tile": "kc._all_ok([kc.case_colstats_groupnorm(n=2, h=8, w=16, cin=64, c=64, seed=340 + c, cfg=c) for c in range(19)])",
+    "gn_fold_linear_spatial": "kc.case_gn_fold_linear(n=3, h=8, w=8, cin=64, c=64, n_out=96)",
+    "gn_fold_linear_temporal": "kc.case_gn_fold_linear(kind='temporal', n=3, h=8, w=8, cin=64, c=64, n_out=64, seed=910)",
+    "gn_fold_linear_every_tile": "kc._all_ok([kc.case_gn_fold_linear(n=2, h=8, w=16, cin=64, c=64, n_out=64, seed=940 + c, cfg=c) for c in range(19)])",
     "carry_linear": "kc.case_carry(kind='linear', n=2, h=8, w=12, cin=64, c=160)",
     "carry_conv": "kc.case_carry(kind='conv', n=2, h=8, w=12, cin=64, c=64)",
     "carry_tconv": "kc.case_carry(kind='tconv', n=3, h=4, w=12, c=64)",
@@ -102,7 +105,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block",
+    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
