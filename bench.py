@@ -505,6 +505,10 @@ def main():
                 rows.append({"mode": 4, "M": int(d.B) * int(d.T) * int(d.HW), "N": int(d.C), "K": 4 * int(d.C), "geglu": 0, "ln": 1, "residual": 1,
                              "colstats": 0, "cfg": -1, "nsplit": 1, "algorithmic_bytes": nb})
                 continue
+            if isinstance(d, _lib.XabDesc):   # the fused text cross-attention sub-block (mv_xattn_block_f16): to_q + to_out
+                rows.append({"mode": 5, "M": int(d.M), "N": int(d.C), "K": 2 * int(d.C), "geglu": 0, "ln": 1, "residual": 1,
+                             "colstats": 0, "cfg": -1, "nsplit": 1, "algorithmic_bytes": nb})
+                continue
             cfg, ns = C.c_int32(), C.c_int32()
             _lib.load().mv_gemm_choice(C.byref(d), C.byref(cfg), C.byref(ns))
             rows.append({"mode": int(d.mode), "M": int(d.M), "N": int(d.N), "K": int(d.K), "geglu": int(d.geglu), "ln": int(bool(d.ln_colsum)),
@@ -539,10 +543,10 @@ def main():
         rec_all, ops.GEMM_RECORD = ops.GEMM_RECORD, None
         den.use_graphs = True
         from musev_amd import _lib as _mvlib
-        names = {0: "linear", 1: "conv3x3", 2: "tconv3", 3: "ffn_fused", 4: "tsa_fused"}
+        names = {0: "linear", 1: "conv3x3", 2: "tconv3", 3: "ffn_fused", 4: "tsa_fused", 5: "xab_fused"}
 
         def rmode(d):
-            return 3 if isinstance(d, _mvlib.FfnDesc) else 4 if isinstance(d, _mvlib.TsaDesc) else int(d.mode)
+            return 3 if isinstance(d, _mvlib.FfnDesc) else 4 if isinstance(d, _mvlib.TsaDesc) else 5 if isinstance(d, _mvlib.XabDesc) else int(d.mode)
         reps = 3
         ops.replay_gemms(rec_all, 1)  # warm (clocks, code objects)
         fam_ms = ops.replay_gemms(rec_all, reps) / reps

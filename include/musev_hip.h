@@ -194,6 +194,36 @@ typedef struct mv_tsa_desc {
 } mv_tsa_desc;
 int mv_temporal_attn_block_f16(const mv_tsa_desc* d, void* stream);
 
+/* ---- the text cross-attention sub-block of a spatial BasicTransformerBlock as ONE launch (ABI 12; level 0: C = 320 = 8 heads x 40) ----
+ *   out = x + to_out( softmax( q K^T scale ) V ) + bias_o,   q = LayerNorm(x) Wq^T
+ * replaces norm2 -> attn2.to_q -> attention over the prompt's keys / values -> attn2.to_out + residual of
+ * musev/models/attention.py:345-396 / attention_processor.py:233-300 (one softmax group: the text tokens) where the three-launch form
+ * (LayerNorm-folded projection, mv_attention_f16 with resident_kv, mv_gemm_f16 + residual) moves q and the attention output through
+ * HBM.  k / v are the prompt's PROJECTED keys / values (constant over the denoise loop: the caller projects them once): rows
+ * [kvb * len, (kvb + 1) * len) belong to key batch kvb = row / rows_per_kvb of x.
+ * wq: [4][128][C] -- per head pair (2 p, 2 p + 1) the rows of to_q.weight [q_a (40 rows) | 24 zero rows | q_b (40) | 24 zero rows];
+ * wo: [C][heads * 64] as for mv_tsa_desc.  MV_ERR_INVALID for any other geometry (more than 80 keys, several softmax groups, other
+ * widths: the caller keeps the three-launch form there). */
+typedef struct mv_xab_desc {
+    const void* x;           /* fp16 [M][ldx], C columns: the rows the LayerNorm reads, also the residual       */
+    const void* ln_gamma;    /* fp16 [C], 16-byte aligned                                                       */
+    const void* ln_beta;     /* fp16 [C], 16-byte aligned                                                       */
+    const void* wq;          /* fp16 [4][128][C] packed (see above)                                             */
+    const void* k;           /* fp16 [key batches][len][ldk], 16-byte aligned                                   */
+    const void* v;           /* fp16 [key batches][len][ldv]                                                    */
+    const void* wo;          /* fp16 [C][heads * 64] packed                                                     */
+    const void* bias_o;      /* fp16 [C] or NULL                                                                */
+    void* out;               /* fp16 [M][ldo]                                                                   */
+    int64_t M;
+    int32_t rows_per_kvb;    /* rows of x per key batch (a multiple of 128)                                     */
+    int32_t len;             /* keys per batch, 1 .. 80                                                         */
+    int32_t C, heads, d;     /* 320, 8, 40                                                                      */
+    int32_t ldk, ldv, ldx, ldo; /* leading dimensions in elements (multiples of 8, >= C)                        */
+    float ln_eps, scale;     /* LayerNorm epsilon; softmax scale (d^-0.5), > 0                                  */
+    int32_t flags;           /* bit 0: workgroups walk the head pairs from different starting pairs             */
+} mv_xab_desc;
+int mv_xattn_block_f16(const mv_xab_desc* d, void* stream);
+
 /* ---- GroupNorm (K1) --------------------------------------------------------------------------------
  * replaces: torch.nn.GroupNorm(32, C)(+SiLU) in ResnetBlock2D.norm1/norm2, Transformer2DModel.norm
  *   (musev/models/transformer_2d.py:260), TransformerTemporalModel.norm (temporal_transformer.py:117,239),

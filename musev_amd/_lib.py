@@ -60,6 +60,16 @@ class TsaDesc(C.Structure):
     ]
 
 
+class XabDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("wq", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("wo", C.c_void_p), ("bias_o", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int64), ("rows_per_kvb", C.c_int32), ("len", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32),
+        ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("ln_eps", C.c_float), ("scale", C.c_float),
+        ("flags", C.c_int32),
+    ]
+
+
 class AttnSeg(C.Structure):
     _fields_ = [
         ("k", C.c_void_p), ("v", C.c_void_p),
@@ -88,6 +98,7 @@ SIGNATURES = {
     "mv_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "mv_ffn_geglu_f16": (_i32, [C.POINTER(FfnDesc), _vp]),
     "mv_temporal_attn_block_f16": (_i32, [C.POINTER(TsaDesc), _vp]),
+    "mv_xattn_block_f16": (_i32, [C.POINTER(XabDesc), _vp]),
     "mv_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
     "mv_gemm_choice": (_i32, [C.POINTER(GemmDesc), _vp, _vp]),
     "mv_gemm_weight_stationary": (_i32, [C.POINTER(GemmDesc)]),

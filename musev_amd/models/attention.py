@@ -48,11 +48,11 @@ class BasicTransformerBlock(HipModule):
         if ctx.refer_self is not None or ctx.refer_self_write is not None:
             ctx.split()  # refer_self_attn_emb is handed over (or collected) per CFG half
         x_in = x
-        x, q = ctx.shared((id(self), "attn1+q"), lambda: self._self_attention_and_query(x_in, ctx, geo, reference_only))
+        x, q = ctx.shared((id(self), "attn1+q"), lambda: self._self_attention_and_query(x_in, ctx, geo, reference_only, use_ip))
         ctx.split()  # the text (and the image-prompt tokens) differ between the CFG halves from here on
         return self._cross_attention_and_ff(x, q, ctx, geo, use_ip)
 
-    def _self_attention_and_query(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool):
+    def _self_attention_and_query(self, x: torch.Tensor, ctx: Ctx, geo: Geo, reference_only: bool, use_ip: bool = False):
         """norm1 -> reference-only self-attention -> + x, then norm2 -> to_q of the cross-attention: the part of the block that
         does not see the text (shared by the CFG halves in the first block of the network, runtime.PrefixMemo)"""
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
@@ -84,7 +84,17 @@ class BasicTransformerBlock(HipModule):
         att = ops.attention(qkv[:, :c], segs, geo.n, geo.hw, h, d, a1.scale)
         x = a1.project_out(att, residual=x)
         a2 = self.attn2
+        if self._xab_applies(ctx, geo, use_ip):
+            return x, None   # level 0, text only: norm2 -> to_q -> attention -> to_out + x is one launch (_cross_attention_and_ff)
         return x, ln_linear(a2, "q", x, self.norm2, lambda: lin_w(a2.to_q).contiguous())
+
+    def _xab_applies(self, ctx: Ctx, geo: Geo, use_ip: bool) -> bool:
+        """the text cross-attention sub-block as one launch (ops.xattn_block): one softmax group of <= 80 keys at C = 320 = 8 x 40"""
+        a2 = self.attn2
+        if a2.to_q.bias is not None or (use_ip and a2.cross_attn_temporal_cond and ctx.clip is not None and ctx.ip_scale > 0) or \
+                (a2.need_t2i_ip_adapter_face and ctx.face is not None and ctx.face_scale > 0):
+            return False
+        return ops.xab_fused_applies(self.heads * self.dim_head, self.heads, self.dim_head, int(ctx.text_len), geo.t * geo.hw)
 
     def _cross_attention_and_ff(self, x: torch.Tensor, q: torch.Tensor, ctx: Ctx, geo: Geo, use_ip: bool) -> torch.Tensor:
         c, h, d = self.heads * self.dim_head, self.heads, self.dim_head
@@ -95,6 +105,12 @@ class BasicTransformerBlock(HipModule):
         # text cross-attention + ip_adapter_scale * image-prompt attention (+ face_scale * FaceID attention, attention_processor.py:
         # 258-300, 308-338): every term its own softmax of the same queries.  Head dims 40 / 80: ONE launch with softmax groups (the
         # queries read once, the output written once); d = 160: one launch per term, accumulated into the output.
+        if q is None:
+            x = ops.xattn_block(x, w16(self.norm2.weight), w16(self.norm2.bias), self.norm2.eps,
+                                a2.packed("xab_q", lambda: ops.pack_xab_q(lin_w(a2.to_q), h, d)), tkv[:, :c], tkv[:, c:], int(ctx.text_len),
+                                geo.t * geo.hw, a2.packed("tsa_out", lambda: ops.pack_tsa_out(lin_w(a2.to_out[0]), h, d)), lin_b(a2.to_out[0]),
+                                h, d, a2.scale)
+            return self.ff.hip_forward(x, residual=x, norm=self.norm3)
         terms = [((tkv[:, :c], tkv[:, c:], ctx.text_len, geo.t, 1, 0), 1.0)]
         if use_ip and a2.cross_attn_temporal_cond and ctx.clip is not None and ctx.ip_scale > 0:
             ikv = cache.setdefault("clip_kv", SourceCache()).get(ctx.clip_src, lambda _s: ops.gemm(ctx.clip, a2.w_kv_ip()))

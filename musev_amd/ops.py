@@ -21,7 +21,7 @@ from ._lib import (AttnDesc, GemmDesc, MV_ACT_NONE, MV_ACT_SILU, MV_GEMM_CONV3X3
                    check)
 
 __all__ = [
-    "gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "groupnorm_fold_linear", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
+    "gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "groupnorm_fold_linear", "xab_fused_applies", "pack_xab_q", "xattn_block", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
     "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "bcthw_to_bthwc", "bthwc_to_bcthw",
     "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step", "pack_conv_weight", "probe_tr16", "MV_ACT_NONE", "MV_ACT_SILU",
 ]
@@ -45,7 +45,7 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 #   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
 #                      COLSTATS, CARRY, CARRY_MAX_C, FFN_FUSED, FFN_ROTATE, TSA_FUSED, LN_FOLD, LN_FOLD_MAX_K, ATTN_GROUPS, XATTN_RESIDENT,
-#                      GEMM_WEIGHT_STATIONARY, GN_FOLD, GN_FOLD_MAX_RATIO); applied at the bottom of this file.  The per-feature variables of earlier rounds
+#                      GEMM_WEIGHT_STATIONARY, GN_FOLD, GN_FOLD_MAX_RATIO, XAB_FUSED); applied at the bottom of this file.  The per-feature variables of earlier rounds
 #                      (MUSEV_CARRY, MUSEV_SHARE_PREFIX, MUSEV_XATTN_RESIDENT, MUSEV_GEMM_WEIGHT_STATIONARY, ...) are gone: setting one
 #                      raises at import, so that an A/B leg written from an old example cannot silently measure the baseline twice.
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
@@ -155,6 +155,8 @@ def _replay_one(lib, d, st) -> None:
         check(lib.mv_ffn_geglu_f16(C.byref(d), st), "mv_ffn_geglu_f16(replay)")
     elif isinstance(d, _lib.TsaDesc):
         check(lib.mv_temporal_attn_block_f16(C.byref(d), st), "mv_temporal_attn_block_f16(replay)")
+    elif isinstance(d, _lib.XabDesc):
+        check(lib.mv_xattn_block_f16(C.byref(d), st), "mv_xattn_block_f16(replay)")
     else:
         check(lib.mv_gemm_f16(C.byref(d), st), "mv_gemm_f16(replay)")
 
@@ -165,6 +167,8 @@ def record_flops(d) -> float:
         return 2.0 * d.M * d.C * 2 * d.H + 2.0 * d.M * d.H * d.C
     if isinstance(d, _lib.TsaDesc):   # the q / k / v projection and to_out (the T x T attention itself is not counted, as before)
         return 2.0 * d.B * d.T * d.HW * d.C * 4 * d.C
+    if isinstance(d, _lib.XabDesc):   # the q projection and to_out (the attention over <= 80 keys is not counted, as for the separate launch)
+        return 2.0 * d.M * d.C * 2 * d.C
     return 2.0 * d.M * d.N * d.K
 
 
@@ -399,6 +403,55 @@ def temporal_attn_block(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor
     if GEMM_RECORD is not None:  # matrix work of the same family (the q / k / v projection + to_out): recorded next to the mv_gemm_f16 launches
         nbytes = 2 * (3 * M * c + 4 * c * c)   # x twice (rows, residual) and the output once; the four weight matrices once
         GEMM_RECORD.append((_lib.TsaDesc.from_buffer_copy(ds), (x, gamma, beta, wqkv_p, wo_p, bias_o, o), nbytes, _stream()))
+    return o
+
+
+
+# The text cross-attention sub-block of level 0 as one launch (mv_xattn_block_f16; A/B: MUSEV_OPS="XAB_FUSED=0" keeps the LayerNorm-folded
+# to_q projection + the resident-K/V cross-attention + to_out)
+XAB_FUSED: bool = True
+XAB_FUSED_HITS: int = 0
+
+
+def xab_fused_applies(c: int, heads: int, d: int, n_keys: int, rows_per_kvb: int) -> bool:
+    return XAB_FUSED and c == 320 and heads == 8 and d == 40 and 1 <= n_keys <= 80 and rows_per_kvb % 128 == 0
+
+
+def pack_xab_q(wq: torch.Tensor, heads: int, d: int) -> torch.Tensor:
+    """to_q.weight [heads * d, C] -> [heads / 2][128][C]: per head pair the rows [q_a (d) | zero rows up to 64 | q_b (d) | zero rows up to 128]"""
+    c = wq.shape[1]
+    out = torch.zeros(heads // 2, 2, 64, c, dtype=torch.float16, device=wq.device)
+    out[:, :, :d] = wq.reshape(heads // 2, 2, d, c).to(torch.float16)
+    return out.reshape(heads // 2, 128, c).contiguous()
+
+
+def xattn_block(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, wq_p: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                n_keys: int, rows_per_kvb: int, wo_p: torch.Tensor, bias_o: Optional[torch.Tensor], heads: int, d: int, scale: float,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x + to_out(softmax(q k^T scale) v) with q = LayerNorm(x) Wq^T in ONE launch (C = 320, 8 heads x 40, <= 80 keys, one softmax group):
+    ``k`` / ``v`` = the prompt's projected keys / values [key batches * n_keys, >= C] (row-major, unit inner stride); rows
+    [b * rows_per_kvb, (b + 1) * rows_per_kvb) of ``x`` attend to key batch b; ``wq_p`` / ``wo_p`` from :func:`pack_xab_q` / :func:`pack_tsa_out`."""
+    x, k, v = _mat(x, "x"), _mat(k, "k"), _mat(v, "v")
+    M, c = x.shape
+    nkvb = (M + rows_per_kvb - 1) // rows_per_kvb
+    if tuple(wq_p.shape) != (heads // 2, 128, c) or tuple(wo_p.shape) != (c, heads * 64) or not wq_p.is_contiguous() or not wo_p.is_contiguous() or \
+            k.shape[0] < nkvb * n_keys or v.shape[0] < nkvb * n_keys or k.shape[1] != c or v.shape[1] != c or not _on_gpu(wq_p) or not _on_gpu(wo_p):
+        raise ValueError("xattn_block: shape mismatch")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(bias_o, "bias_o", c)
+    o = _out(out, M, c, x)
+    ds = _lib.XabDesc()
+    ds.x, ds.ln_gamma, ds.ln_beta, ds.wq, ds.k, ds.v = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), wq_p.data_ptr(), k.data_ptr(), v.data_ptr()
+    ds.wo, ds.bias_o, ds.out = wo_p.data_ptr(), _p(bias_o), o.data_ptr()
+    ds.M, ds.rows_per_kvb, ds.len, ds.C, ds.heads, ds.d = M, rows_per_kvb, n_keys, c, heads, d
+    ds.ldk, ds.ldv, ds.ldx, ds.ldo, ds.ln_eps, ds.scale, ds.flags = k.stride(0), v.stride(0), x.stride(0), o.stride(0), float(eps), float(scale), int(FFN_ROTATE)
+    check(_lib.load().mv_xattn_block_f16(C.byref(ds), _stream()), "mv_xattn_block_f16")
+    global XAB_FUSED_HITS
+    XAB_FUSED_HITS += 1
+    if GEMM_RECORD is not None:  # matrix work of the same family (the q projection + to_out): recorded next to the mv_gemm_f16 launches
+        nbytes = 2 * (3 * M * c + 2 * c * c)   # x twice (rows, residual) and the output once; the two weight matrices once
+        GEMM_RECORD.append((_lib.XabDesc.from_buffer_copy(ds), (x, gamma, beta, wq_p, k, v, wo_p, bias_o, o), nbytes, _stream()))
     return o
 
 
@@ -972,7 +1025,7 @@ def _apply_env_overrides() -> None:
     for item in filter(None, (x.strip() for x in spec.split(","))):
         name, _, val = item.partition("=")
         if name not in ("COLSTATS", "CARRY", "CARRY_MAX_C", "FFN_FUSED", "FFN_ROTATE", "LN_FOLD", "ATTN_GROUPS", "XATTN_RESIDENT",
-                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K", "GN_FOLD", "GN_FOLD_MAX_RATIO"):
+                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K", "GN_FOLD", "GN_FOLD_MAX_RATIO", "XAB_FUSED"):
             raise ValueError(f"MUSEV_OPS: unknown switch {name!r}")
         cur = globals()[name]
         globals()[name] = bool(int(val)) if isinstance(cur, bool) else float(val) if isinstance(cur, float) else int(val)

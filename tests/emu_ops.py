@@ -424,6 +424,48 @@ def temporal_attn_block(x, gamma, beta, eps, wqkv_p, wo_p, bias_o, b, t, hw, hea
     return _store(y + x.float(), out)
 
 
+
+def xab_fused_applies(c, heads, d, n_keys, rows_per_kvb):
+    return c == 320 and heads == 8 and d == 40 and 1 <= n_keys <= 80 and rows_per_kvb % 128 == 0
+
+
+def pack_xab_q(wq, heads, d):
+    c = wq.shape[1]
+    out = torch.zeros(heads // 2, 2, 64, c, dtype=torch.float16)
+    out[:, :, :d] = wq.reshape(heads // 2, 2, d, c).to(torch.float16)
+    return out.reshape(heads // 2, 128, c).contiguous()
+
+
+def xattn_block(x, gamma, beta, eps, wq_p, k, v, n_keys, rows_per_kvb, wo_p, bias_o, heads, d, scale, out=None):
+    """the kernel's arithmetic (mv_xattn_block_f16): LayerNorm rounded to fp16, q rounded to fp16, probabilities normalised then rounded to
+    fp16, the attention output rounded to fp16, fp32 accumulation and an fp32 residual add, rounded once"""
+    _mat(x, "x")
+    _mat(k, "k")
+    _mat(v, "v")
+    M, c = x.shape
+    _req(xab_fused_applies(c, heads, d, n_keys, rows_per_kvb), "xattn_block: C = 320 = 8 x 40, <= 80 keys, rows_per_kvb % 128")
+    nkvb = (M + rows_per_kvb - 1) // rows_per_kvb
+    _req(tuple(wq_p.shape) == (heads // 2, 128, c) and tuple(wo_p.shape) == (c, heads * 64) and wq_p.is_contiguous() and wo_p.is_contiguous(), "xattn_block: packed weights")
+    _req(k.shape[0] >= nkvb * n_keys and v.shape[0] >= nkvb * n_keys and k.shape[1] == c and v.shape[1] == c, "xattn_block: keys / values")
+    _vec(gamma, "gamma", c)
+    _vec(beta, "beta", c)
+    _vec(bias_o, "bias_o", c)
+    _check_out(out, M, c, 8)
+    xn = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), eps).to(torch.float16).float()
+    wq = wq_p.float().reshape(heads // 2, 2, 64, c)[:, :, :d].reshape(heads * d, c)
+    q = (xn @ wq.t()).to(torch.float16).float().reshape(M, heads, d)
+    kb = torch.arange(M) // rows_per_kvb
+    kk = k.float()[:nkvb * n_keys].reshape(nkvb, n_keys, heads, d)[kb]      # [M, keys, heads, d]
+    vv = v.float()[:nkvb * n_keys].reshape(nkvb, n_keys, heads, d)[kb]
+    s = torch.einsum("mhd,mkhd->mhk", q, kk) * scale
+    p = torch.softmax(s, dim=-1).to(torch.float16).float()
+    o = torch.einsum("mhk,mkhd->mhd", p, vv).to(torch.float16).float()
+    y = torch.einsum("mhd,chd->mc", o, wo_p.float().reshape(c, heads, 64)[:, :, :d])
+    if bias_o is not None:
+        y = y + bias_o.float()
+    return _store(y + x.float(), out)
+
+
 def conv3x3_cin_small(x, w, bias, n_img, h, w_, add_=None, _carry=False):
     cin = x.shape[1]
     _req(x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[0] == n_img * h * w_, "conv_in: x")
@@ -550,7 +592,7 @@ def pack_geglu(w, bias):
 EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "groupnorm_fold_linear", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
             "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
-            "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu", "tsa_fused_applies", "pack_tsa_qkv", "pack_tsa_out", "temporal_attn_block"]
+            "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu", "tsa_fused_applies", "pack_tsa_qkv", "pack_tsa_out", "temporal_attn_block", "xab_fused_applies", "pack_xab_q", "xattn_block"]
 
 
 def install(monkeypatch) -> None:

@@ -326,6 +326,41 @@ def case_tsa_block(b=1, t=13, hw=24, seed=720, offset=0.0, with_bias=True):
     return _all_ok(results)
 
 
+def case_xab_block(nkvb=2, rows_per_kvb=256, n_keys=77, seed=760, offset=0.0, with_bias=True, ragged=0):
+    """the text cross-attention sub-block as one launch (mv_xattn_block_f16): x + to_out(softmax(LN(x) Wq^T K^T scale) V) against torch fp32 and
+    against the three-launch HIP form (LayerNorm + projection, mv_attention_f16, to_out + residual).  ``ragged``: rows cut off the last block."""
+    from musev_amd import ops
+    c, heads, d = 320, 8, 40
+    M = nkvb * rows_per_kvb - ragged
+    x = _rand((M, c), seed) + offset
+    gamma = _rand((c,), seed + 1) * 0.2 + 1.0
+    beta = _rand((c,), seed + 2, 0.2)
+    wq = _rand((c, c), seed + 3, 1.0 / math.sqrt(c))
+    wo = _rand((c, c), seed + 4, 1.0 / math.sqrt(c))
+    bo = _rand((c,), seed + 5, 0.3) if with_bias else None
+    kv = _rand((nkvb * n_keys, 2 * c), seed + 6)          # the fused K | V projection of the prompt, as the model hands it over
+    k, v = kv[:, :c], kv[:, c:]
+    scale = d ** -0.5
+    got = ops.xattn_block(x, gamma, beta, 1e-5, ops.pack_xab_q(wq, heads, d), k, v, n_keys, rows_per_kvb, ops.pack_tsa_out(wo, heads, d), bo, heads, d, scale)
+    xn = F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    q = (xn @ wq.float().t()).reshape(M, heads, d)
+    kb = torch.arange(M, device=x.device) // rows_per_kvb
+    kk = k.float().reshape(nkvb, n_keys, heads, d)[kb]
+    vv = v.float().reshape(nkvb, n_keys, heads, d)[kb]
+    p = torch.softmax(torch.einsum("mhd,mkhd->mhk", q, kk) * scale, dim=-1)
+    o = torch.einsum("mhk,mkhd->mhd", p, vv).reshape(M, c)
+    ref = x.float() + o @ wo.float().t() + (bo.float() if bo is not None else 0.0)
+    res = [_cmp(f"xab_block {nkvb}x{rows_per_kvb}-{ragged} keys {n_keys} vs torch fp32", got, ref, atol=6e-3)]
+    if ragged == 0:
+        # the three-launch form on the same inputs (frames of rows_per_kvb rows, one key batch each)
+        xh = ops.layernorm(x, gamma, beta, 1e-5)
+        qh = ops.gemm(xh, wq)
+        att = ops.attention(qh, [(k, v, n_keys, 1, 1, 0)], nkvb, rows_per_kvb, heads, d, scale)
+        plain = ops.gemm(att, wo, bias=bo, residual=x)
+        res.append(_cmp(f"xab_block {nkvb}x{rows_per_kvb} keys {n_keys} vs the three-launch form", got, plain.float(), atol=6e-3))
+    return _all_ok(res)
+
+
 def case_tail_carry(n=3, h=16, w=16, c=320, seed=800):
     """the network's tail on a carried stream: conv_norm_out reads hi + lo (statistics of hi, from the producer's column statistics or
     its own pass), normalises in fp32 and hands conv_out two fp16 halves; conv_out (320 -> 4, fp32 out) reads both.  Against the
@@ -999,6 +1034,10 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("tsa_block", case_tsa_block),
     ("tsa_block_two_items_t5", lambda: case_tsa_block(b=2, t=5, hw=16, seed=730, offset=0.7)),
     ("tsa_block_t16_no_bias", lambda: case_tsa_block(b=1, t=16, hw=8, seed=740, with_bias=False)),
+    ("xab_block", case_xab_block),
+    ("xab_block_ragged_large_mean", lambda: case_xab_block(nkvb=3, rows_per_kvb=128, seed=770, offset=0.7, ragged=37)),
+    ("xab_block_5_keys_no_bias", lambda: case_xab_block(nkvb=2, rows_per_kvb=384, n_keys=5, seed=780, with_bias=False)),
+    ("xab_block_80_keys", lambda: case_xab_block(nkvb=1, rows_per_kvb=4096, n_keys=80, seed=790)),
     ("attention_spike", case_attention_spike),
     ("temporal_attention", case_temporal_attention),
     ("temporal_attention_d160_t4", lambda: case_temporal_attention(b=1, t=4, hw=64, d=160, seed=91)),

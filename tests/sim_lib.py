@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = os.path.join(ROOT, "tests", "cpu_sim")
 CSRC = os.path.join(ROOT, "musev_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ("lib", "gemm", "norm", "attention", "elementwise", "ffn", "tsa")
+SOURCES = ("lib", "gemm", "norm", "attention", "elementwise", "ffn", "tsa", "xab")
 
 
 def transform(text: str) -> str:

@@ -60,6 +60,8 @@ CASES = {
     "gemm_weight_stationary_split": "kc.case_gemm_weight_stationary(M=130, N=640, K=1024, splitk=4, seed=885)",
     "tsa_block": "kc.case_tsa_block(b=1, t=13, hw=8, seed=720)",
     "tsa_block_t5_two_items": "kc.case_tsa_block(b=2, t=5, hw=8, seed=730, offset=0.7)",
+    "xab_block": "kc.case_xab_block(nkvb=2, rows_per_kvb=128)",
+    "xab_block_ragged_5_keys": "kc.case_xab_block(nkvb=2, rows_per_kvb=128, n_keys=5, seed=780, with_bias=False, ragged=37, offset=0.7)",
     "attention_resident": "kc.case_attention_resident(d=40, nb=2, t=2, lq=36)",
     "attention_resident_text_ip": "kc.case_attention_resident(d=40, nb=2, t=2, lq=36, face=False, seed=99)",
     "attention_resident_rows_per_block": "kc._all_ok([kc.case_attention_resident(d=40, nb=2, t=2, lq=70, groups=False, seed=101, rows=r) for r in (16, 48, 512)])",
@@ -105,7 +107,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block",
+    default = ("tr16_probe", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
