@@ -301,6 +301,86 @@ static void run_ring_pipe(const RingArgs& a, int blocks, double ghz, int cus) {
     fflush(stdout);
 }
 
+// the ring with TWO tiles per step: one counted wait + one barrier + four LDS-DMA issues per 32 KiB (half the synchronisation per byte)
+template <int RING, int NREAD, int NMFMA>
+__global__ __launch_bounds__(512) void ring_probe2(const RingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.span, 0x00020000);
+    const int lrow = lane >> 3;
+    const unsigned lsl = (unsigned)((lane & 7) ^ lrow);
+    unsigned off[2];
+    const unsigned kt_per_row = a.rowb / 128u;
+    const unsigned ntiles_src = (a.span / a.rowb / 128u) * kt_per_row;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) off[q] = (8 * (wave + 8 * q) + lrow) * a.rowb + lsl * 16u;
+    unsigned cur = (a.rot * blockIdx.x) % ntiles_src;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const unsigned so = (cur / kt_per_row) * 128u * a.rowb + (cur % kt_per_row) * 128u;
+        cur = cur + 1 == ntiles_src ? 0 : cur + 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + stage * 16384 + (wave + 8 * q) * 1024), 16, (int)off[q], (int)so, 0, 0);
+    };
+    static_assert(RING % 2 == 0, "pairs of stages");
+#pragma unroll
+    for (int t = 0; t < RING - 2; ++t) issue(t);
+    float4v acc[4] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+    half8v xr[2];
+    for (int e = 0; e < 8; ++e) { xr[0][e] = (half_t)(0.001f * lane); xr[1][e] = (half_t)(0.002f * lane); }
+    int stage = 0, istage = RING - 2;
+    const int swz = l15 & 7;
+    for (int t = 0; t < a.tiles; t += 2) {
+        // tiles t, t + 1 have landed when the RING - 4 tiles behind them may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (RING - 4)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + RING - 2 < a.tiles) { issue(istage); issue(istage + 1); }
+        istage = istage + 2 == RING ? 0 : istage + 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const half_t* tile = reinterpret_cast<const half_t*>(lds + (stage + u) * 16384);
+            half8v wf[NREAD];
+#pragma unroll
+            for (int j = 0; j < NREAD; ++j) {
+                const int kk = j & 1, jj = (j >> 1) & 7;
+                wf[j] = *reinterpret_cast<const half8v*>(tile + (16 * jj + l15) * 64 + ((((kk * 4 + g) ^ swz)) << 3));
+            }
+#pragma unroll
+            for (int m = 0; m < NMFMA; ++m)
+                acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[m % NREAD], xr[(m >> 2) & 1], acc[m & 3], 0, 0, 0);
+        }
+        stage = stage + 2 == RING ? 0 : stage + 2;
+    }
+    a.sink[blockIdx.x * 512 + tid] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+}
+
+template <int RING, int NREAD, int NMFMA>
+static void run_ring2(const RingArgs& a, int blocks, double ghz, int cus) {
+    const int smem = RING * 16384;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ring_probe2<RING, NREAD, NMFMA>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((ring_probe2<RING, NREAD, NMFMA>), dim3(blocks), dim3(512), smem, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ring_probe2<RING, NREAD, NMFMA>), dim3(blocks), dim3(512), smem, 0, a);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double rounds = (double)((blocks + cus - 1) / cus);
+    const double cyc_per_tile = ms * 1e-3 * ghz * 1e9 / (a.tiles * rounds);
+    printf("TWO TILES PER BARRIER ring %d stages, %2d reads, %2d MFMAs per wave and tile, strided rows, rot %3u, blocks %4d: %7.3f ms  %6.0f cycles per tile and block  %5.1f B/clk/CU  MFMA pipe %4.2f\n",
+           RING, NREAD, NMFMA, a.rot, blocks, ms, cyc_per_tile, 16384.0 / cyc_per_tile, NMFMA * 2 * 16.0 / cyc_per_tile);
+    fflush(stdout);
+}
+
 template <int MODE, int DEPTH, int WAVES>
 static double run(const char* name, const Args& a, int blocks, double clock_ghz, int cus) {
     const int smem = WAVES * DEPTH * 1024;
@@ -403,6 +483,9 @@ int main(int argc, char**) {
         run_ring_pipe<8, 8, 16, 1>(a, cus, ghz, cus);
         run_ring_pipe<8, 8, 32, 1>(a, cus, ghz, cus);
         run_ring_pipe<8, 4, 16, 1>(a, cus, ghz, cus);
+        run_ring2<8, 8, 16>(a, cus, ghz, cus);
+        run_ring2<8, 4, 16>(a, cus, ghz, cus);
+        run_ring2<8, 8, 32>(a, cus, ghz, cus);
     }
     return 0;
 }
