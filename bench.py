@@ -36,7 +36,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: see musev_amd/__init__.py (streams sharing a hardware queue serialise)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -256,7 +258,7 @@ def device_state(local_rank: int) -> dict:
         return {"error": repr(ex)[:200]}
 
 
-FAMILY_ENTRIES = ("mv_gemm_f16", "mv_ffn_geglu_f16", "mv_temporal_attn_block_f16")
+FAMILY_ENTRIES = ("mv_gemm_f16", "mv_ffn_geglu_f16", "mv_temporal_attn_block_f16", "mv_xattn_block_f16")
 
 
 class issue_family_twice:
@@ -601,6 +603,8 @@ def main():
                     key = ("ffn_fused", int(d.M), int(d.C), int(d.H), "ln+geglu+res", 0, 0)
                 elif rmode(d) == 4:
                     key = ("tsa_fused", int(d.B) * int(d.T) * int(d.HW), int(d.C), 4 * int(d.C), "ln+attn+res", 0, 0)
+                elif rmode(d) == 5:
+                    key = ("xab_fused", int(d.M), int(d.C), 2 * int(d.C), "ln+xattn+res", 0, 0)
                 else:
                     key = (names[int(d.mode)], int(d.M), int(d.N), int(d.K), "geglu" if d.geglu else "ln" if d.ln_colsum else "res" if d.residual else "-",
                            int(bool(d.colstats)), int(bool(d.a2)))
@@ -641,7 +645,7 @@ def main():
         else:   # (N > 1 / --workload runs without the doubled leg: the isolated figure)
             fam_step_ms, ach = fam_ms * rec_scale, iso
         roofline = {
-            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch) + tsa_kernel (the fused level-0 temporal self-attention sub-block: q / k / v projection + to_out per launch)",
+            "bound": "mfma", "kernel": "gemm2_kernel<MODE,TM,TN,WGM,WGN,SCHED> (implicit-GEMM family: linear / conv3x3 / tconv3) + ffn_geglu_kernel (the fused level-0 feed-forward: two projections per launch) + tsa_kernel (the fused level-0 temporal self-attention sub-block: q / k / v projection + to_out per launch) + xab_kernel (the fused level-0 text cross-attention sub-block: to_q + to_out per launch)",
             "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
             # PMC bytes of the family per step / the step's API launches: the same denominator as algorithmic_bytes_per_launch
             "traffic": (measured_traffic(workload)[0] / max(fam_n * rec_scale, 1)) if measured_traffic(workload)[0] is not None else None,
@@ -657,7 +661,7 @@ def main():
             # `isolated` = the same launches alone on one stream (what rocprofv3's per-kernel durations reproduce; round 1-5's `achieved`).
             "method": (f"in-step: {in_step['steps']} graph-replayed steps with every launch of the family issued twice ({in_step['ms_per_step_family_issued_twice']:.3f} ms) "
                        f"minus the timed step ({ms_per_step:.3f} ms) = the family's marginal time per step; " if in_step is not None and ach != iso else "") +
-                      f"isolated: one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 / mv_temporal_attn_block_f16 launches re-issued back to back on one stream, "
+                      f"isolated: one recorded step's {fam_n} mv_gemm_f16 / mv_ffn_geglu_f16 / mv_temporal_attn_block_f16 / mv_xattn_block_f16 launches re-issued back to back on one stream, "
                       f"{reps} repetitions between one HIP event pair (device time; no per-launch host gap)",
             "in_step": in_step,
             "isolated": {"achieved": iso, "frac": iso / PEAK_MFMA_TFLOPS, "family_ms_per_step": fam_ms * rec_scale, "avg_launch_ms": fam_ms / max(fam_n, 1)},
@@ -714,7 +718,8 @@ def main():
                        # strong-scaling workloads: the speed-up this rank count can reach at best = total units / the largest shard
                        "ideal_speedup_vs_1gpu_same_workload": (n_windows * 2) / max(len(s_) for s_ in shards),
                        "weights": "seeded random fp16, SD-1.5 MuseV architecture (1.42 B parameters)",
-                       "output_finite": finite, "graphs": bool(graphs), "device_state": dev_state},
+                       "output_finite": finite, "graphs": bool(graphs), "device_state": dev_state,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "roofline": roofline, "cpu_baseline": cpu, "config4_n1": config4_n1, "multi_gpu": multi,
         }
         if args.rehearse_shared_gpu:

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 ENTRIES = [
     "mv_gemm_f16:linear", "mv_gemm_f16:conv3x3", "mv_gemm_f16:tconv3", "mv_ffn_geglu_f16", "mv_temporal_attn_block_f16",
     "mv_attention_f16:d40self", "mv_attention_f16:short", "mv_attention_f16:rest", "mv_temporal_attention_f16",
-    "mv_groupnorm_cs_f16", "mv_groupnorm_f16", "mv_layernorm_f16", "mv_add_f16",
+    "mv_groupnorm_cs_f16", "mv_groupnorm_cs_fold_linear_f16", "mv_groupnorm_f16", "mv_layernorm_f16", "mv_add_f16", "mv_xattn_block_f16",
 ]
 BENCH_ARGS = ["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-config4"]
 

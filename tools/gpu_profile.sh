@@ -26,7 +26,7 @@ python tools/pmc_summary.py $TAG > $OUT/${TAG}_pmc_summary.log 2>&1
 # per-dispatch rows of the implicit-GEMM kernels (small) stay, for tools/pmc_by_problem.py; the full counter tables do not
 for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do
   f=$(find $OUT/${TAG}_pmc_$c -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && ( head -1 "$f"; grep -E "gemm2_kernel|splitk_reduce|ffn_geglu_kernel|tsa_kernel" "$f" ) > $OUT/${TAG}_pmc_${c}_gemm_rows.csv
+  [ -n "$f" ] && ( head -1 "$f"; grep -E "gemm2_kernel|splitk_reduce|ffn_geglu_kernel|tsa_kernel|xab_kernel" "$f" ) > $OUT/${TAG}_pmc_${c}_gemm_rows.csv
 done
 ( MUSEV_NO_GRAPH=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-config4 --dump-gemm-launches $OUT/${TAG}_gemm_launches.json 2>&1 | tail -1 ) > /dev/null
 python tools/pmc_by_problem.py $TAG > $OUT/${TAG}_pmc_by_problem.log 2>&1

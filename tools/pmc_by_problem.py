@@ -28,6 +28,8 @@ def join(launches, fetch, write):
     have_ffn = any("ffn_geglu" in r[1] for r in fetch)
     if not have_ffn:  # rows kept before the fused feed-forward's dispatches were part of the filter: its launches cannot be joined
         launches = [l for l in launches if l["mode"] != 3]
+    if not any("xab_kernel" in r[1] for r in fetch):  # (likewise: rows kept before the fused cross-attention sub-block was part of the filter)
+        launches = [l for l in launches if l["mode"] != 5]
     per_step = sum(1 + (1 if l["nsplit"] > 1 else 0) for l in launches)
     out = []
     for rows in (fetch, write):
@@ -38,7 +40,7 @@ def join(launches, fetch, write):
     res, i = [], 0
     for l in launches:
         n = 1 + (1 if l["nsplit"] > 1 else 0)
-        want = "ffn_geglu" if l["mode"] == 3 else "tsa_kernel" if l["mode"] == 4 else "gemm2_kernel"
+        want = "ffn_geglu" if l["mode"] == 3 else "tsa_kernel" if l["mode"] == 4 else "xab_kernel" if l["mode"] == 5 else "gemm2_kernel"
         if not (want in f[i][1] and (n == 1 or "splitk_reduce" in f[i + 1][1])):
             raise SystemExit(f"dispatch order does not match the launch list at launch {len(res)}: {f[i][1][:60]}")
         fb = sum(v for _d, _n, v in f[i:i + n])
@@ -56,7 +58,7 @@ def main():
     write = dispatch_values(os.path.join(out, f"{tag}_pmc_WRITE_SIZE_gemm_rows.csv"))
     agg = defaultdict(lambda: [0, 0.0, 0.0])
     for l, measured in join(launches, fetch, write):
-        key = (("linear", "conv3x3", "tconv3", "ffn_fused", "tsa_fused")[l["mode"]], l["M"], l["N"], l["K"], "geglu" if l["geglu"] else "ln" if l["ln"] else "res" if l["residual"] else "-",
+        key = (("linear", "conv3x3", "tconv3", "ffn_fused", "tsa_fused", "xab_fused")[l["mode"]], l["M"], l["N"], l["K"], "geglu" if l["geglu"] else "ln" if l["ln"] else "res" if l["residual"] else "-",
                l["cfg"], l["nsplit"])
         a = agg[key]
         a[0] += 1

@@ -27,7 +27,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row.get("Kernel_Name", "")
-                fam = ("splitk_reduce" if "splitk_reduce" in name else "gemm" if "gemm" in name else "ffn_fused" if "ffn_geglu" in name else "tsa_fused" if "tsa_kernel" in name else
+                fam = ("splitk_reduce" if "splitk_reduce" in name else "gemm" if "gemm" in name else "ffn_fused" if "ffn_geglu" in name else "tsa_fused" if "tsa_kernel" in name else "xab_fused" if "xab_kernel" in name else
                        "tattn" if "tattn" in name else
                        "attn" if "attn_kernel" in name or "attn3_kernel" in name else
                        "groupnorm" if "gn_" in name else "layernorm" if "layernorm" in name else "other")
@@ -41,7 +41,7 @@ for fam in out.get("FETCH_SIZE", {}):
     n = max(f["launches"], 1)
     res[fam] = {"launches": f["launches"], "fetch_kb_per_launch_raw": f["avg_kb"], "write_kb_per_launch": w["avg_kb"],
                 "hbm_bytes_per_launch": (2.0 * f["avg_kb"] + w["avg_kb"]) * 1024.0}
-FAM = ("gemm", "splitk_reduce", "ffn_fused", "tsa_fused")   # what bench.py's roofline family records: mv_gemm_f16 + mv_ffn_geglu_f16 + mv_temporal_attn_block_f16 launches
+FAM = ("gemm", "splitk_reduce", "ffn_fused", "tsa_fused", "xab_fused")   # what bench.py's roofline family records: mv_gemm_f16 + mv_ffn_geglu_f16 + mv_temporal_attn_block_f16 + mv_xattn_block_f16 launches
 total = sum(res[f]["hbm_bytes_per_launch"] * res[f]["launches"] for f in FAM if f in res)
 res["gemm_family"] = {"steps": steps, "hbm_bytes_per_step": total / max(steps, 1),
                       "kernel_dispatches_per_step": sum(res[f]["launches"] for f in FAM if f in res) / max(steps, 1)}
