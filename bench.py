@@ -453,7 +453,7 @@ def main():
     # ---- the matrix family's cost IN THE STEP (roofline.achieved): the same timed loop once more with every launch of the family issued
     # twice, on fresh captures; extra ms per step = the family's marginal cost under the step's two streams + graph replay ----
     in_step = None
-    if world == 1 and not args.no_roofline:
+    if world == 1 and not args.no_roofline and dev.type == "cuda":   # (a CPU dry run has no launches to double: its difference is timer noise)
         den2 = ParallelDenoiser(unet, context_frames=win, context_overlap=4, context_stride=1, context_schedule="uniform")
         k2, w2 = args.steps, max(args.warmup, 2)
         marks2 = {}
@@ -566,7 +566,7 @@ def main():
         # the same launches as the loop runs them: the two CFG halves' lists concurrently on two streams (info; `achieved` stays the
         # one-stream figure, which is what a rocprofv3 kernel trace -- it serialises the streams -- reproduces)
         two_stream = None
-        if den.half_streams and fam_n % 2 == 0 and hasattr(ops, "replay_gemms_two_streams"):
+        if den.half_streams and fam_n >= 2 and dev.type == "cuda" and hasattr(ops, "replay_gemms_two_streams"):
             # the two lists = the launches each of the loop's two streams issued (every recorded launch carries its stream; with more
             # than one window per step a plain split of the list in half would mix the CFG halves of different windows)
             main_s = torch.cuda.current_stream().cuda_stream
