@@ -26,7 +26,7 @@ extern "C" {
 #define MV_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MV_ERR_LAUNCH (-2)    /* HIP launch error */
 
-#define MV_ABI_VERSION 12
+#define MV_ABI_VERSION 13
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int mv_abi_version(void);
@@ -364,6 +364,13 @@ int mv_silu_f16(const void* x, void* y, int64_t n, void* stream);
  * formed in fp32 and stored as two fp16 halves again (the ControlNet residuals added to the UNet's skips, pipeline_controlnet.py:
  * 2045-2067 / unet_3d_condition.py:1160-1175, join the unrounded stream instead of rounding it a second time). */
 int mv_add_f16(const void* a, const void* a_lo, const void* b, void* y, void* y_lo, int64_t n, void* stream);
+/* nearest-neighbour resize of channels-last fp16 images [n_img, hin, win, c] -> [n_img, hout, wout, c] to an EXPLICIT size: torch's rule
+ * src = min(floor(dst * (float)in / out), in - 1).  replaces: diffusers Upsample2D.forward(hidden_states, output_size) =
+ * F.interpolate(size=output_size, mode="nearest"), reached through upsampler(hidden_states, upsample_size) (unet_3d_blocks.py:1235,1397)
+ * when the latent size is not a multiple of 2^(number of upsamplers) (forward_upsample_size, unet_3d_condition.py:841-849,1209-1210).
+ * The exact x 2 case never comes here: it is fused into mv_gemm_f16(CONV3X3, upsample = 1). */
+int mv_upsample_nearest_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t n_img, int32_t hin, int32_t win, int32_t hout,
+                            int32_t wout, int32_t c, void* stream);
 /* rows of x selected by zeroing: y[g, :] = 0 for group rows flagged in mask (temb zeroing of the          */
 /* vision-condition frames, unet_3d_condition.py:898-906)                                                   */
 int mv_zero_rows_f16(void* x, int32_t ld, const int32_t* row_idx, int32_t n_idx, int32_t cols, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUSEV_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "l
 MV_GEMM_LINEAR, MV_GEMM_CONV3X3, MV_GEMM_TCONV3 = 0, 1, 2
 MV_ACT_NONE, MV_ACT_SILU = 0, 1
 MV_ATTN_MAX_SEG = 4
-MV_ABI_VERSION = 12
+MV_ABI_VERSION = 13
 
 
 class MuseVHipError(RuntimeError):
@@ -127,6 +127,7 @@ SIGNATURES = {
     "mv_timestep_embedding_f16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "mv_silu_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "mv_add_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mv_upsample_nearest_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mv_zero_rows_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     "mv_bcthw_to_bthwc_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mv_bthwc_to_bcthw_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

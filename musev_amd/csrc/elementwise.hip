@@ -67,6 +67,29 @@ __global__ void zero_rows_kernel(half_t* x, int ld, const int* row_idx, int n_id
     }
 }
 
+// nearest-neighbour resize of channels-last images to an EXPLICIT size (diffusers Upsample2D with output_size: F.interpolate(size=...,
+// mode="nearest")): y[n, oy, ox, :] = x[n, min(floor(oy * sy), hin - 1), min(floor(ox * sx), win - 1), :] with sy = hin / hout, sx = win / wout
+// as floats -- torch's own index rule (the scales are formed on the host in IEEE float, the products rounded once here).  One thread =
+// 8 channels of one output pixel (16-byte loads / stores).  Only taken for latent sizes that are not multiples of 2^(number of
+// upsamplers); the exact x 2 case stays fused into the convolution's gather.
+__global__ void upsample_nearest_kernel(const half_t* x, int ldx, half_t* y, int ldy, long n_img, int hin, int win, int hout, int wout,
+                                        int c8, float sy, float sx) {
+    const long total = n_img * hout * wout * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c8);
+        const long pix = i / c8;
+        const int ox = (int)(pix % wout);
+        const long t = pix / wout;
+        const int oy = (int)(t % hout);
+        const long n = t / hout;
+        int iy = (int)floorf((float)oy * sy), ix = (int)floorf((float)ox * sx);
+        iy = iy < hin - 1 ? iy : hin - 1;
+        ix = ix < win - 1 ? ix : win - 1;
+        const half8v v = *reinterpret_cast<const half8v*>(x + ((n * hin + iy) * win + ix) * (long)ldx + 8 * cc);
+        *reinterpret_cast<half8v*>(y + pix * (long)ldy + 8 * cc) = v;
+    }
+}
+
 // sinusoidal embedding, flip_sin_to_cos=True, downscale_freq_shift=0: out = [cos(t f_k), sin(t f_k)], f_k = 10000^(-k/half)
 __global__ void timestep_embedding_kernel(const float* t, int n, int dim, half_t* out) {
     const int half_dim = dim / 2;
@@ -554,6 +577,18 @@ extern "C" int mv_add_f16(const void* a, const void* a_lo, const void* b, void* 
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)a_lo, (const half_t*)b,
                        (half_t*)y, (half_t*)y_lo, (long)(n / 8));
     MV_CHECK_LAUNCH("mv_add_f16");
+    return MV_OK;
+}
+
+extern "C" int mv_upsample_nearest_f16(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t n_img, int32_t hin, int32_t win, int32_t hout,
+                                       int32_t wout, int32_t c, void* stream) {
+    MV_REQUIRE(x && y && n_img > 0 && hin > 0 && win > 0 && hout > 0 && wout > 0 && c > 0 && c % 8 == 0 && ldx >= c && ldy >= c && ldx % 8 == 0 && ldy % 8 == 0,
+               "mv_upsample_nearest_f16: bad args (channels and leading dimensions in multiples of 8)");
+    MV_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "mv_upsample_nearest_f16: 16-byte aligned pointers");
+    const float sy = (float)hin / (float)hout, sx = (float)win / (float)wout;   // torch: compute_scales_value<float>(nullopt, in, out)
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for(n_img * hout * wout * (c / 8))), dim3(kBlock), 0, (hipStream_t)stream, (const half_t*)x, ldx,
+                       (half_t*)y, ldy, (long)n_img, hin, win, hout, wout, c / 8, sy, sx);
+    MV_CHECK_LAUNCH("mv_upsample_nearest_f16");
     return MV_OK;
 }
 

@@ -151,9 +151,16 @@ class Upsample2D(HipModule):
         super().__init__()
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
-    def hip_forward(self, x: torch.Tensor, geo: Geo) -> torch.Tensor:
+    def hip_forward(self, x: torch.Tensor, geo: Geo, output_size=None):
+        """-> (rows, geometry of the result).  ``output_size`` = (h, w): the explicit size the reference forwards for latents that are not
+        multiples of 2^(number of upsamplers) (``upsampler(hidden_states, upsample_size)``, unet_3d_blocks.py:1235,1397 -> diffusers
+        Upsample2D: F.interpolate(size=output_size, mode="nearest")); an exact x 2 stays fused into the convolution's gather."""
         w = self.packed("conv", lambda: ops.pack_conv_weight(self.conv.weight.detach()))
-        return ops.conv3x3(x, w, geo.n, geo.h, geo.w, upsample=True, bias=w16(self.conv.bias))
+        if output_size is None or tuple(int(v) for v in output_size) == (2 * geo.h, 2 * geo.w):
+            return ops.conv3x3(x, w, geo.n, geo.h, geo.w, upsample=True, bias=w16(self.conv.bias)), geo.up()
+        ho, wo = (int(v) for v in output_size)
+        up = ops.upsample_nearest(x, geo.n, geo.h, geo.w, ho, wo)
+        return ops.conv3x3(up, w, geo.n, ho, wo, bias=w16(self.conv.bias)), Geo(geo.b, geo.t, ho, wo)
 
 
 class GEGLU(nn.Module):

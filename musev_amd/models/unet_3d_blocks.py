@@ -219,7 +219,7 @@ class CrossAttnUpBlock3D(nn.Module):
         self.temp_attentions = nn.ModuleList(temp_attentions)
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
-    def hip_forward(self, x, skips: List[torch.Tensor], ctx: Ctx, geo: Geo):
+    def hip_forward(self, x, skips: List[torch.Tensor], ctx: Ctx, geo: Geo, upsample_size=None):
         for res, tconv, attn, tattn in zip(self.resnets, self.temp_convs, self.attentions, self.temp_attentions):
             x = res.hip_forward(x, skips.pop(), ctx, geo)
             if tconv is not None:
@@ -228,8 +228,7 @@ class CrossAttnUpBlock3D(nn.Module):
             if tattn is not None:
                 x = tattn.hip_forward(x, ctx, geo)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].hip_forward(x, geo)
-            geo = geo.up()
+            x, geo = self.upsamplers[0].hip_forward(x, geo, upsample_size)
         return x, geo
 
 
@@ -253,14 +252,13 @@ class UpBlock3D(nn.Module):
         self.temp_convs = nn.ModuleList(temp_convs)
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
-    def hip_forward(self, x, skips: List[torch.Tensor], ctx: Ctx, geo: Geo):
+    def hip_forward(self, x, skips: List[torch.Tensor], ctx: Ctx, geo: Geo, upsample_size=None):
         for res, tconv in zip(self.resnets, self.temp_convs):
             x = res.hip_forward(x, skips.pop(), ctx, geo)
             if tconv is not None:
                 x = tconv.hip_forward(x, ctx, geo)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].hip_forward(x, geo)
-            geo = geo.up()
+            x, geo = self.upsamplers[0].hip_forward(x, geo, upsample_size)
         return x, geo
 
 

@@ -359,8 +359,9 @@ class UNet3DConditionModel(HipModule):
             self.set_skip_temporal_layers(skip_temporal_layers)
         self._check_param_versions()
 
-        if any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w)):
-            raise NotImplementedError("latent height/width must be multiples of 2**num_upsamplers")
+        # a latent size that is not a multiple of 2^(number of upsamplers): the up path is told the size of the skip it has to meet
+        # (forward_upsample_size, :841-849; upsample_size = down_block_res_samples[-1].shape[2:], :1209-1210)
+        forward_upsample_size = any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w))
         geo = Geo(b, t, h, w)
         dev = x.device
         ch0 = self.block_out_channels[0]
@@ -464,6 +465,7 @@ class UNet3DConditionModel(HipModule):
 
         # ---- 3. down (:1076-1156) ----
         skips: List[torch.Tensor] = [x]
+        skip_geos: List[Geo] = [geo]
         for i, blk in enumerate(self.down_blocks):
             refer = None
             if use_refer:
@@ -474,6 +476,7 @@ class UNet3DConditionModel(HipModule):
             x, geo, outs = blk.hip_forward(x, ctx, geo, refer)
             ctx.split()  # (at the latest: only the first down block's layers are wrapped in ctx.shared)
             skips.extend(o for o, _ in outs)
+            skip_geos.extend(g_ for _, g_ in outs)
             for j, (o, g_) in enumerate(outs):
                 self._tap(f"down_blocks.{i}.out{j}", o, g_)
         if down_block_additional_residuals is not None:
@@ -489,7 +492,11 @@ class UNet3DConditionModel(HipModule):
 
         # ---- 5. up (:1199-1245) ----
         for i, blk in enumerate(self.up_blocks):
-            x, geo = blk.hip_forward(x, skips, ctx, geo)
+            del skip_geos[-len(blk.resnets):]   # (the block pops its own skips; what is left on top is the size the next block works at)
+            upsample_size = None
+            if forward_upsample_size and i != len(self.up_blocks) - 1:
+                upsample_size = (skip_geos[-1].h, skip_geos[-1].w)
+            x, geo = blk.hip_forward(x, skips, ctx, geo, upsample_size)
             self._tap(f"up_blocks.{i}", x, geo)
 
         # ---- 6. post-process (:1258-1263) ----

@@ -113,8 +113,7 @@ class UpDecoderBlock2D(nn.Module):
         for r in self.resnets:
             x = r.hip_forward(x, geo)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].hip_forward(x, geo)
-            geo = geo.up()
+            x, geo = self.upsamplers[0].hip_forward(x, geo)
         return x, geo
 
 

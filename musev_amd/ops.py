@@ -881,6 +881,22 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return out
 
 
+def upsample_nearest(x: torch.Tensor, n_img: int, h: int, w_: int, ho: int, wo: int) -> torch.Tensor:
+    """nearest-neighbour resize of channels-last images x = [n_img*h*w_, C] to an explicit (ho, wo): F.interpolate(size=(ho, wo), mode="nearest")
+    (diffusers Upsample2D with output_size).  Only for latent sizes that are not multiples of 2^(number of upsamplers); the exact x 2 case
+    is fused into :func:`conv3x3` (``upsample=True``)."""
+    x = _mat(x, "x")
+    if x.shape[0] != n_img * h * w_:
+        raise ValueError("upsample_nearest: x rows != n_img*h*w")
+    c = x.shape[1]
+    if c % 8:
+        raise ValueError("upsample_nearest: channels must be a multiple of 8")
+    y = torch.empty((n_img * ho * wo, c), dtype=torch.float16, device=x.device)
+    check(_lib.load().mv_upsample_nearest_f16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), n_img, h, w_, ho, wo, c, _stream()),
+          "mv_upsample_nearest_f16")
+    return y
+
+
 def zero_rows(x: torch.Tensor, row_idx: torch.Tensor) -> None:
     x = _mat(x, "x")
     idx = row_idx.to(dtype=torch.int32).contiguous()

@@ -710,7 +710,13 @@ def unet3d_forward(
                 x = transformer_2d(sd, f"{p}.attentions.{j}", x, ehs, heads, ctx)
                 x = tattn(f"{p}.temp_attentions.{j}", x)
         if i != len(ch) - 1:
-            x = F.interpolate(_h("stream_read", x), scale_factor=2.0, mode="nearest")
+            # forward_upsample_size (:841-849): a latent size that is not a multiple of 2^(number of upsamplers) hands the upsampler the size
+            # of the skip on top of the remaining stack (upsample_size = down_block_res_samples[-1].shape[2:], :1209-1210; diffusers
+            # Upsample2D then interpolates to size=output_size instead of x 2 -- un-vendored, restated from its published forward)
+            if any(v % (2 ** (len(ch) - 1)) != 0 for v in sample.shape[-2:]):
+                x = F.interpolate(_h("stream_read", x), size=tuple(skips[-1].shape[-2:]), mode="nearest")
+            else:
+                x = F.interpolate(_h("stream_read", x), scale_factor=2.0, mode="nearest")
             x = _h("gemm", F.conv2d(x, sd[f"{p}.upsamplers.0.conv.weight"], sd[f"{p}.upsamplers.0.conv.bias"], padding=1))
         rec(p, x)
 

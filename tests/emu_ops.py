@@ -528,6 +528,13 @@ def timestep_embedding(t, dim):
     return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1).to(torch.float16)  # flip_sin_to_cos, freq_shift 0
 
 
+def upsample_nearest(x, n_img, h, w_, ho, wo):
+    x = _mat(x, "x", 8)
+    _req(x.shape[0] == n_img * h * w_ and x.shape[1] % 8 == 0, "upsample_nearest: rows / channels")
+    y = F.interpolate(x.float().reshape(n_img, h, w_, -1).permute(0, 3, 1, 2), size=(ho, wo), mode="nearest")
+    return y.permute(0, 2, 3, 1).reshape(n_img * ho * wo, -1).to(torch.float16).contiguous()
+
+
 def zero_rows(x, row_idx):
     _mat(x, "x", 1)
     _req(row_idx.numel() > 0 and int(row_idx.max()) < x.shape[0], "zero_rows: index range")
@@ -590,7 +597,7 @@ def pack_geglu(w, bias):
 
 
 EMULATED = ["gemm", "ln_fold_applies", "fold_layernorm", "conv3x3", "tconv3", "groupnorm", "groupnorm_fold_linear", "layernorm", "attention", "temporal_attention", "geglu", "silu", "add", "softmax_rows_",
-            "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows",
+            "conv3x3_cin_small", "conv3x3_cin_small_gemm", "pad_cols", "conv3x3_cout_small", "conv3x3_direct", "timestep_embedding", "zero_rows", "upsample_nearest",
             "bcthw_to_bthwc", "bthwc_to_bcthw", "window_gather", "window_scatter_add", "window_units_reduce", "cfg_ddim_step", "cfg_affine_step",
             "pack_conv_weight", "pack_geglu", "ffn_fused_applies", "ffn_geglu", "tsa_fused_applies", "pack_tsa_qkv", "pack_tsa_out", "temporal_attn_block", "xab_fused_applies", "pack_xab_q", "xattn_block"]
 

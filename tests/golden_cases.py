@@ -52,6 +52,9 @@ UNET_CASES = {
     # (norm1's output) in the caller's list as [(b t), c, h, w]; the golden holds the output AND the list
     "musev_hipw_refer_self_write": dict(flavour="musev", arch=_HIPW, b=1, t=2, h=8, w=8, n_cond=1, weight_seed=14, input_seed=24, timestep=401,
                                         refer_self=True, refer_self_write=True),
+    # a latent size that is NOT a multiple of 2^(number of upsamplers) (forward_upsample_size, unet_3d_condition.py:841-849,1209-1210):
+    # 10 x 6 latents under two upsamplers -> 5 x 3 -> 3 x 2; the first upsampler is told to produce 5 x 3 (not 6 x 4), the second 10 x 6
+    "musev_hipw3_odd_size": dict(flavour="musev", arch=_HIPW3, b=2, t=4, h=10, w=6, n_cond=1, weight_seed=15, input_seed=25, timestep=451),
     "refnet_hipw_faceid": dict(flavour="musev_referencenet", arch=dict(_HIPW3, need_t2i_ip_adapter_face=True), b=2, t=4, h=16, w=16,
                                n_cond=1, weight_seed=12, input_seed=22, timestep=301, face=True),
 }

@@ -824,6 +824,20 @@ def case_layout_and_misc():
             "parts": {t["name"]: t["ok"] for t in parts}}
 
 
+def case_upsample_nearest():
+    """mv_upsample_nearest_f16 against F.interpolate(size=..., mode="nearest") (diffusers Upsample2D with output_size; the sizes are the
+    3 -> 5, 5 -> 10, 9 -> 17 / 13 steps a latent that is not a multiple of 8 produces, plus a down-size and a strided source view): exact"""
+    from musev_amd import ops
+    parts = []
+    for k, (n, h, w_, ho, wo, c) in enumerate([(3, 3, 3, 5, 5, 40), (2, 5, 5, 10, 10, 64), (2, 9, 7, 17, 13, 24), (1, 8, 6, 5, 4, 16), (26, 8, 8, 15, 15, 1280)]):
+        x = _rand((n * h * w_, c + 8), 140 + k)[:, :c]   # (a view with a leading dimension of c + 8)
+        got = ops.upsample_nearest(x, n, h, w_, ho, wo)
+        ref = F.interpolate(x.float().reshape(n, h, w_, c).permute(0, 3, 1, 2), size=(ho, wo), mode="nearest").permute(0, 2, 3, 1).reshape(n * ho * wo, c)
+        parts.append(_cmp(f"upsample_nearest {h}x{w_}->{ho}x{wo} c{c}", got, ref, atol=0.0, rtol=0.0))
+    ok = all(t["ok"] for t in parts)
+    return {"name": "upsample_nearest", "ok": ok, "max_abs_err": max(t["max_abs_err"] for t in parts), "parts": {t["name"]: t["ok"] for t in parts}}
+
+
 def case_window_loop():
     """gather / scatter-add / CFG + DDIM step against the torch expressions of pipeline_controlnet.py:1902-2117."""
     from musev_amd import ops
@@ -1049,6 +1063,7 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("conv_in_out", case_conv_in_out),
     ("timestep_embedding", case_timestep_embedding),
     ("layout_misc", case_layout_and_misc),
+    ("upsample_nearest", case_upsample_nearest),
     ("window_loop", case_window_loop),
     ("window_units_reduce", case_window_units_reduce),
     ("softmax_rows", case_softmax_rows),

@@ -56,7 +56,7 @@ def test_emulation_matches_kernel_references(emulated):
         lambda: kc.case_layernorm(rows=99, c=64),
         lambda: kc.case_attention_self(d=40, b=2, t=3, lq=20, cond_idx=1), lambda: kc.case_attention_cross(d=80, nb=6, t=3, lq=13),
         lambda: kc.case_temporal_attention(b=2, t=5, hw=7, d=40), kc.case_geglu, kc.case_conv_in_out, kc.case_timestep_embedding,
-        kc.case_layout_and_misc, kc.case_window_loop, kc.case_cfg_affine_step, kc.case_conv3x3_direct,
+        kc.case_layout_and_misc, kc.case_upsample_nearest, kc.case_window_loop, kc.case_cfg_affine_step, kc.case_conv3x3_direct,
     ]
     for fn in cases:
         res = fn()
