@@ -3,6 +3,8 @@ import sys
 
 import pytest  # noqa: F401
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # the product's process default (musev_amd/__init__.py), set before any test touches the GPU
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -130,3 +130,15 @@ def test_tile_order_window_locality():
             worst[group], mean[group] = max(costs), float(np.mean(costs))
         assert worst[8] <= 32, (tiles_m, tiles_n, worst)        # 8 x 8 window = 16, up to ~2x across a group boundary
         assert worst[8] <= worst[0] and mean[8] < 0.9 * mean[0], (tiles_m, tiles_n, worst, mean)
+
+
+def test_package_import_sets_the_hardware_queue_default_without_overriding_the_user():
+    """musev_amd/__init__.py: GPU_MAX_HW_QUEUES=8 unless the user set it (streams that share a hardware queue serialise)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, musev_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.strip() == "4"
