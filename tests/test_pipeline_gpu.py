@@ -53,7 +53,7 @@ def _unplain(v):
     return v
 
 
-def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim", n_cond=1, vis=None):
+def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim", n_cond=1, vis=None, hw=(8, 8)):
     from oracle import pipeline as opipe
     from oracle import unet3d
     from musev_amd.models.unet_loader import load_unet_by_name
@@ -61,7 +61,7 @@ def _run(flavour, T, win, ov, steps, with_cond=True, seed=0, scheduler="ddim", n
     cfg = unet3d.flavour_config(flavour, **ARCH)
     sd = unet3d.init_state_dict(cfg, 3)
     g = torch.Generator().manual_seed(seed)
-    h = w = 8
+    h, w = hw
     latents = torch.randn(1, 4, T, h, w, generator=g)
     sched = None
     if scheduler == "euler":
@@ -100,6 +100,16 @@ def test_loop_parity_first_steps(T, win, ov, steps):
     assert err < 1e-2, f"|delta latent|max = {err}"
     # the vision-condition frame is re-inserted untouched in front (pipeline_controlnet.py:2149-2156)
     assert torch.equal(got[:, :, 0], want[:, :, 0])
+
+
+def test_loop_parity_latent_size_not_a_multiple_of_the_upsampling_factor():
+    """9 x 7 latents under one upsampler: the loop runs the forward_upsample_size path of the UNet (unet_3d_condition.py:841-849,1209-1210:
+    5 x 4 -> 9 x 7 by an explicit-size nearest resize, mv_upsample_nearest_f16) window after window; graph replay included"""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    want, got, got2 = _run("musev", 8, 6, 2, 2, hw=(9, 7))
+    assert got.shape == want.shape and torch.equal(got, got2)
+    err = (got - want).abs().max().item()
+    assert err < 1e-2, f"|delta latent|max = {err}"
 
 
 @pytest.mark.parametrize("flavour,n_cond,vis", [("musev", 2, [0, -1]), ("musev_referencenet", 2, [0, -1]), ("musev", 1, [-1]), ("musev", 2, [1, 0])])
