@@ -162,8 +162,8 @@ def test_referencenet_features_feed_the_unet(emulated):
 
 
 # ---- 4. the denoise loop over the real module (not the closed-form fake UNet of test_parallel_sharding.py) -----------------
-@pytest.mark.parametrize("scheduler", ["ddim", "euler"])
-def test_denoise_loop_over_the_module(scheduler, emulated):
+@pytest.mark.parametrize("scheduler,hw", [("ddim", (8, 8)), ("euler", (8, 8)), ("ddim", (10, 6))])   # (10 x 6: forward_upsample_size in the loop)
+def test_denoise_loop_over_the_module(scheduler, hw, emulated):
     from oracle import pipeline as opipe
     from oracle import unet3d
     from musev_amd.models.unet_loader import load_unet_by_name
@@ -173,7 +173,8 @@ def test_denoise_loop_over_the_module(scheduler, emulated):
     cfg = unet3d.flavour_config("musev", **arch)
     sd = unet3d.init_state_dict(cfg, 3)
     g = torch.Generator().manual_seed(0)
-    T, win, ov, h, w = 8, 6, 2, 8, 8
+    T, win, ov = 8, 6, 2
+    h, w = hw
     latents = torch.randn(1, 4, T, h, w, generator=g)
     sched = None
     if scheduler == "euler":
