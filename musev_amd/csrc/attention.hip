@@ -495,9 +495,12 @@ void attn3_kernel(const AttnArgs p) {
     // ~24 pairs at once and re-fetched K / V from the fabric: removing the tile DMA sped the kernel up by 17 % (ablation, r02).
     const int qblocks = (p.lq + C::QB - 1) / C::QB;
     const int id = mv_xcd_remap(blockIdx.x, gridDim.x);
+    // (frame, head) pairs HEAD-major: with 8 heads an XCD walks one head over all frames -- every XCD gets its share of the frames whose
+    // condition segment is not walked (dup_seg below; frame-major, the first XCD held all of them and the launch ended with the others),
+    // and the condition frame's K / V of that head (shared by all frames of a batch item) stay in its L2
     const int hn = id / qblocks;
-    const int h = hn % p.heads;
-    const int n = hn / p.heads;
+    const int h = hn / p.nb;
+    const int n = hn - h * p.nb;
     const int q0 = (id - hn * qblocks) * C::QB + wave * (16 * C::QT);
     const int npw = (C::PIECES - wave + C::NW - 1) / C::NW;  // pieces this wave issues per tile pair (wave-uniform)
 
@@ -571,6 +574,22 @@ void attn3_kernel(const AttnArgs p) {
 
     __syncthreads();  // the zero fill (and the ones column) is complete before the first DMA may land
     bool first = true;    // no tile processed yet (the first tile sets the reference unconditionally)
+    // A later segment of the (single) softmax that addresses the very rows of segment 0 is not walked.  Reference-only self-attention
+    // appends the vision-condition frame's keys / values to every frame's own (attention_processor.py:431-468): for the condition
+    // frame itself that is its own key set a second time.  A key set counted twice has twice the softmax weight, i.e.
+    // exp2(score + 1): segment 0 runs with its reference lowered by one instead (exact: a power of two on numerators and row sums
+    // alike, relative to the other segments), and the block saves the duplicate's tiles (1 frame in 13 at config 2: half its work).
+    int dup_seg = -1;
+    if constexpr (!C::GRP) {
+        const long kvb0 = (long)(n / p.seg[0].div) * p.seg[0].mul + p.seg[0].add;
+#pragma unroll
+        for (int s2 = 1; s2 < MV_ATTN_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && dup_seg < 0 && p.seg[s2].k == p.seg[0].k && p.seg[s2].v == p.seg[0].v && p.seg[s2].len == p.seg[0].len &&
+                p.seg[s2].ldk == p.seg[0].ldk && p.seg[s2].ldv == p.seg[0].ldv &&
+                (long)(n / p.seg[s2].div) * p.seg[s2].mul + p.seg[s2].add == kvb0)
+                dup_seg = s2;
+        }
+    }
     // ---- walk the key/value segments; per segment a three-stage LDS ring with two tiles in flight (the ring drains at a segment
     // boundary: a segment is 64 tiles at level 0, and everything that selects it -- base pointers, strides, descriptors, the
     // lanes' chunk offsets -- is computed here once instead of per tile) ----
@@ -593,6 +612,8 @@ void attn3_kernel(const AttnArgs p) {
                 gscale = ATTN_SEG_FIELD(p, seg, gscale);
             }
         }
+        if (seg == dup_seg) continue;   // (block-uniform) the rows of segment 0 again: counted there
+        const float seg_bias = (seg == 0 && dup_seg > 0) ? 1.0f : 0.0f;
         const int len = ATTN_SEG_FIELD(p, seg, len);
         const int ldk = ATTN_SEG_FIELD(p, seg, ldk), ldv = ATTN_SEG_FIELD(p, seg, ldv);
         const int sdiv = ATTN_SEG_FIELD(p, seg, div), smul = ATTN_SEG_FIELD(p, seg, mul), sadd = ATTN_SEG_FIELD(p, seg, add);
@@ -669,7 +690,7 @@ void attn3_kernel(const AttnArgs p) {
         float4v acc_s[C::QT][4];
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            const float m0 = -m_ref[qt];
+            const float m0 = seg_bias - m_ref[qt];
 #pragma unroll
             for (int st = 0; st < 4; ++st) acc_s[qt][st] = float4v{m0, m0, m0, m0};
         }
