@@ -43,7 +43,7 @@ class PrefixMemo:
 
     The loop hands both classifier-free-guidance halves the SAME latents (`latent_model_input = torch.cat([latents] * 2)`,
     pipeline_controlnet.py:1908-1910) and the same timestep; the halves only start to differ at the first text cross-attention.
-    Everything before it -- conv_in, transformer_in, the first ResnetBlock2D / TemporalConvLayer, the first Transformer2DModel's
+    Everything before it -- the timestep / frame embeddings and every block's projection of them, conv_in, transformer_in, the first ResnetBlock2D / TemporalConvLayer, the first Transformer2DModel's
     norm / proj_in / reference-only self-attention / to_q -- is the same arithmetic on the same values twice.  The first half's
     forward RECORDS those tensors (``get`` computes and stores), the second half's forward REPLAYS them (``get`` returns the stored
     tensor) and starts computing at the split.  Bit-identical to computing them twice; the model calls ``split()`` before the first

@@ -367,31 +367,41 @@ class UNet3DConditionModel(HipModule):
         ch0 = self.block_out_channels[0]
 
         # ---- 1. time embedding (:887-906) ----
-        if not torch.is_tensor(timestep):
-            tt = torch.tensor([float(timestep)], dtype=torch.float32, device=dev)
-        else:
-            tt = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
-        tt = tt.expand(b).repeat_interleave(t).contiguous()  # one row per frame: emb.repeat_interleave(num_frames)
-        emb = self.time_embedding.hip_forward(ops.timestep_embedding(tt, ch0), final_silu=self.use_anivv1_cfg)
         vis_idx = None
         if vision_conditon_frames_sample_index is not None:
             if torch.is_tensor(vision_conditon_frames_sample_index):  # the reference passes a LongTensor (device sync)
                 vis_idx = [int(i) for i in vision_conditon_frames_sample_index.reshape(-1).tolist()]
             else:  # host ints: no device round trip (what the parallel-denoise loop passes; hipGraph-capture safe)
                 vis_idx = [int(i) for i in vision_conditon_frames_sample_index]
-        if self.keep_vision_condtion and t > 1 and sample_index is not None and vis_idx is not None:
-            ops.zero_rows(emb, self._const_rows(tuple(bi * t + i for bi in range(b) for i in vis_idx), dev))
-        temb_act = emb if self.resnet_2d_skip_time_act else ops.silu(emb)  # ResnetBlock2D applies SiLU unless skip_time_act
 
-        # ---- frame embedding (:909-937): window-local positions ----
-        femb_act = None
-        if self.frame_embedding is not None:
-            fi = torch.arange(t, dtype=torch.float32, device=dev)
-            if self.use_anivv1_cfg:
-                fi = (torch.arange(t, device=dev) * sample_frame_rate).to(dtype=torch.long).to(torch.float32)
-            fi = fi.repeat(b).contiguous()  # rows (b, t)
-            femb = self.frame_embedding.hip_forward(ops.timestep_embedding(fi, ch0), final_silu=self.use_anivv1_cfg)
-            femb_act = ops.silu(femb)  # TransformerTemporalModel.nonlinearity (temporal_transformer.py:247-249)
+        def embeddings():
+            """timestep / frame embeddings and every block's projection of them: functions of (timestep, b, t, frame rate, condition
+            positions) only -- the same for both CFG halves, so part of the shared prefix (runtime.PrefixMemo: the second half's forward
+            takes the first half's tensors instead of walking the ~12 small launches again at the head of its critical path)"""
+            if not torch.is_tensor(timestep):
+                tt = torch.tensor([float(timestep)], dtype=torch.float32, device=dev)
+            else:
+                tt = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+            tt = tt.expand(b).repeat_interleave(t).contiguous()  # one row per frame: emb.repeat_interleave(num_frames)
+            emb = self.time_embedding.hip_forward(ops.timestep_embedding(tt, ch0), final_silu=self.use_anivv1_cfg)
+            if self.keep_vision_condtion and t > 1 and sample_index is not None and vis_idx is not None:
+                ops.zero_rows(emb, self._const_rows(tuple(bi * t + i for bi in range(b) for i in vis_idx), dev))
+            temb = emb if self.resnet_2d_skip_time_act else ops.silu(emb)  # ResnetBlock2D applies SiLU unless skip_time_act
+            # ---- frame embedding (:909-937): window-local positions ----
+            femb_a = None
+            if self.frame_embedding is not None:
+                fi = torch.arange(t, dtype=torch.float32, device=dev)
+                if self.use_anivv1_cfg:
+                    fi = (torch.arange(t, device=dev) * sample_frame_rate).to(dtype=torch.long).to(torch.float32)
+                fi = fi.repeat(b).contiguous()  # rows (b, t)
+                femb = self.frame_embedding.hip_forward(ops.timestep_embedding(fi, ch0), final_silu=self.use_anivv1_cfg)
+                femb_a = ops.silu(femb)  # TransformerTemporalModel.nonlinearity (temporal_transformer.py:247-249)
+            proj = self._batched_emb_proj(temb, femb_a)
+            # (a flat tuple: the caller marks every tensor of a memo entry as used by the second half's stream)
+            return (temb, femb_a, proj) + tuple(proj.values())
+
+        emb_all = embeddings() if prefix_memo is None else prefix_memo.get("embeddings", embeddings)
+        temb_act, femb_act, emb_proj = emb_all[0], emb_all[1], emb_all[2]
 
         # ---- conditioning rows ----
         if encoder_hidden_states.ndim != 3:
@@ -428,7 +438,6 @@ class UNet3DConditionModel(HipModule):
                 raise NotImplementedError("ip_adapter_face_emb must be [b, n, q]")
             face = ip_adapter_face_emb.to(dtype=torch.float16).reshape(-1, ip_adapter_face_emb.shape[-1]).contiguous()
             face_len = ip_adapter_face_emb.shape[1]
-        emb_proj = self._batched_emb_proj(temb_act, femb_act)
         ctx = Ctx(emb_proj=emb_proj, temb_act=temb_act, femb_act=femb_act, text=text, text_len=encoder_hidden_states.shape[1], vis_idx=vis_idx,
                   clip=clip, clip_len=clip_len, ip_scale=float(ip_adapter_scale), skip_temporal=False,
                   text_src=encoder_hidden_states, clip_src=vision_clip_emb, face=face, face_len=face_len,

@@ -549,6 +549,28 @@ def case_attention_self(d=40, b=2, t=3, lq=200, cond_idx=0, seed=60, qscale=1.0)
     return _cmp(f"attention self+cond d{d} nb{nb} lq{lq} qscale{qscale}", got, ref, atol=3e-3 * qscale * qscale)
 
 
+def case_attention_self_ref(d=40, b=2, t=3, lq=150, lr=90, cond_idx=1, seed=65):
+    """reference-only self-attention with ReferenceNet tokens: segments = [own frame, vision-condition frame, reference tokens of the
+    batch item] under ONE softmax (attention_processor.py:431-491).  For the condition frame itself the second segment repeats the
+    first: the kernel does not walk it and counts segment 0 twice instead (exp2(score + 1)) -- the third segment keeps its weight."""
+    from musev_amd import ops
+    heads = 8
+    c = heads * d
+    nb = b * t
+    qkv = _rand((nb * lq, 3 * c), seed)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    rkv = _rand((b * lr, 2 * c), seed + 1)
+    scale = d ** -0.5
+    got = ops.attention(q, [(k, v, lq, 1, 1, 0), (k, v, lq, t, t, cond_idx), (rkv[:, :c], rkv[:, c:], lr, t, 1, 0)], nb, lq, heads, d, scale)
+    k3, v3 = k.reshape(nb, lq, c), v.reshape(nb, lq, c)
+    cond = [(n // t) * t + cond_idx for n in range(nb)]
+    bi = [n // t for n in range(nb)]
+    ks = torch.cat([k3, k3[cond], rkv[:, :c].reshape(b, lr, c)[bi]], dim=1)
+    vs = torch.cat([v3, v3[cond], rkv[:, c:].reshape(b, lr, c)[bi]], dim=1)
+    ref = _attn_ref(q.reshape(nb, lq, c), ks, vs, heads, d, scale)
+    return _cmp(f"attention self+cond+ref d{d} nb{nb} lq{lq} lr{lr}", got, ref, atol=3e-3)
+
+
 def case_attention_cross(d=80, nb=6, t=3, lq=130, lk=77, seed=70, with_ip=True):
     """text cross attention (keys per batch item, shared by its t frames) + IP-Adapter second attention."""
     from musev_amd import ops
@@ -1030,6 +1052,8 @@ ALL_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("attention_self_d80", lambda: case_attention_self(d=80, lq=100, seed=61)),
     ("attention_self_d160", lambda: case_attention_self(d=160, lq=64, seed=62)),
     ("attention_self_d40_big", lambda: case_attention_self(d=40, b=1, t=2, lq=1024, cond_idx=1, seed=63, qscale=2.0)),
+    ("attention_self_ref_d40", case_attention_self_ref),
+    ("attention_self_ref_d80", lambda: case_attention_self_ref(d=80, lq=100, lr=70, cond_idx=0, seed=66)),
     ("attention_cross_d80", case_attention_cross),
     ("attention_cross_d40", lambda: case_attention_cross(d=40, seed=71)),
     ("attention_cross_d160", lambda: case_attention_cross(d=160, lq=64, seed=72)),

@@ -203,7 +203,7 @@ def test_denoise_loop_over_the_module(scheduler, hw, emulated):
 def test_shared_cfg_prefix_is_bit_identical_to_two_forwards(name, emulated):
     """models/runtime.PrefixMemo: the first CFG half's forward records everything in front of the first text cross-attention, the
     second half's forward replays it.  Checked on the emulated kernels: both halves' outputs are bit-identical to two independent
-    batch-1 forwards; the `musev` flavour really shares (conv_in, transformer_in, the first resnet / temporal conv, the first
+    batch-1 forwards; the `musev` flavour really shares (the timestep / frame embeddings and their projections, conv_in, transformer_in, the first resnet / temporal conv, the first
     block's self-attention and query); flavours / calls whose front depends on per-half tensors (ReferenceNet features,
     refer_self_attn_emb) share only what precedes them."""
     from oracle import unet3d
@@ -241,7 +241,7 @@ def test_shared_cfg_prefix_is_bit_identical_to_two_forwards(name, emulated):
     if name == "musev_hipw":
         assert memo.hits == len(memo.store) >= 5, (memo.hits, list(memo.store))
     elif name == "refnet_hipw":
-        assert memo.hits == len(memo.store) == 1   # conv_in only: the ReferenceNet features come per half right behind it
+        assert memo.hits == len(memo.store) == 2   # the embeddings and conv_in only: the ReferenceNet features come per half right behind
 
 
 @pytest.mark.parametrize("one_half_per_forward", [True, False])

@@ -55,6 +55,7 @@ CASES = {
     "groupnorm_one_launch_reread": "kc.case_groupnorm(n=1, rows=2100, c1=1024, silu=False)",     # > 8 rows per thread: second pass re-reads
     "layernorm": "kc.case_layernorm(rows=99, c=64)",
     "attention_self": "kc.case_attention_self(d=40, b=1, t=2, lq=70, cond_idx=1)",
+    "attention_self_ref": "kc.case_attention_self_ref(d=40, b=1, t=2, lq=70, lr=40, cond_idx=1)",
     "attention_groups": "kc.case_attention_groups(d=40, nb=4, t=2, lq=70)",
     "gemm_weight_stationary": "kc.case_gemm_weight_stationary(M=200, N=640, K=128)",
     "gemm_weight_stationary_split": "kc.case_gemm_weight_stationary(M=130, N=640, K=1024, splitk=4, seed=885)",
@@ -108,7 +109,7 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "upsample_nearest", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
+    default = ("tr16_probe", "upsample_nearest", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_self_ref", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
