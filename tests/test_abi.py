@@ -142,3 +142,24 @@ def test_package_import_sets_the_hardware_queue_default_without_overriding_the_u
     assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.strip() == "8"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.strip() == "4"
+
+
+def test_timeline_tool_stamps_every_launching_entry():
+    """tools/gpu_timeline.py wraps the C-ABI entries whose last parameter is the stream (parsed from include/musev_hip.h): every one of
+    them must be an exported symbol, and every entry musev_amd.ops launches through must be among them -- a launch the tool does not
+    stamp would be missing from the step's timeline"""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gpu_timeline", os.path.join(ROOT, "tools", "gpu_timeline.py"))
+    tl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tl)
+    entries = tl.launch_entries()
+    from musev_amd import _lib
+    lib = _lib.load()
+    for name in entries:
+        assert hasattr(lib, name), name
+    src = open(os.path.join(ROOT, "musev_amd", "ops.py")).read()
+    used = set(re.findall(r"\.(mv_\w+)\(", src))
+    host_only = {"mv_attention_resident_ok", "mv_gemm_choice", "mv_gemm_stats_layout", "mv_gemm_workspace_bytes", "mv_groupnorm_default_nsplit"}
+    assert used - host_only <= set(entries), sorted(used - host_only - set(entries))   # (host-side queries launch nothing)
+    assert set(entries) <= used, sorted(set(entries) - used)
