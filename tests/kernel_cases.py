@@ -1161,6 +1161,9 @@ AT_SIZE_CASES: List[Tuple[str, Callable[[], Dict]]] = [
     ("tconv_l3", lambda: case_tconv3(b=2, t=13, hw=64, c=1280, seed=222)),                       # M 1664, K 3840: split-K
     ("tconv_l3_half", lambda: case_tconv3(b=1, t=13, hw=64, c=1280, seed=223)),
     ("attention_level0", case_attention_level0),
+    # config 3's level-0 reference-only self-attention: own frame | condition frame | ReferenceNet tokens = 12 288 keys; frame 0 is the
+    # condition frame itself (its duplicate segment is not walked, the ReferenceNet tokens keep their weight)
+    ("attention_level0_refnet_tokens", lambda: case_attention_self_ref(d=40, b=1, t=2, lq=4096, lr=4096, cond_idx=0, seed=67)),
     ("attention_groups_l0_half", lambda: case_attention_groups(d=40, nb=13, t=13, lq=4096, seed=78)),   # level-0 cross attention, one CFG half
     ("attention_groups_l1_half", lambda: case_attention_groups(d=80, nb=13, t=13, lq=1024, seed=79)),
     ("tsa_block_l0_half", lambda: case_tsa_block(b=1, t=13, hw=4096, seed=750)),   # one CFG half of a level-0 temporal sub-block
