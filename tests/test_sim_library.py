@@ -109,8 +109,9 @@ def sim_so(tmp_path_factory):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "upsample_nearest", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self", "attention_self_ref", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
+    default = ("tr16_probe", "upsample_nearest", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self_ref", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
                "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
+    # ("attention_self" -- two segments -- is covered by "attention_self_ref": the same duplicate-segment path + a third segment)
     if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
     code = _RUNNER.format(root=sim_lib.ROOT, here=HERE, so=sim_so, expr=CASES[name])
