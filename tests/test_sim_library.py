@@ -107,17 +107,43 @@ def sim_so(tmp_path_factory):
     return sim_lib.build(tmp_path_factory.mktemp("sim_lib"))
 
 
+_DEFAULT = ("tr16_probe", "upsample_nearest", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self_ref", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
+            "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
+# ("attention_self" -- two segments -- is covered by "attention_self_ref": the same duplicate-segment path + a third segment)
+
+
+def _run_case(so, name):
+    code = _RUNNER.format(root=sim_lib.ROOT, here=HERE, so=so, expr=CASES[name])
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        return r.returncode, r.stdout, r.stderr
+    except subprocess.TimeoutExpired as ex:
+        return -9, "", f"timed out: {ex}"
+
+
+@pytest.fixture(scope="module")
+def case_results(sim_so, request):
+    """every SELECTED case of this module, run once, four child processes at a time (each case is its own interpreter on the simulated
+    library, two torch threads: the cases are independent, and one after the other they were half of the CPU suite's time)"""
+    from concurrent.futures import ThreadPoolExecutor
+    full = bool(os.environ.get("MUSEV_SIM_FULL"))
+    names = []
+    for it in request.session.items:
+        if getattr(it, "originalname", "") == "test_kernel_case_through_the_simulated_library":
+            n = it.callspec.params["name"]
+            if (full or n in _DEFAULT) and n not in names:
+                names.append(n)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        return dict(zip(names, pool.map(lambda n: _run_case(sim_so, n), names)))
+
+
 @pytest.mark.parametrize("name", list(CASES))
-def test_kernel_case_through_the_simulated_library(sim_so, name):
-    default = ("tr16_probe", "upsample_nearest", "gemm", "gemm_geglu", "gemm_ln", "gemm_ln_geglu", "colstats_conv_two_src_seam", "colstats_tconv", "gn_fold_linear_spatial", "gn_fold_linear_temporal", "carry_linear", "carry_conv", "carry_tconv", "carry_256x320", "ffn_fused", "tail_carry", "conv3x3_two_src", "tconv3", "groupnorm_two_src", "groupnorm_one_launch", "groupnorm_one_launch_16_waves", "groupnorm_one_launch_reread", "layernorm", "attention_self_ref", "attention_groups", "attention_resident", "attention_resident_text_ip", "attention_resident_5_heads", "gemm_weight_stationary", "tsa_block", "xab_block", "xab_block_ragged_5_keys",
-               "temporal_attention", "temporal_attention_d160_t4", "window_loop", "cfg_affine_step")
-    # ("attention_self" -- two segments -- is covered by "attention_self_ref": the same duplicate-segment path + a third segment)
-    if name not in default and not os.environ.get("MUSEV_SIM_FULL"):
+def test_kernel_case_through_the_simulated_library(case_results, name):
+    if name not in _DEFAULT and not os.environ.get("MUSEV_SIM_FULL"):
         pytest.skip("the default CPU suite runs a representative subset (suite time); MUSEV_SIM_FULL=1 runs every case")
-    code = _RUNNER.format(root=sim_lib.ROOT, here=HERE, so=sim_so, expr=CASES[name])
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
-    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    rc, out, err = case_results[name]
+    assert rc == 0, (rc, err[-1500:])
+    line = [ln for ln in out.splitlines() if ln.startswith("RESULT ")][-1]
     res = json.loads(line[len("RESULT "):])
     assert res["ok"], res
 
