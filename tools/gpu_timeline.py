@@ -59,7 +59,13 @@ def main():
     import torch
     from musev_amd import _lib
     lib = _lib.load()
-    ts = C.CDLL(os.path.join(ROOT, "tools", "scratch", "libmvts.so"))
+    so = os.path.join(ROOT, "tools", "scratch", "libmvts.so")
+    if not os.path.exists(so):   # the stamp kernel (tool code, not part of libmusev_hip): built on first use
+        import subprocess
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so,
+                        os.path.join(ROOT, "tools", "timeline_ts.hip")], check=True)
+    ts = C.CDLL(so)
     ts.mvts_record.restype = C.c_int
     ts.mvts_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     nslots = 1 << 20
