@@ -45,7 +45,7 @@ GEMM_RECORD: Optional[list] = None
 #   MUSEV_GEMM_SPLITK  0 = library's choice (default); >= 1 = that many K slices where the workspace cap allows
 #   MUSEV_OPS          "NAME=VALUE,..." sets module switches of this file by name at import (same-box A/B legs of tools/gpu_ab.sh:
 #                      COLSTATS, CARRY, CARRY_MAX_C, FFN_FUSED, FFN_ROTATE, TSA_FUSED, LN_FOLD, LN_FOLD_MAX_K, ATTN_GROUPS, XATTN_RESIDENT,
-#                      GEMM_WEIGHT_STATIONARY, GN_FOLD, GN_FOLD_MAX_RATIO, XAB_FUSED); applied at the bottom of this file.  The per-feature variables of earlier rounds
+#                      XATTN_RESIDENT_MAX_D, GEMM_WEIGHT_STATIONARY, GN_FOLD, GN_FOLD_MAX_RATIO, XAB_FUSED); applied at the bottom of this file.  The per-feature variables of earlier rounds
 #                      (MUSEV_CARRY, MUSEV_SHARE_PREFIX, MUSEV_XATTN_RESIDENT, MUSEV_GEMM_WEIGHT_STATIONARY, ...) are gone: setting one
 #                      raises at import, so that an A/B leg written from an old example cannot silently measure the baseline twice.
 GEMM_CFG: int = int(os.environ.get("MUSEV_GEMM_CFG", "-1"))
@@ -705,6 +705,11 @@ ATTN_GROUPS: bool = True
 # many query rows per block instead of the launcher's choice (tools/gpu_xattn_bench.py sweeps it).
 XATTN_RESIDENT: int = 1
 XATTN_RESIDENT_HITS: int = 0
+# ... up to this head dim.  Round 6, rotated same-box A/B legs of the whole step (profiles/r06zp ... r06zs): at d = 80 (level 1: the kernels
+# are equal alone, 20.7 against 22.6 us) the tiled kernel is worth -0.2 ms per config-2 step (-0.10 / -0.21 / -0.23 on three boxes): the
+# resident kernel's 512-thread blocks wait longer for a compute unit beside the other half's one-block-per-CU tiles.  Level 0 (d = 40)
+# keeps it (35.5 against 64.6 us with the IP-Adapter group).  A/B: MUSEV_OPS="XATTN_RESIDENT_MAX_D=80".
+XATTN_RESIDENT_MAX_D: int = 40
 
 
 def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int, d: int, scale: float, *,
@@ -740,7 +745,7 @@ def attention(q: torch.Tensor, segs: Sequence[Seg], nb: int, lq: int, heads: int
             if group_scales[i] is not None:
                 s.new_group, s.group_scale = 1, float(group_scales[i])
     lib = _lib.load()
-    if XATTN_RESIDENT and not accumulate and lib.mv_attention_resident_ok(C.byref(ds)):
+    if XATTN_RESIDENT and d <= XATTN_RESIDENT_MAX_D and not accumulate and lib.mv_attention_resident_ok(C.byref(ds)):
         global XATTN_RESIDENT_HITS
         XATTN_RESIDENT_HITS += 1
         ds.resident_kv = max(1, int(XATTN_RESIDENT))
@@ -1041,7 +1046,7 @@ def _apply_env_overrides() -> None:
     for item in filter(None, (x.strip() for x in spec.split(","))):
         name, _, val = item.partition("=")
         if name not in ("COLSTATS", "CARRY", "CARRY_MAX_C", "FFN_FUSED", "FFN_ROTATE", "LN_FOLD", "ATTN_GROUPS", "XATTN_RESIDENT",
-                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K", "GN_FOLD", "GN_FOLD_MAX_RATIO", "XAB_FUSED"):
+                        "GEMM_WEIGHT_STATIONARY", "TSA_FUSED", "LN_FOLD_MAX_K", "GN_FOLD", "GN_FOLD_MAX_RATIO", "XAB_FUSED", "XATTN_RESIDENT_MAX_D"):
             raise ValueError(f"MUSEV_OPS: unknown switch {name!r}")
         cur = globals()[name]
         globals()[name] = bool(int(val)) if isinstance(cur, bool) else float(val) if isinstance(cur, float) else int(val)

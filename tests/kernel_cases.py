@@ -691,15 +691,16 @@ def case_attention_resident(d=40, nb=6, t=3, lq=130, lk=77, seed=77, groups=True
             ref = ref + 0.4 * _attn_ref(q3, kvf[:, :c].reshape(b, 16, c)[bidx], kvf[:, c:].reshape(b, 16, c)[bidx], heads, d, scale)
     else:
         segs, gs = [(k, v, lk, t, 1, 0)], None
-    flag, hits = ops.XATTN_RESIDENT, ops.XATTN_RESIDENT_HITS
+    flag, hits, max_d = ops.XATTN_RESIDENT, ops.XATTN_RESIDENT_HITS, ops.XATTN_RESIDENT_MAX_D
     try:
         ops.XATTN_RESIDENT = rows   # True / 1: the launcher's rows per block; >= 16: that many
+        ops.XATTN_RESIDENT_MAX_D = 80   # (the model takes the kernel at d = 40 only since round 6; the d = 80 form stays in the library and is tested)
         got = ops.attention(q, segs, nb, lq, heads, d, scale, group_scales=gs)
         took = ops.XATTN_RESIDENT_HITS == hits + 1
         ops.XATTN_RESIDENT = False
         tiled = ops.attention(q, segs, nb, lq, heads, d, scale, group_scales=gs)
     finally:
-        ops.XATTN_RESIDENT = flag
+        ops.XATTN_RESIDENT, ops.XATTN_RESIDENT_MAX_D = flag, max_d
     name = f"attention resident d{d} nb{nb} lq{lq} lk{lk} groups{int(groups)}"
     if not took:
         return {"name": name, "ok": False, "max_abs_err": float("nan"), "detail": "the launch did not take the resident-K/V kernel"}

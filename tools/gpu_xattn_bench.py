@@ -15,6 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from musev_amd import ops  # noqa: E402
+ops.XATTN_RESIDENT_MAX_D = 80   # (the model's default is 40 since round 6: this tool measures the kernel at both head dims)
 
 dev = torch.device("cuda", 0)
 

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from musev_amd import ops  # noqa: E402
+ops.XATTN_RESIDENT_MAX_D = 80   # (the model's default is 40 since round 6: this tool measures the kernel at both head dims)
 
 torch.set_printoptions(precision=3, linewidth=220, sci_mode=False)
 dev = torch.device("cuda", 0)
