@@ -483,8 +483,10 @@ LN_FOLD: bool = True
 # ... and only for projections with K <= LN_FOLD_MAX_K: beside the pair-timed tile table (round 5) the 1 280-wide levels run faster as
 # mv_layernorm_f16 + a plain projection on a 256 x 256 / 256 x 320 tile than folded (the folded tiles stop at 256 x 256 and carry the
 # in-loop row statistics): same-box alternating legs 49.65 -> 49.27 ms per config-2 step at 640, 49.35 with no folding at all
-# (profiles/r05zf_ab_lnfold{,2}.log; per launch of a pair 32 against 39 us at 3 328 x 3 840 x 1 280)
-LN_FOLD_MAX_K: int = 640
+# (profiles/r05zf_ab_lnfold{,2}.log; per launch of a pair 32 against 39 us at 3 328 x 3 840 x 1 280).  Round 6, 12 rotated same-box rounds
+# per leg (profiles/r06zw_*): 320 against 640 is -0.05 ms at config 2 (47.55 / 47.60), **-0.47 ms at config 3** (54.87 / 55.33), nothing at
+# config 5 (898.2 / 897.7) -- the 640-wide level folds no more either.
+LN_FOLD_MAX_K: int = 320
 _ln_fold_cache: dict = {}
 
 
